@@ -1,0 +1,122 @@
+/* ============================================================================
+ * oracle/cvo_oracle.h  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * C interface of the CPU restatement ("oracle") of CVO-SLAM's per-frame-pair
+ * CVO alignment hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (cvo_slam_amd/, include/)
+ * never includes, links or calls anything in oracle/.
+ *
+ * Parity status: PARITY UNPINNED by the reference's own tests -- the reference
+ * ships no tests, golden vectors or fixtures for this path (SURVEY.md section 4,
+ * section 8c) and cvo.cpp cannot be built here (needs Eigen, OpenCV, legacy TBB,
+ * Boost; none present).  What IS pinned against real reference code:
+ *   - the exact radius-search semantics (strict `<`, float squared-L2 expression
+ *     order, result ordering) against the reference's vendored nanoflann.hpp,
+ *     compiled from where it lies into oracle/_ref/ (oracle/ref_nanoflann.cpp);
+ *   - closed-form pieces (cubic roots, SE(3) exp / log norm, 6x6 eigen shift)
+ *     against numpy/scipy known answers (tests/golden/).
+ *
+ * Everything follows thirdparty/cvo/src/cvo.cpp and thirdparty/cvo/src/LieGroup.cpp
+ * of the reference; each function cites the file:line it restates.
+ * ========================================================================== */
+#ifndef CVO_ORACLE_H
+#define CVO_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hyper-parameters, defaults = reference ctor constants (cvo.cpp:35-51) */
+typedef struct orc_params {
+    float ell;        /* initial kernel length-scale 0.15       cvo.cpp:35 */
+    float sigma;      /* 0.1                                    cvo.cpp:36 */
+    float sp_thres;   /* 8e-3                                   cvo.cpp:37 */
+    float c;          /* 7.0                                    cvo.cpp:38 */
+    float d;          /* 7.0                                    cvo.cpp:39 */
+    float c_ell;      /* 200                                    cvo.cpp:41 */
+    float c_sigma;    /* 1                                      cvo.cpp:42 */
+    int   max_iter;   /* 2000                                   cvo.cpp:48 */
+    float min_step;   /* 0.2                                    cvo.cpp:49 */
+    float eps;        /* 5e-5                                   cvo.cpp:50 */
+    float eps_2;      /* 1e-5                                   cvo.cpp:51 */
+} orc_params;
+
+/* inn_p (cvo.hpp:52-80) */
+typedef struct orc_inn_p { float value; int num; int num_e; } orc_inn_p;
+
+/* one row per align() iteration, for per-iteration parity */
+typedef struct orc_trace_row {
+    float  omega[3];
+    float  v[3];
+    int    nnz;
+    double B, C, D, E;
+    float  step;
+    float  ell;       /* ell used by this iteration */
+    float  dist;      /* dist_se3(dR,dT); -1 if stop A fired before the update */
+} orc_trace_row;
+
+typedef struct orc_cvo orc_cvo;   /* opaque: one reference `cvo::cvo` object */
+
+enum { ORC_SEARCH_BRUTE = 0, ORC_SEARCH_KDTREE = 1 };
+enum { ORC_SLOT_FIXED = 0, ORC_SLOT_MOVING = 1, ORC_SLOT_PREVIOUS = 2 };
+
+void     orc_default_params(orc_params* p);
+orc_cvo* orc_create(const orc_params* p);                 /* cvo::cvo ctor  cvo.cpp:18-71 */
+void     orc_destroy(orc_cvo* o);
+/* search mode + thread count of the row loops (the TBB parallel_for stand-in) */
+void     orc_set_exec(orc_cvo* o, int search_mode, int threads);
+
+/* set_pcd (cvo.cpp:345-386) with the pcd_generator output handed in directly:
+ * xyz = n x 3 AoS (cloud_t, data_type.h:30), feat = 5 channel-major arrays of n
+ * (Eigen col-major Matrix<float,Dynamic,5>, data_type.h:75). */
+int  orc_set_pcd(orc_cvo* o, const float* xyz, const float* feat, int n);
+int  orc_align(orc_cvo* o, orc_trace_row* trace, int trace_cap, int* trace_len);   /* cvo.cpp:763-821 */
+int  orc_match(orc_cvo* o, const float* xyz, const float* feat, int n, double transform_out[12]); /* match_odometry / match_keyframe cvo.cpp:461-473,563-576 */
+
+void orc_update_fixed_pcd(orc_cvo* o);                    /* cvo.cpp:578-582 */
+void orc_update_previous_pcd(orc_cvo* o);                 /* cvo.cpp:584-589 */
+void orc_reset_keyframe(orc_cvo* o, const float odom[12]);/* cvo.cpp:591-604 */
+void orc_reset_transform(orc_cvo* o, const float odom[12]);/* cvo.cpp:606-609 */
+void orc_reset_initial(orc_cvo* o, const float odom[12], float out[12]); /* cvo.cpp:611-618 */
+
+/* function_inner_product / se3_Hessian on (slot a, optional 3x4 row-major
+ * transform applied to a's positions) vs slot b.   cvo.cpp:388-459, 620-759 */
+int  orc_function_inner_product(orc_cvo* o, int slot_a, const float* tran_a, int slot_b, orc_inn_p* out);
+int  orc_se3_hessian(orc_cvo* o, int slot_a, const float* tran_a, int slot_b,
+                     double H[36], int* inliers, double H_raw_f64[36]);
+/* compute_innerproduct cvo.cpp:475-503 */
+int  orc_compute_innerproduct(orc_cvo* o, orc_inn_p* pre, orc_inn_p* post, double H[36],
+                              const float tran[12], int* inliers, orc_inn_p* inn_fixed,
+                              orc_inn_p* inn_moving, float* cos_angle);
+/* compute_innerproduct_lc cvo.cpp:505-561 */
+int  orc_compute_innerproduct_lc(orc_cvo* o, orc_inn_p* prior, orc_inn_p* lc_prior, orc_inn_p* lc_pre,
+                                 orc_inn_p* lc_post, double H[36], const float prior_tran[12],
+                                 const float lc_prior_tran[12], const float lc_prior_tran_2[12],
+                                 const float lc_tran[12], int* inliers_svd, int* inliers_pnp,
+                                 orc_inn_p* inn_fixed, orc_inn_p* inn_moving, float* cos_angle);
+
+/* state access (public members + getters, cvo.hpp:139-144,268-270) */
+void orc_get_state(const orc_cvo* o, float R[9], float T[3], float* ell, float transform[12],
+                   int* iter, int* A_nonzero, int* num_fixed, int* num_moving);
+void orc_set_state(orc_cvo* o, const float R[9], const float T[3], float ell);
+void orc_get_accum(const orc_cvo* o, float prev_transform[12], float accum_transform[12]);
+int  orc_get_init(const orc_cvo* o);
+
+/* one iteration's pieces, exposed for kernel-level parity */
+int  orc_flow_once(orc_cvo* o, float omega[3], float v[3], int* nnz, double BCDE[4], float* step,
+                   int* csr_rowptr /* nf+1 or NULL */, int* csr_col /* cap or NULL */,
+                   float* csr_val /* cap or NULL */, int csr_cap);
+
+/* closed-form pieces */
+float orc_cubic_step(float c3, float c2, float c1, float c0, float min_step);   /* cvo.cpp:76-92,317-333 */
+void  orc_exp_sek3(const float omega[3], const float v[3], float dt, float dR[9], float dT[3]); /* LieGroup.cpp:159-186 */
+float orc_dist_se3(const float dR[9], const float dT[3]);                        /* cvo.cpp:94-104 */
+void  orc_hessian_regularize(const float Hin[36], int inliers, double Hout[36]); /* cvo.cpp:726-758 */
+/* exact radius search used by ORC_SEARCH_KDTREE, for cross-checking vs brute force and nanoflann */
+int   orc_radius_search(const float* cloud_xyz, int n, const float* query, float radius_sq,
+                        int* out_idx, float* out_d2, int cap, int use_kdtree);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

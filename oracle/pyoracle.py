@@ -1,0 +1,254 @@
+"""ctypes binding of oracle/libcvo_oracle.so -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcvo_oracle.so")
+REF_LIB_PATH = os.path.join(HERE, "_ref", "libref_nanoflann.so")
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and oracle/_ref when /root/reference exists)."""
+    src = os.path.join(HERE, "cvo_oracle.cpp")
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(
+        os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "cvo_oracle.h")))
+    if force or stale:
+        subprocess.check_call(["make", "-C", HERE, "-s", os.path.join(HERE, "libcvo_oracle.so")])
+    if os.path.exists("/root/reference/thirdparty/cvo/thirdparty/nanoflann.hpp") and (force or not os.path.exists(REF_LIB_PATH)):
+        subprocess.check_call(["make", "-C", HERE, "-s", "ref"])
+
+
+class Params(C.Structure):
+    _fields_ = [("ell", C.c_float), ("sigma", C.c_float), ("sp_thres", C.c_float), ("c", C.c_float), ("d", C.c_float),
+                ("c_ell", C.c_float), ("c_sigma", C.c_float), ("max_iter", C.c_int), ("min_step", C.c_float),
+                ("eps", C.c_float), ("eps_2", C.c_float)]
+
+
+class InnP(C.Structure):
+    _fields_ = [("value", C.c_float), ("num", C.c_int), ("num_e", C.c_int)]
+
+
+class TraceRow(C.Structure):
+    _fields_ = [("omega", C.c_float * 3), ("v", C.c_float * 3), ("nnz", C.c_int), ("B", C.c_double), ("C", C.c_double),
+                ("D", C.c_double), ("E", C.c_double), ("step", C.c_float), ("ell", C.c_float), ("dist", C.c_float)]
+
+
+SEARCH_BRUTE, SEARCH_KDTREE = 0, 1
+SLOT_FIXED, SLOT_MOVING, SLOT_PREVIOUS = 0, 1, 2
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        fp = C.POINTER(C.c_float); dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int)
+        L.orc_default_params.argtypes = [C.POINTER(Params)]
+        L.orc_create.argtypes = [C.POINTER(Params)]; L.orc_create.restype = C.c_void_p
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_exec.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_set_pcd.argtypes = [C.c_void_p, fp, fp, C.c_int]
+        L.orc_align.argtypes = [C.c_void_p, C.POINTER(TraceRow), C.c_int, ip]
+        L.orc_match.argtypes = [C.c_void_p, fp, fp, C.c_int, dp]
+        for name in ("orc_update_fixed_pcd", "orc_update_previous_pcd"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc_reset_keyframe.argtypes = [C.c_void_p, fp]
+        L.orc_reset_transform.argtypes = [C.c_void_p, fp]
+        L.orc_reset_initial.argtypes = [C.c_void_p, fp, fp]
+        L.orc_function_inner_product.argtypes = [C.c_void_p, C.c_int, fp, C.c_int, C.POINTER(InnP)]
+        L.orc_se3_hessian.argtypes = [C.c_void_p, C.c_int, fp, C.c_int, dp, ip, dp]
+        L.orc_compute_innerproduct.argtypes = [C.c_void_p, C.POINTER(InnP), C.POINTER(InnP), dp, fp, ip,
+                                               C.POINTER(InnP), C.POINTER(InnP), fp]
+        L.orc_compute_innerproduct_lc.argtypes = [C.c_void_p] + [C.POINTER(InnP)] * 4 + [dp, fp, fp, fp, fp, ip, ip,
+                                                                                          C.POINTER(InnP), C.POINTER(InnP), fp]
+        L.orc_get_state.argtypes = [C.c_void_p, fp, fp, fp, fp, ip, ip, ip, ip]
+        L.orc_set_state.argtypes = [C.c_void_p, fp, fp, C.c_float]
+        L.orc_get_accum.argtypes = [C.c_void_p, fp, fp]
+        L.orc_get_init.argtypes = [C.c_void_p]
+        L.orc_flow_once.argtypes = [C.c_void_p, fp, fp, ip, dp, fp, ip, ip, fp, C.c_int]
+        L.orc_cubic_step.argtypes = [C.c_float] * 5; L.orc_cubic_step.restype = C.c_float
+        L.orc_exp_sek3.argtypes = [fp, fp, C.c_float, fp, fp]
+        L.orc_dist_se3.argtypes = [fp, fp]; L.orc_dist_se3.restype = C.c_float
+        L.orc_hessian_regularize.argtypes = [fp, C.c_int, dp]
+        L.orc_radius_search.argtypes = [fp, C.c_int, fp, C.c_float, ip, fp, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """oracle/_ref/libref_nanoflann.so (the reference's own nanoflann), or None."""
+    if not os.path.exists(REF_LIB_PATH):
+        return None
+    L = C.CDLL(REF_LIB_PATH)
+    fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int)
+    L.ref_radius_search.argtypes = [fp, C.c_int, fp, C.c_int, C.c_float, ip, ip, fp, C.c_int]
+    return L
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_params() -> Params:
+    p = Params(); lib().orc_default_params(C.byref(p)); return p
+
+
+class OracleCvo:
+    """The reference's `cvo::cvo` (cvo.hpp:82-282) with pcd_generator output handed in."""
+
+    def __init__(self, params: Params | None = None, search=SEARCH_BRUTE, threads=1):
+        self.L = lib()
+        self.params = params or default_params()
+        self.h = C.c_void_p(self.L.orc_create(C.byref(self.params)))
+        self.L.orc_set_exec(self.h, search, threads)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_destroy(self.h); self.h = None
+        except Exception:
+            pass
+
+    def set_exec(self, search, threads):
+        self.L.orc_set_exec(self.h, search, threads)
+
+    def set_pcd(self, xyz, feat):
+        x, xp = _f(xyz); f, fp_ = _f(feat)
+        assert x.shape[1] == 3 and f.shape[0] == 5 and f.shape[1] == x.shape[0]
+        return self.L.orc_set_pcd(self.h, xp, fp_, x.shape[0])
+
+    def align(self, trace_cap=0):
+        if trace_cap:
+            rows = (TraceRow * trace_cap)(); n = C.c_int(0)
+            rc = self.L.orc_align(self.h, rows, trace_cap, C.byref(n))
+            tr = [dict(omega=np.array(r.omega[:], np.float32), v=np.array(r.v[:], np.float32), nnz=r.nnz,
+                       BCDE=np.array([r.B, r.C, r.D, r.E]), step=r.step, ell=r.ell, dist=r.dist) for r in rows[: n.value]]
+            return rc, tr
+        return self.L.orc_align(self.h, None, 0, None), None
+
+    def match(self, xyz, feat):
+        x, xp = _f(xyz); f, fp_ = _f(feat)
+        out = np.zeros(12, np.float64)
+        rc = self.L.orc_match(self.h, xp, fp_, x.shape[0], out.ctypes.data_as(C.POINTER(C.c_double)))
+        return rc, out.reshape(3, 4)
+
+    def update_fixed_pcd(self): self.L.orc_update_fixed_pcd(self.h)
+    def update_previous_pcd(self): self.L.orc_update_previous_pcd(self.h)
+
+    def reset_keyframe(self, odom):
+        o, op = _f(np.asarray(odom).reshape(12)); self.L.orc_reset_keyframe(self.h, op)
+
+    def reset_transform(self, odom):
+        o, op = _f(np.asarray(odom).reshape(12)); self.L.orc_reset_transform(self.h, op)
+
+    def reset_initial(self, odom):
+        o, op = _f(np.asarray(odom).reshape(12)); out = np.zeros(12, np.float32)
+        self.L.orc_reset_initial(self.h, op, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out.reshape(3, 4)
+
+    def function_inner_product(self, slot_a, tran_a, slot_b):
+        r = InnP()
+        tp = None
+        if tran_a is not None:
+            t, tp = _f(np.asarray(tran_a).reshape(12))
+        rc = self.L.orc_function_inner_product(self.h, slot_a, tp, slot_b, C.byref(r))
+        return rc, (r.value, r.num, r.num_e)
+
+    def se3_hessian(self, slot_a, tran_a, slot_b):
+        H = np.zeros(36); Hraw = np.zeros(36); inl = C.c_int(0)
+        tp = None
+        if tran_a is not None:
+            t, tp = _f(np.asarray(tran_a).reshape(12))
+        dp = C.POINTER(C.c_double)
+        rc = self.L.orc_se3_hessian(self.h, slot_a, tp, slot_b, H.ctypes.data_as(dp), C.byref(inl), Hraw.ctypes.data_as(dp))
+        return rc, H.reshape(6, 6), inl.value, Hraw.reshape(6, 6)
+
+    def compute_innerproduct(self, tran):
+        pre, post, fx, mv = InnP(), InnP(), InnP(), InnP()
+        H = np.zeros(36); inl = C.c_int(0); cos = C.c_float(0)
+        t, tp = _f(np.asarray(tran).reshape(12))
+        rc = self.L.orc_compute_innerproduct(self.h, C.byref(pre), C.byref(post), H.ctypes.data_as(C.POINTER(C.c_double)), tp,
+                                             C.byref(inl), C.byref(fx), C.byref(mv), C.byref(cos))
+        tup = lambda r: (r.value, r.num, r.num_e)
+        return rc, dict(inn_pre=tup(pre), inn_post=tup(post), post_hessian=H.reshape(6, 6), inliers=inl.value,
+                        inn_fixed_pcd=tup(fx), inn_moving_pcd=tup(mv), cos_angle=cos.value)
+
+    def compute_innerproduct_lc(self, prior_tran, lc_prior_tran, lc_prior_tran_2, lc_tran):
+        prior, lcp, lcpre, lcpost, fx, mv = (InnP() for _ in range(6))
+        H = np.zeros(36); i1 = C.c_int(0); i2 = C.c_int(0); cos = C.c_float(0)
+        keep = [_f(np.asarray(t).reshape(12)) for t in (prior_tran, lc_prior_tran, lc_prior_tran_2, lc_tran)]
+        rc = self.L.orc_compute_innerproduct_lc(self.h, C.byref(prior), C.byref(lcp), C.byref(lcpre), C.byref(lcpost),
+                                                H.ctypes.data_as(C.POINTER(C.c_double)), keep[0][1], keep[1][1], keep[2][1], keep[3][1],
+                                                C.byref(i1), C.byref(i2), C.byref(fx), C.byref(mv), C.byref(cos))
+        tup = lambda r: (r.value, r.num, r.num_e)
+        return rc, dict(inn_prior=tup(prior), inn_lc_prior=tup(lcp), inn_lc_pre=tup(lcpre), inn_lc_post=tup(lcpost),
+                        post_hessian=H.reshape(6, 6), inliers_svd=i1.value, inliers_pnpransac=i2.value,
+                        inn_fixed_pcd=tup(fx), inn_moving_pcd=tup(mv), cos_angle=cos.value)
+
+    def get_state(self):
+        R = np.zeros(9, np.float32); T = np.zeros(3, np.float32); tf = np.zeros(12, np.float32)
+        ell = C.c_float(0); it = C.c_int(0); nnz = C.c_int(0); nf = C.c_int(0); nm = C.c_int(0)
+        fp = C.POINTER(C.c_float)
+        self.L.orc_get_state(self.h, R.ctypes.data_as(fp), T.ctypes.data_as(fp), C.byref(ell), tf.ctypes.data_as(fp),
+                             C.byref(it), C.byref(nnz), C.byref(nf), C.byref(nm))
+        return dict(R=R.reshape(3, 3), T=T, ell=ell.value, transform=tf.reshape(3, 4), iter=it.value, A_nonzero=nnz.value,
+                    num_fixed=nf.value, num_moving=nm.value)
+
+    def set_state(self, R, T, ell):
+        r, rp = _f(np.asarray(R).reshape(9)); t, tp = _f(np.asarray(T).reshape(3))
+        self.L.orc_set_state(self.h, rp, tp, float(ell))
+
+    def flow_once(self, want_csr=False, csr_cap=0):
+        om = np.zeros(3, np.float32); v = np.zeros(3, np.float32); nnz = C.c_int(0); bcde = np.zeros(4); step = C.c_float(0)
+        fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int)
+        st = self.get_state()
+        if want_csr:
+            rowptr = np.zeros(st["num_fixed"] + 1, np.int32); col = np.zeros(csr_cap, np.int32); val = np.zeros(csr_cap, np.float32)
+            rc = self.L.orc_flow_once(self.h, om.ctypes.data_as(fp), v.ctypes.data_as(fp), C.byref(nnz),
+                                      bcde.ctypes.data_as(C.POINTER(C.c_double)), C.byref(step),
+                                      rowptr.ctypes.data_as(ip), col.ctypes.data_as(ip), val.ctypes.data_as(fp), csr_cap)
+            return rc, dict(omega=om, v=v, nnz=nnz.value, BCDE=bcde, step=step.value, rowptr=rowptr, col=col[: nnz.value], val=val[: nnz.value])
+        rc = self.L.orc_flow_once(self.h, om.ctypes.data_as(fp), v.ctypes.data_as(fp), C.byref(nnz),
+                                  bcde.ctypes.data_as(C.POINTER(C.c_double)), C.byref(step), None, None, None, 0)
+        return rc, dict(omega=om, v=v, nnz=nnz.value, BCDE=bcde, step=step.value)
+
+
+def cubic_step(c3, c2, c1, c0, min_step=0.2):
+    return float(lib().orc_cubic_step(c3, c2, c1, c0, min_step))
+
+
+def exp_sek3(omega, v, dt):
+    o, op = _f(omega); vv, vp = _f(v); dR = np.zeros(9, np.float32); dT = np.zeros(3, np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().orc_exp_sek3(op, vp, float(dt), dR.ctypes.data_as(fp), dT.ctypes.data_as(fp))
+    return dR.reshape(3, 3), dT
+
+
+def dist_se3(dR, dT):
+    r, rp = _f(np.asarray(dR).reshape(9)); t, tp = _f(dT)
+    return float(lib().orc_dist_se3(rp, tp))
+
+
+def hessian_regularize(H, inliers):
+    h, hp = _f(np.asarray(H).reshape(36)); out = np.zeros(36)
+    lib().orc_hessian_regularize(hp, int(inliers), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out.reshape(6, 6)
+
+
+def radius_search(cloud_xyz, query, r2, use_kdtree, cap=4096):
+    c, cp = _f(cloud_xyz); q, qp = _f(query)
+    idx = np.zeros(cap, np.int32); d2 = np.zeros(cap, np.float32)
+    n = lib().orc_radius_search(cp, c.shape[0], qp, float(r2), idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                d2.ctypes.data_as(C.POINTER(C.c_float)), cap, int(use_kdtree))
+    return idx[:n], d2[:n]
