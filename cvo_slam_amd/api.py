@@ -1,0 +1,353 @@
+"""ctypes binding of libcvo_hip.so, mirroring the reference's `cvo::cvo` interface
+(thirdparty/cvo/include/cvo.hpp:216-276): same method names, argument meaning and
+error behaviour, with the pcd_generator output (positions + features) handed in
+where the reference takes the RGB / depth images.
+
+Every call goes through the C ABI of include/cvo_hip.h.  There is no fallback: a
+missing library raises at load time, a missing gfx950 device raises CvoError on the
+first call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CVO_OK, CVO_ERR_NOT_INITIALIZED, CVO_ERR_EMPTY_CLOUD, CVO_ERR_HIP, CVO_ERR_INVALID, CVO_ERR_NO_DEVICE, CVO_ERR_TIMEOUT = range(7)
+SLOT_FIXED, SLOT_MOVING, SLOT_PREVIOUS = 0, 1, 2
+RESULT_FLOATS = 16
+
+
+class CvoError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libcvo_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("ell", C.c_float), ("sigma", C.c_float), ("sp_thres", C.c_float), ("c", C.c_float), ("d", C.c_float),
+                ("c_ell", C.c_float), ("c_sigma", C.c_float), ("max_iter", C.c_int), ("min_step", C.c_float),
+                ("eps", C.c_float), ("eps_2", C.c_float)]
+
+
+class InnP(C.Structure):
+    _fields_ = [("value", C.c_float), ("num", C.c_int), ("num_e", C.c_int)]
+
+
+class TraceRow(C.Structure):
+    _fields_ = [("omega", C.c_float * 3), ("v", C.c_float * 3), ("nnz", C.c_int), ("candidates", C.c_int),
+                ("B", C.c_double), ("C", C.c_double), ("D", C.c_double), ("E", C.c_double),
+                ("step", C.c_float), ("ell", C.c_float), ("dist", C.c_float), ("pad_", C.c_int)]
+
+
+class PairResult(C.Structure):
+    _fields_ = [("transform", C.c_float * 12), ("R", C.c_float * 9), ("T", C.c_float * 3), ("ell", C.c_float),
+                ("iter", C.c_int), ("A_nonzero", C.c_int), ("iterations_run", C.c_int), ("status", C.c_int)]
+
+
+# every symbol include/cvo_hip.h declares (tests check the .so exports exactly these)
+ABI_SYMBOLS = [
+    "cvo_last_error", "cvo_device_count", "cvo_default_params", "cvo_create", "cvo_destroy", "cvo_set_pcd", "cvo_align",
+    "cvo_align_traced", "cvo_match_odometry", "cvo_match_keyframe", "cvo_function_inner_product", "cvo_se3_hessian",
+    "cvo_compute_innerproduct", "cvo_compute_innerproduct_lc", "cvo_update_fixed_pcd", "cvo_update_previous_pcd",
+    "cvo_reset_keyframe", "cvo_reset_transform", "cvo_reset_initial", "cvo_get_fixed_and_moving_number",
+    "cvo_get_iteration_number", "cvo_get_A_nonzero", "cvo_get_transform", "cvo_get_prev_accum_transform", "cvo_get_init",
+    "cvo_get_first_frame", "cvo_set_first_frame", "cvo_get_state", "cvo_set_state", "cvo_set_workgroups",
+    "cvo_batch_create", "cvo_batch_destroy", "cvo_batch_set_pair", "cvo_batch_set_state", "cvo_batch_set_workgroups",
+    "cvo_batch_reset_states", "cvo_batch_align_async", "cvo_batch_wait", "cvo_batch_last_launch",
+    "cvo_batch_results_to_device",
+]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "libcvo_hip.so")
+
+
+def load_library():
+    """Load libcvo_hip.so (built in-tree by cvo_slam_amd/build.py).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: build it with `python -m cvo_slam_amd.build` (hipcc, gfx950). "
+                                "There is no CPU fallback.")
+    L = C.CDLL(path)
+    fp = C.POINTER(C.c_float); dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int); vp = C.c_void_p
+    L.cvo_last_error.restype = C.c_char_p
+    L.cvo_default_params.argtypes = [C.POINTER(Params)]
+    L.cvo_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp)]
+    L.cvo_destroy.argtypes = [vp]
+    L.cvo_set_pcd.argtypes = [vp, fp, fp, C.c_int]
+    L.cvo_align.argtypes = [vp]
+    L.cvo_align_traced.argtypes = [vp, C.POINTER(TraceRow), C.c_int, ip]
+    L.cvo_match_odometry.argtypes = [vp, fp, fp, C.c_int, dp]
+    L.cvo_match_keyframe.argtypes = [vp, fp, fp, C.c_int, dp]
+    L.cvo_function_inner_product.argtypes = [vp, C.c_int, fp, C.c_int, C.POINTER(InnP)]
+    L.cvo_se3_hessian.argtypes = [vp, C.c_int, fp, C.c_int, dp, ip]
+    L.cvo_compute_innerproduct.argtypes = [vp, C.POINTER(InnP), C.POINTER(InnP), dp, fp, ip, C.POINTER(InnP), C.POINTER(InnP), fp]
+    L.cvo_compute_innerproduct_lc.argtypes = [vp] + [C.POINTER(InnP)] * 4 + [dp, fp, fp, fp, fp, ip, ip, C.POINTER(InnP), C.POINTER(InnP), fp]
+    L.cvo_update_fixed_pcd.argtypes = [vp]
+    L.cvo_update_previous_pcd.argtypes = [vp]
+    L.cvo_reset_keyframe.argtypes = [vp, fp]
+    L.cvo_reset_transform.argtypes = [vp, fp]
+    L.cvo_reset_initial.argtypes = [vp, fp, fp]
+    L.cvo_get_fixed_and_moving_number.argtypes = [vp, ip, ip]
+    L.cvo_get_iteration_number.argtypes = [vp, ip]
+    L.cvo_get_A_nonzero.argtypes = [vp, ip]
+    L.cvo_get_transform.argtypes = [vp, fp]
+    L.cvo_get_prev_accum_transform.argtypes = [vp, fp, fp]
+    L.cvo_get_init.argtypes = [vp, ip]
+    L.cvo_get_first_frame.argtypes = [vp, ip]
+    L.cvo_set_first_frame.argtypes = [vp, C.c_int]
+    L.cvo_get_state.argtypes = [vp, fp, fp, fp]
+    L.cvo_set_state.argtypes = [vp, fp, fp, C.c_float]
+    L.cvo_set_workgroups.argtypes = [vp, C.c_int]
+    L.cvo_batch_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(vp)]
+    L.cvo_batch_destroy.argtypes = [vp]
+    L.cvo_batch_set_pair.argtypes = [vp, C.c_int, fp, fp, C.c_int, fp, fp, C.c_int]
+    L.cvo_batch_set_state.argtypes = [vp, C.c_int, fp, fp, C.c_float]
+    L.cvo_batch_set_workgroups.argtypes = [vp, C.c_int]
+    L.cvo_batch_reset_states.argtypes = [vp]
+    L.cvo_batch_align_async.argtypes = [vp, C.c_int, vp]
+    L.cvo_batch_wait.argtypes = [vp, C.POINTER(PairResult), C.c_int]
+    L.cvo_batch_last_launch.argtypes = [vp, fp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.cvo_batch_results_to_device.argtypes = [vp, vp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != CVO_OK:
+        raise CvoError(rc, load_library().cvo_last_error().decode())
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _tran(t):
+    if t is None:
+        return None, None
+    return _f(np.asarray(t, dtype=np.float32).reshape(12))
+
+
+def default_params() -> Params:
+    p = Params(); _check(load_library().cvo_default_params(C.byref(p))); return p
+
+
+def device_count() -> int:
+    return int(load_library().cvo_device_count())
+
+
+def _cloud_args(xyz, feat):
+    x, xp = _f(xyz); f, fpt = _f(feat)
+    if x.ndim != 2 or x.shape[1] != 3 or f.shape != (5, x.shape[0]):
+        raise ValueError("cloud must be xyz (n,3) and feat (5,n)")
+    return x, xp, f, fpt
+
+
+class Cvo:
+    """One `cvo::cvo` object (cvo.hpp:82-282) living on a gfx950 device."""
+
+    def __init__(self, params: Params | None = None, device: int = 0):
+        self.L = load_library()
+        self.params = params or default_params()
+        self.h = C.c_void_p()
+        _check(self.L.cvo_create(C.byref(self.params), device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.cvo_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- cvo.cpp:345-386 (cloud handed in instead of RGB/depth)
+    def set_pcd(self, xyz, feat):
+        x, xp, f, fpt = _cloud_args(xyz, feat)
+        _check(self.L.cvo_set_pcd(self.h, xp, fpt, x.shape[0]))
+
+    # -- cvo.cpp:763-821
+    def align(self, trace_cap: int = 0):
+        if trace_cap:
+            rows = (TraceRow * trace_cap)(); n = C.c_int(0)
+            _check(self.L.cvo_align_traced(self.h, rows, trace_cap, C.byref(n)))
+            return [dict(omega=np.array(r.omega[:], np.float32), v=np.array(r.v[:], np.float32), nnz=r.nnz,
+                         candidates=r.candidates, BCDE=np.array([r.B, r.C, r.D, r.E]), step=r.step, ell=r.ell, dist=r.dist)
+                    for r in rows[: min(n.value, trace_cap)]]
+        _check(self.L.cvo_align(self.h))
+        return None
+
+    # -- cvo.cpp:461-473 / 563-576.  "cvo not initialized !" -> CvoError(code 1), output untouched
+    def match_odometry(self, xyz, feat):
+        x, xp, f, fpt = _cloud_args(xyz, feat); out = np.zeros(12, np.float64)
+        _check(self.L.cvo_match_odometry(self.h, xp, fpt, x.shape[0], out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.reshape(3, 4)
+
+    def match_keyframe(self, xyz, feat):
+        x, xp, f, fpt = _cloud_args(xyz, feat); out = np.zeros(12, np.float64)
+        _check(self.L.cvo_match_keyframe(self.h, xp, fpt, x.shape[0], out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.reshape(3, 4)
+
+    # -- cvo.cpp:388-459
+    def function_inner_product(self, slot_a, tran_a, slot_b):
+        r = InnP(); t, tp = _tran(tran_a)
+        _check(self.L.cvo_function_inner_product(self.h, slot_a, tp, slot_b, C.byref(r)))
+        return (r.value, r.num, r.num_e)
+
+    # -- cvo.cpp:620-759
+    def se3_hessian(self, slot_a, tran_a, slot_b, inliers: int = 0):
+        H = np.zeros(36); inl = C.c_int(inliers); t, tp = _tran(tran_a)
+        _check(self.L.cvo_se3_hessian(self.h, slot_a, tp, slot_b, H.ctypes.data_as(C.POINTER(C.c_double)), C.byref(inl)))
+        return H.reshape(6, 6), inl.value
+
+    # -- cvo.cpp:475-503
+    def compute_innerproduct(self, tran):
+        pre, post, fx, mv = InnP(), InnP(), InnP(), InnP()
+        H = np.zeros(36); inl = C.c_int(0); cos = C.c_float(0); t, tp = _tran(tran)
+        _check(self.L.cvo_compute_innerproduct(self.h, C.byref(pre), C.byref(post), H.ctypes.data_as(C.POINTER(C.c_double)), tp,
+                                               C.byref(inl), C.byref(fx), C.byref(mv), C.byref(cos)))
+        tup = lambda r: (r.value, r.num, r.num_e)
+        return dict(inn_pre=tup(pre), inn_post=tup(post), post_hessian=H.reshape(6, 6), inliers=inl.value,
+                    inn_fixed_pcd=tup(fx), inn_moving_pcd=tup(mv), cos_angle=cos.value)
+
+    # -- cvo.cpp:505-561
+    def compute_innerproduct_lc(self, prior_tran, lc_prior_tran, lc_prior_tran_2, lc_tran):
+        prior, lcp, lcpre, lcpost, fx, mv = (InnP() for _ in range(6))
+        H = np.zeros(36); i1 = C.c_int(0); i2 = C.c_int(0); cos = C.c_float(0)
+        keep = [_tran(t) for t in (prior_tran, lc_prior_tran, lc_prior_tran_2, lc_tran)]
+        _check(self.L.cvo_compute_innerproduct_lc(self.h, C.byref(prior), C.byref(lcp), C.byref(lcpre), C.byref(lcpost),
+                                                  H.ctypes.data_as(C.POINTER(C.c_double)), keep[0][1], keep[1][1], keep[2][1], keep[3][1],
+                                                  C.byref(i1), C.byref(i2), C.byref(fx), C.byref(mv), C.byref(cos)))
+        tup = lambda r: (r.value, r.num, r.num_e)
+        return dict(inn_prior=tup(prior), inn_lc_prior=tup(lcp), inn_lc_pre=tup(lcpre), inn_lc_post=tup(lcpost),
+                    post_hessian=H.reshape(6, 6), inliers_svd=i1.value, inliers_pnpransac=i2.value,
+                    inn_fixed_pcd=tup(fx), inn_moving_pcd=tup(mv), cos_angle=cos.value)
+
+    # -- cvo.cpp:578-618
+    def update_fixed_pcd(self): _check(self.L.cvo_update_fixed_pcd(self.h))
+    def update_previous_pcd(self): _check(self.L.cvo_update_previous_pcd(self.h))
+
+    def reset_keyframe(self, odometry):
+        t, tp = _tran(odometry); _check(self.L.cvo_reset_keyframe(self.h, tp))
+
+    def reset_transform(self, odometry):
+        t, tp = _tran(odometry); _check(self.L.cvo_reset_transform(self.h, tp))
+
+    def reset_initial(self, odometry):
+        t, tp = _tran(odometry); out = np.zeros(12, np.float32)
+        _check(self.L.cvo_reset_initial(self.h, tp, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out.reshape(3, 4)
+
+    # -- getters, cvo.hpp:268-270 + public members cvo.hpp:139-144
+    def get_fixed_and_moving_number(self):
+        a = C.c_int(0); b = C.c_int(0); _check(self.L.cvo_get_fixed_and_moving_number(self.h, C.byref(a), C.byref(b))); return a.value, b.value
+
+    def get_iteration_number(self):
+        a = C.c_int(0); _check(self.L.cvo_get_iteration_number(self.h, C.byref(a))); return a.value
+
+    def get_A_nonzero(self):
+        a = C.c_int(0); _check(self.L.cvo_get_A_nonzero(self.h, C.byref(a))); return a.value
+
+    @property
+    def transform(self):
+        out = np.zeros(12, np.float32); _check(self.L.cvo_get_transform(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))); return out.reshape(3, 4)
+
+    @property
+    def init(self):
+        a = C.c_int(0); _check(self.L.cvo_get_init(self.h, C.byref(a))); return bool(a.value)
+
+    @property
+    def first_frame(self):
+        a = C.c_int(0); _check(self.L.cvo_get_first_frame(self.h, C.byref(a))); return bool(a.value)
+
+    @first_frame.setter
+    def first_frame(self, v):
+        _check(self.L.cvo_set_first_frame(self.h, int(bool(v))))
+
+    def prev_accum_transform(self):
+        a = np.zeros(12, np.float32); b = np.zeros(12, np.float32); fp = C.POINTER(C.c_float)
+        _check(self.L.cvo_get_prev_accum_transform(self.h, a.ctypes.data_as(fp), b.ctypes.data_as(fp)))
+        return a.reshape(3, 4), b.reshape(3, 4)
+
+    def get_state(self):
+        R = np.zeros(9, np.float32); T = np.zeros(3, np.float32); ell = C.c_float(0); fp = C.POINTER(C.c_float)
+        _check(self.L.cvo_get_state(self.h, R.ctypes.data_as(fp), T.ctypes.data_as(fp), C.byref(ell)))
+        return dict(R=R.reshape(3, 3), T=T, ell=ell.value)
+
+    def set_state(self, R, T, ell):
+        r, rp = _f(np.asarray(R).reshape(9)); t, tp = _f(np.asarray(T).reshape(3))
+        _check(self.L.cvo_set_state(self.h, rp, tp, float(ell)))
+
+    def set_workgroups(self, g: int):
+        _check(self.L.cvo_set_workgroups(self.h, int(g)))
+
+
+class CvoBatch:
+    """Independent frame pairs aligned in one persistent launch (the
+    keyframe<->keyframe batch of keyframe_graph.cpp:622-731; BASELINE configs 3-4)."""
+
+    def __init__(self, max_pairs: int, params: Params | None = None, device: int = 0):
+        self.L = load_library()
+        self.params = params or default_params()
+        self.max_pairs = max_pairs
+        self.h = C.c_void_p()
+        _check(self.L.cvo_batch_create(C.byref(self.params), device, max_pairs, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.cvo_batch_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_pair(self, p, fixed_xyz, fixed_feat, moving_xyz, moving_feat):
+        fx, fxp, ff, ffp = _cloud_args(fixed_xyz, fixed_feat)
+        mx, mxp, mf, mfp = _cloud_args(moving_xyz, moving_feat)
+        _check(self.L.cvo_batch_set_pair(self.h, p, fxp, ffp, fx.shape[0], mxp, mfp, mx.shape[0]))
+
+    def set_state(self, p, R, T, ell):
+        r, rp = _f(np.asarray(R).reshape(9)); t, tp = _f(np.asarray(T).reshape(3))
+        _check(self.L.cvo_batch_set_state(self.h, p, rp, tp, float(ell)))
+
+    def set_workgroups(self, g: int):
+        _check(self.L.cvo_batch_set_workgroups(self.h, int(g)))
+
+    def reset_states(self):
+        _check(self.L.cvo_batch_reset_states(self.h))
+
+    def align_async(self, n_pairs: int, stream: int | None = None):
+        _check(self.L.cvo_batch_align_async(self.h, n_pairs, C.c_void_p(stream) if stream else None))
+
+    def wait(self, n: int = 0):
+        if n <= 0:
+            _check(self.L.cvo_batch_wait(self.h, None, 0)); return []
+        res = (PairResult * n)()
+        _check(self.L.cvo_batch_wait(self.h, res, n))
+        return [dict(transform=np.array(r.transform[:], np.float32).reshape(3, 4), R=np.array(r.R[:], np.float32).reshape(3, 3),
+                     T=np.array(r.T[:], np.float32), ell=r.ell, iter=r.iter, A_nonzero=r.A_nonzero,
+                     iterations_run=r.iterations_run, status=r.status) for r in res]
+
+    def align(self, n_pairs: int):
+        self.align_async(n_pairs)
+        return self.wait(n_pairs)
+
+    def last_launch(self):
+        ms = C.c_float(0); it = C.c_longlong(0); ca = C.c_longlong(0)
+        _check(self.L.cvo_batch_last_launch(self.h, C.byref(ms), C.byref(it), C.byref(ca)))
+        return dict(kernel_ms=ms.value, iterations_total=it.value, candidates_total=ca.value)
+
+    def results_to_device(self, dst_device_ptr: int, n: int, stream: int | None = None):
+        _check(self.L.cvo_batch_results_to_device(self.h, C.c_void_p(dst_device_ptr), n, C.c_void_p(stream) if stream else None))

@@ -1,0 +1,725 @@
+// cvo_capi.hip -- host side of libcvo_hip.so: the C ABI of include/cvo_hip.h.
+//
+// Holds the state machine of the reference's cvo::cvo object (cloud slots,
+// R/T/ell carried between calls, transform bookkeeping; thirdparty/cvo/src/
+// cvo.cpp:345-386, 461-618) and drives the gfx950 kernels.  There is no CPU
+// compute path: without a gfx950 device every entry point fails with
+// CVO_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/cvo_hip.h"
+#include "cvo_device.h"
+#include "cvo_math.hpp"
+
+namespace cvohip {
+size_t align_shared_bytes(int tile);
+hipError_t launch_align(int rpt, int grid, int block, int tile, hipStream_t stream, const PairDesc* descs, int n_pairs, int G, const DevParams& P);
+hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
+int score_grid(int na);
+int score_nout();
+hipError_t launch_score(const ScoreDesc& D, const DevParams& P, double* partials, hipStream_t stream);
+}  // namespace cvohip
+
+using namespace cvohip;
+
+static_assert(sizeof(cvo_trace_row) == sizeof(TraceRow), "trace row layout");
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) return fail(CVO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return CVO_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 4;
+        HIP_TRY(hipMalloc(&p, want));
+        bytes = want;
+        return CVO_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+struct PinBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return CVO_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        HIP_TRY(hipHostMalloc(&p, need + need / 4, hipHostMallocDefault));
+        bytes = need + need / 4;
+        return CVO_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
+// a point cloud resident in HBM: n records of 8 floats {x,y,z,f0..f4}
+struct Cloud {
+    DevBuf buf; int n = 0;
+    float* rec() const { return static_cast<float*>(buf.p); }
+    ~Cloud() { buf.release(); }
+};
+
+DevParams to_dev(const cvo_params& p) {
+    DevParams d;
+    d.sigma = p.sigma; d.sp_thres = p.sp_thres; d.c = p.c; d.d = p.d; d.c_ell = p.c_ell; d.c_sigma = p.c_sigma;
+    d.min_step = p.min_step; d.eps = p.eps; d.eps_2 = p.eps_2; d.max_iter = p.max_iter;
+    return d;
+}
+
+int check_device(int device, int* num_cus) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(CVO_ERR_NO_DEVICE, "no HIP device visible: libcvo_hip has no CPU path");
+    if (device < 0 || device >= count) return fail(CVO_ERR_INVALID, "device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CVO_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libcvo_hip is built for gfx950 only");
+    if (num_cus) *num_cus = prop.multiProcessorCount;
+    return CVO_OK;
+}
+
+// Launch machinery shared by single-object handles and batches.
+struct Engine {
+    int device = 0, num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevParams P;
+    DevBuf d_descs, d_states, d_ybuf, d_jlist, d_alist, d_cnt, d_xch, d_trace, d_tracelen, d_partials;
+    PinBuf h_descs, h_states, h_stage, h_partials;
+    int wg_request = 0;          // 0 = auto
+    int tile_request = 0;        // 0 = auto
+    int cap_request = 0;
+    float last_ms = 0.f;
+    bool launched = false;
+
+    int init(int dev, const cvo_params& prm) {
+        device = dev;
+        int rc = check_device(dev, &num_cus); if (rc) return rc;
+        HIP_TRY(hipSetDevice(dev));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+        P = to_dev(prm);
+        if (const char* e = std::getenv("CVO_HIP_CAND_CAP")) cap_request = std::atoi(e);
+        if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
+        if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
+        return CVO_OK;
+    }
+    void destroy() {
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jlist, &d_alist, &d_cnt, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (PinBuf* b : {&h_descs, &h_states, &h_stage, &h_partials}) b->release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr; ev0 = ev1 = nullptr;
+    }
+
+    // host arrays in the reference layout -> device records
+    int upload(Cloud& c, const float* xyz, const float* feat, int n) {
+        HIP_TRY(hipSetDevice(device));
+        if (n < 0) return fail(CVO_ERR_INVALID, "negative point count");
+        if (n > 65535) return fail(CVO_ERR_INVALID, "more than 65535 points per cloud is not supported (16-bit column indices)");
+        c.n = n;
+        if (n == 0) return CVO_OK;
+        if (!xyz || !feat) return fail(CVO_ERR_INVALID, "null cloud pointer");
+        const size_t bytes = (size_t)n * REC * sizeof(float);
+        int rc = c.buf.ensure(bytes); if (rc) return rc;
+        rc = h_stage.ensure(bytes); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));                       // staging buffer may still feed an earlier copy
+        float* s = static_cast<float*>(h_stage.p);
+        for (int i = 0; i < n; ++i) {
+            s[(size_t)i * REC + 0] = xyz[(size_t)i * 3 + 0];
+            s[(size_t)i * REC + 1] = xyz[(size_t)i * 3 + 1];
+            s[(size_t)i * REC + 2] = xyz[(size_t)i * 3 + 2];
+            for (int ch = 0; ch < 5; ++ch) s[(size_t)i * REC + 3 + ch] = feat[(size_t)ch * n + i];
+        }
+        HIP_TRY(hipMemcpyAsync(c.buf.p, s, bytes, hipMemcpyHostToDevice, stream));
+        return CVO_OK;
+    }
+
+    struct PairIn { const Cloud* fixed; const Cloud* moving; };
+
+    int pick_workgroups(int n_pairs) const {
+        int G = wg_request;
+        if (G <= 0) { G = 1; while (G * 2 * n_pairs <= num_cus && G < 32) G *= 2; }
+        G = std::max(1, std::min(G, num_cus));
+        return G;
+    }
+
+    // One persistent launch aligning n pairs.  states (host, n entries) are uploaded
+    // first when upload_states is set; results land in h_states after wait().
+    int launch(const std::vector<PairIn>& pairs, const PairState* states_in, bool upload_states, hipStream_t on_stream,
+               bool want_trace, int trace_cap) {
+        HIP_TRY(hipSetDevice(device));
+        const int n = (int)pairs.size();
+        if (n <= 0) return fail(CVO_ERR_INVALID, "no pairs to align");
+        hipStream_t s = on_stream ? on_stream : stream;
+        int nf_max = 0, nm_max = 0;
+        for (const PairIn& p : pairs) { nf_max = std::max(nf_max, p.fixed ? p.fixed->n : 0); nm_max = std::max(nm_max, p.moving ? p.moving->n : 0); }
+        const int G = pick_workgroups(n);
+        const int slots = std::max(1, std::min(n, num_cus / G));
+        const int grid = slots * G;
+        const int nf_pad = round_up(std::max(nf_max, 1), 64), nm_pad = round_up(std::max(nm_max, 1), 64);
+        int cap = cap_request;
+        if (cap <= 0) { cap = 128; while (cap < nm_max / 6 && cap < 2048) cap *= 2; }
+        int tile = tile_request > 0 ? round_up(tile_request, 4) : std::min(round_up(std::max(nm_max, 4), 4), 8192);
+        const int rows_per = (nf_max + G - 1) / G;
+        int block = rows_per > 1024 ? 1024 : (rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64)));
+        int rpt = std::max(1, std::min(4, (rows_per + block - 1) / block));
+
+        int rc;
+        if ((rc = d_descs.ensure(sizeof(PairDesc) * n))) return rc;
+        if ((rc = h_descs.ensure(sizeof(PairDesc) * n))) return rc;
+        if ((rc = d_states.ensure(sizeof(PairState) * n))) return rc;
+        if ((rc = h_states.ensure(sizeof(PairState) * n))) return rc;
+        if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
+        if ((rc = d_jlist.ensure(sizeof(uint16_t) * (size_t)n * cap * nf_pad))) return rc;
+        if ((rc = d_alist.ensure(sizeof(float) * (size_t)n * cap * nf_pad))) return rc;
+        if ((rc = d_cnt.ensure(sizeof(int) * (size_t)n * nf_pad))) return rc;
+        const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n * 2 * G * XCH_WORDS;
+        if ((rc = d_xch.ensure(xch_bytes))) return rc;
+        if (want_trace) {
+            if ((rc = d_trace.ensure(sizeof(TraceRow) * (size_t)std::max(1, trace_cap)))) return rc;
+            if ((rc = d_tracelen.ensure(sizeof(int) * 4))) return rc;
+            HIP_TRY(hipMemsetAsync(d_tracelen.p, 0, sizeof(int) * 4, s));
+        }
+        PairDesc* hd = static_cast<PairDesc*>(h_descs.p);
+        for (int i = 0; i < n; ++i) {
+            PairDesc& D = hd[i];
+            D.fixed = pairs[i].fixed ? pairs[i].fixed->rec() : nullptr;
+            D.moving = pairs[i].moving ? pairs[i].moving->rec() : nullptr;
+            D.nf = pairs[i].fixed ? pairs[i].fixed->n : 0;
+            D.nm = pairs[i].moving ? pairs[i].moving->n : 0;
+            D.nf_pad = nf_pad; D.cap = cap; D.nm_pad = nm_pad;
+            D.ybuf = static_cast<float4*>(d_ybuf.p) + (size_t)i * G * nm_pad;
+            D.jlist = static_cast<uint16_t*>(d_jlist.p) + (size_t)i * cap * nf_pad;
+            D.alist = static_cast<float*>(d_alist.p) + (size_t)i * cap * nf_pad;
+            D.cnt = static_cast<int*>(d_cnt.p) + (size_t)i * nf_pad;
+            D.xch = static_cast<unsigned long long*>(d_xch.p) + (size_t)i * 2 * G * XCH_WORDS;
+            D.state = static_cast<PairState*>(d_states.p) + i;
+            D.trace = (want_trace && i == 0) ? static_cast<TraceRow*>(d_trace.p) : nullptr;
+            D.trace_cap = want_trace ? trace_cap : 0;
+            D.trace_len = want_trace ? static_cast<int*>(d_tracelen.p) : nullptr;
+        }
+        HIP_TRY(hipMemcpyAsync(d_descs.p, hd, sizeof(PairDesc) * n, hipMemcpyHostToDevice, s));
+        if (upload_states) {
+            std::memcpy(h_states.p, states_in, sizeof(PairState) * n);
+            HIP_TRY(hipMemcpyAsync(d_states.p, h_states.p, sizeof(PairState) * n, hipMemcpyHostToDevice, s));
+        }
+        if (G > 1) HIP_TRY(hipMemsetAsync(d_xch.p, 0, xch_bytes, s));
+        HIP_TRY(hipEventRecord(ev0, s));
+        hipError_t e = launch_align(rpt, grid, block, tile, s, static_cast<const PairDesc*>(d_descs.p), n, G, P);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
+        HIP_TRY(hipEventRecord(ev1, s));
+        HIP_TRY(hipMemcpyAsync(h_states.p, d_states.p, sizeof(PairState) * n, hipMemcpyDeviceToHost, s));
+        launched = true;
+        last_stream = s;
+        return CVO_OK;
+    }
+    hipStream_t last_stream = nullptr;
+
+    int wait() {
+        HIP_TRY(hipSetDevice(device));
+        if (!launched) return fail(CVO_ERR_INVALID, "no launch to wait for");
+        HIP_TRY(hipStreamSynchronize(last_stream));
+        HIP_TRY(hipEventElapsedTime(&last_ms, ev0, ev1));
+        return CVO_OK;
+    }
+    const PairState* results() const { return static_cast<const PairState*>(h_states.p); }
+
+    // function_inner_product / se3_Hessian: out[0]=sum_A, out[1]=count, out[2..22]=Hessian terms
+    int score(const Cloud& a, const float* tran, const Cloud& b, float ell, bool hessian, double out[24]) {
+        HIP_TRY(hipSetDevice(device));
+        if (a.n <= 0 || b.n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "empty cloud");
+        ScoreDesc D;
+        D.a = a.rec(); D.b = b.rec(); D.na = a.n; D.nb = b.n; D.ell = ell; D.want_hessian = hessian ? 1 : 0; D.out = nullptr;
+        D.use_tran = tran ? 1 : 0;
+        for (int i = 0; i < 12; ++i) D.tran[i] = tran ? tran[i] : 0.f;
+        const int grid = score_grid(a.n), nout = score_nout();
+        int rc;
+        if ((rc = d_partials.ensure(sizeof(double) * (size_t)grid * nout))) return rc;
+        if ((rc = h_partials.ensure(sizeof(double) * (size_t)grid * nout))) return rc;
+        hipError_t e = launch_score(D, P, static_cast<double*>(d_partials.p), stream);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("score kernel launch: ") + hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(h_partials.p, d_partials.p, sizeof(double) * (size_t)grid * nout, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const double* hp = static_cast<const double*>(h_partials.p);
+        for (int q = 0; q < 24; ++q) out[q] = 0;
+        for (int g = 0; g < grid; ++g) for (int q = 0; q < nout && q < 24; ++q) out[q] += hp[(size_t)g * nout + q];
+        return CVO_OK;
+    }
+};
+
+// ---- host-side pieces of the reference's state helpers ----------------------
+struct Aff { float m[12]; };
+Aff aff_identity() { Aff a; std::memset(a.m, 0, sizeof(a.m)); a.m[0] = a.m[5] = a.m[10] = 1.f; return a; }
+Aff aff_mul(const Aff& a, const Aff& b) {   // Affine3f * Affine3f
+    Aff c;
+    for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 3; ++k)
+            c.m[r * 4 + k] = (a.m[r * 4 + 0] * b.m[0 * 4 + k] + a.m[r * 4 + 1] * b.m[1 * 4 + k]) + (a.m[r * 4 + 2] * b.m[2 * 4 + k] + a.m[r * 4 + 3] * 0.f);
+        c.m[r * 4 + 3] = (a.m[r * 4 + 0] * b.m[0 * 4 + 3] + a.m[r * 4 + 1] * b.m[1 * 4 + 3]) + (a.m[r * 4 + 2] * b.m[2 * 4 + 3] + a.m[r * 4 + 3] * 1.f);
+    }
+    return c;
+}
+Aff aff_inverse(const Aff& a) {             // Affine3f::inverse(), Affine mode: cofactor inverse of the linear part
+    float L[9]; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) L[r * 3 + c] = a.m[r * 4 + c];
+    const float c00 = L[4] * L[8] - L[5] * L[7], c01 = L[5] * L[6] - L[3] * L[8], c02 = L[3] * L[7] - L[4] * L[6];
+    const float det = sum3f(L[0] * c00, L[1] * c01, L[2] * c02), id = 1.f / det;
+    float Li[9];
+    Li[0] = c00 * id; Li[1] = (L[2] * L[7] - L[1] * L[8]) * id; Li[2] = (L[1] * L[5] - L[2] * L[4]) * id;
+    Li[3] = c01 * id; Li[4] = (L[0] * L[8] - L[2] * L[6]) * id; Li[5] = (L[2] * L[3] - L[0] * L[5]) * id;
+    Li[6] = c02 * id; Li[7] = (L[1] * L[6] - L[0] * L[7]) * id; Li[8] = (L[0] * L[4] - L[1] * L[3]) * id;
+    const float t[3] = {a.m[3], a.m[7], a.m[11]}; float nt[3];
+    mat3_vec(Li, t, nt);
+    Aff r;
+    for (int i = 0; i < 3; ++i) { for (int k = 0; k < 3; ++k) r.m[i * 4 + k] = Li[i * 3 + k]; r.m[i * 4 + 3] = -nt[i]; }
+    return r;
+}
+// Affine3f::rotation(): orthogonal polar factor of the linear part (Eigen uses an
+// SVD); Newton iteration X <- (X + X^-T)/2 in double reaches the same matrix.
+void polar_rotation(const float* L, float* Rout) {
+    double X[9]; for (int i = 0; i < 9; ++i) X[i] = L[i];
+    for (int it = 0; it < 32; ++it) {
+        const double c00 = X[4] * X[8] - X[5] * X[7], c01 = X[5] * X[6] - X[3] * X[8], c02 = X[3] * X[7] - X[4] * X[6];
+        const double det = X[0] * c00 + X[1] * c01 + X[2] * c02;
+        double inv[9];
+        inv[0] = c00 / det; inv[1] = (X[2] * X[7] - X[1] * X[8]) / det; inv[2] = (X[1] * X[5] - X[2] * X[4]) / det;
+        inv[3] = c01 / det; inv[4] = (X[0] * X[8] - X[2] * X[6]) / det; inv[5] = (X[2] * X[3] - X[0] * X[5]) / det;
+        inv[6] = c02 / det; inv[7] = (X[1] * X[6] - X[0] * X[7]) / det; inv[8] = (X[0] * X[4] - X[1] * X[3]) / det;
+        double delta = 0, Y[9];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+            Y[r * 3 + c] = 0.5 * (X[r * 3 + c] + inv[c * 3 + r]);
+            delta = std::max(delta, std::fabs(Y[r * 3 + c] - X[r * 3 + c]));
+        }
+        std::memcpy(X, Y, sizeof(X));
+        if (delta < 1e-15) break;
+    }
+    for (int i = 0; i < 9; ++i) Rout[i] = (float)X[i];
+}
+
+void sym_eig6(const double* Hin, double* ev) {   // cyclic Jacobi
+    double A[36]; std::memcpy(A, Hin, sizeof(A));
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0; for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += A[i * 6 + j] * A[i * 6 + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 6; ++p) for (int q = p + 1; q < 6; ++q) {
+            if (A[p * 6 + q] == 0.0) continue;
+            const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2.0 * A[p * 6 + q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 6; ++k) { const double akp = A[k * 6 + p], akq = A[k * 6 + q]; A[k * 6 + p] = c * akp - s * akq; A[k * 6 + q] = s * akp + c * akq; }
+            for (int k = 0; k < 6; ++k) { const double apk = A[p * 6 + k], aqk = A[q * 6 + k]; A[p * 6 + k] = c * apk - s * aqk; A[q * 6 + k] = s * apk + c * aqk; }
+        }
+    }
+    for (int i = 0; i < 6; ++i) ev[i] = A[i * 6 + i];
+}
+
+// 21 upper-triangle terms -> 6x6 [[A, C^T],[C, D]] (cvo.cpp:700-704), then the
+// scale / eigen-shift epilogue of se3_Hessian (cvo.cpp:726-758) in f32 as the reference.
+void finish_hessian(const double* terms21, int inliers, double Hout[36]) {
+    float H[36];
+    if (inliers) {
+        const double* t = terms21;
+        float A3[9], C3[9], D3[9];
+        A3[0] = (float)t[0]; A3[1] = A3[3] = (float)t[1]; A3[2] = A3[6] = (float)t[2]; A3[4] = (float)t[3]; A3[5] = A3[7] = (float)t[4]; A3[8] = (float)t[5];
+        for (int i = 0; i < 9; ++i) C3[i] = (float)t[6 + i];
+        D3[0] = (float)t[15]; D3[1] = D3[3] = (float)t[16]; D3[2] = D3[6] = (float)t[17]; D3[4] = (float)t[18]; D3[5] = D3[7] = (float)t[19]; D3[8] = (float)t[20];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+            H[r * 6 + c] = A3[r * 3 + c]; H[r * 6 + 3 + c] = C3[c * 3 + r]; H[(3 + r) * 6 + c] = C3[r * 3 + c]; H[(3 + r) * 6 + 3 + c] = D3[r * 3 + c];
+        }
+        const float scale = (float)(-1.0 / 100000);                 // cvo.cpp:727
+        for (int i = 0; i < 36; ++i) H[i] = H[i] * scale;
+        double Hd[36], evd[6]; for (int i = 0; i < 36; ++i) Hd[i] = H[i];
+        sym_eig6(Hd, evd);
+        float ev[6]; for (int i = 0; i < 6; ++i) ev[i] = (float)evd[i];
+        auto min_abs = [&]() { int mi = 0; for (int i = 1; i < 6; ++i) if (std::fabs(ev[i]) < std::fabs(ev[mi])) mi = i; return ev[mi]; };
+        float sufficient_scale = 0.0f, min_eigen = min_abs();
+        int guard = 0;
+        while (std::fabs(min_eigen) < 1.0 && guard++ < 1000) {      // cvo.cpp:740-746
+            sufficient_scale += (float)(1.0 - min_eigen);
+            for (int i = 0; i < 6; ++i) ev[i] += (float)(1.0 - min_eigen) * 1.0f;
+            min_eigen = min_abs();
+        }
+        for (int i = 0; i < 6; ++i) H[i * 6 + i] += sufficient_scale * 1.0f;   // cvo.cpp:747
+    } else {
+        for (int i = 0; i < 36; ++i) H[i] = (i % 7 == 0) ? 1.f : 0.f;         // cvo.cpp:755
+    }
+    for (int i = 0; i < 36; ++i) Hout[i] = (double)H[i];                      // cvo.cpp:758
+}
+
+}  // namespace
+
+// =============================================================================
+struct cvo_handle_s {
+    cvo_params prm;
+    Engine eng;
+    std::unique_ptr<Cloud> fixed, moving, previous;     // ptr_fixed_pcd / ptr_moving_pcd / ptr_previous_pcd, cvo.hpp:91-94
+    bool pre_pc_init = false, init = false, first_frame = true;
+    int num_fixed = 0, num_moving = 0;
+    float R[9], T[3], ell;
+    Aff transform, prev_transform, accum_transform;
+    int iter = 0, A_nonzero = 0;
+};
+
+struct cvo_batch_s {
+    cvo_params prm;
+    Engine eng;
+    int max_pairs = 0;
+    std::vector<std::unique_ptr<Cloud>> fixed, moving;
+    std::vector<PairState> init_states;     // what set_pair / set_state last gave
+    bool states_dirty = true;               // device states differ from init_states
+    int last_n = 0;
+};
+
+namespace {
+Cloud* slot_cloud(cvo_handle_s* h, int slot) {
+    switch (slot) { case CVO_SLOT_FIXED: return h->fixed.get(); case CVO_SLOT_MOVING: return h->moving.get(); case CVO_SLOT_PREVIOUS: return h->previous.get(); }
+    return nullptr;
+}
+void fresh_state(PairState& s, float ell) {
+    std::memset(&s, 0, sizeof(s));
+    s.R[0] = s.R[4] = s.R[8] = 1.f; s.ell = ell;
+    s.transform[0] = s.transform[5] = s.transform[10] = 1.f;
+}
+int do_align(cvo_handle_s* h, cvo_trace_row* trace, int trace_cap, int* trace_len) {
+    if (trace_len) *trace_len = 0;
+    if (!h->fixed || !h->moving || h->fixed->n <= 0 || h->moving->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "align: empty fixed or moving cloud");
+    PairState st; fresh_state(st, h->ell);
+    std::memcpy(st.R, h->R, sizeof(st.R)); std::memcpy(st.T, h->T, sizeof(st.T));
+    st.iter = h->iter;
+    std::memcpy(st.transform, h->transform.m, sizeof(st.transform));
+    std::vector<Engine::PairIn> pairs{{h->fixed.get(), h->moving.get()}};
+    const bool want_trace = trace && trace_cap > 0;
+    int rc = h->eng.launch(pairs, &st, true, nullptr, want_trace, trace_cap); if (rc) return rc;
+    if (want_trace) {
+        // results copy is already queued; queue the trace copies behind it on the same stream
+        HIP_TRY(hipMemcpyAsync(trace, h->eng.d_trace.p, sizeof(TraceRow) * trace_cap, hipMemcpyDeviceToHost, h->eng.stream));
+        HIP_TRY(hipMemcpyAsync(trace_len, h->eng.d_tracelen.p, sizeof(int), hipMemcpyDeviceToHost, h->eng.stream));
+    }
+    rc = h->eng.wait(); if (rc) return rc;
+    const PairState& r = h->eng.results()[0];
+    if (r.status != CVO_OK) return fail(r.status, "align kernel reported an error (6 = inter-workgroup wait timed out)");
+    std::memcpy(h->R, r.R, sizeof(h->R)); std::memcpy(h->T, r.T, sizeof(h->T));
+    h->ell = r.ell; h->iter = r.iter; h->A_nonzero = r.A_nonzero;
+    Aff prev; std::memcpy(prev.m, r.prev_transform, sizeof(prev.m));
+    h->prev_transform = prev;                                        // cvo.cpp:815
+    h->accum_transform = aff_mul(h->accum_transform, prev);          // cvo.cpp:816
+    std::memcpy(h->transform.m, r.transform, sizeof(float) * 12);    // update_tf, cvo.cpp:817
+    return CVO_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* cvo_last_error(void) { return g_err.c_str(); }
+
+int cvo_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < count; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int cvo_default_params(cvo_params* p) {
+    if (!p) return fail(CVO_ERR_INVALID, "null params");
+    p->ell = 0.15; p->sigma = 0.1; p->sp_thres = 8e-3; p->c = 7.0; p->d = 7.0; p->c_ell = 200; p->c_sigma = 1;
+    p->max_iter = 2000; p->min_step = 2 * 1.0e-1; p->eps = 5 * 1.0e-5; p->eps_2 = 1.0e-5;
+    return CVO_OK;
+}
+
+int cvo_create(const cvo_params* p, int device, cvo_handle* out) {
+    if (!out) return fail(CVO_ERR_INVALID, "null out");
+    *out = nullptr;
+    std::unique_ptr<cvo_handle_s> h(new cvo_handle_s());
+    if (p) h->prm = *p; else cvo_default_params(&h->prm);
+    int rc = h->eng.init(device, h->prm); if (rc) return rc;
+    h->fixed.reset(new Cloud());                                     // ptr_fixed_pcd(new point_cloud), cvo.cpp:30
+    h->ell = h->prm.ell;
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(h->R, I, sizeof(I)); h->T[0] = h->T[1] = h->T[2] = 0;  // cvo.cpp:66-67
+    h->transform = h->prev_transform = h->accum_transform = aff_identity();   // cvo.cpp:68-70
+    *out = h.release();
+    return CVO_OK;
+}
+
+int cvo_destroy(cvo_handle h) {
+    if (!h) return CVO_OK;
+    (void)hipSetDevice(h->eng.device);
+    if (h->eng.stream) (void)hipStreamSynchronize(h->eng.stream);
+    h->fixed.reset(); h->moving.reset(); h->previous.reset();
+    h->eng.destroy();
+    delete h;
+    return CVO_OK;
+}
+
+int cvo_set_pcd(cvo_handle h, const float* xyz, const float* feat, int n) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (!h->init) {                                                  // cvo.cpp:352-360
+        if (!h->fixed) h->fixed.reset(new Cloud());
+        int rc = h->eng.upload(*h->fixed, xyz, feat, n); if (rc) return rc;
+        h->init = true;
+        return CVO_OK;
+    }
+    h->moving.reset(new Cloud());                                    // cvo.cpp:362-366
+    int rc = h->eng.upload(*h->moving, xyz, feat, n); if (rc) return rc;
+    h->num_fixed = h->fixed ? h->fixed->n : 0; h->num_moving = h->moving->n;   // cvo.cpp:370-371
+    h->A_nonzero = 0;                                                // cvo.cpp:385
+    return CVO_OK;
+}
+
+int cvo_align_traced(cvo_handle h, cvo_trace_row* trace, int trace_cap, int* trace_len) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (trace && !trace_len) return fail(CVO_ERR_INVALID, "trace_len required with trace");
+    return do_align(h, trace, trace_cap, trace_len);
+}
+int cvo_align(cvo_handle h) { return cvo_align_traced(h, nullptr, 0, nullptr); }
+
+int cvo_match_odometry(cvo_handle h, const float* xyz, const float* feat, int n, double transform_out[12]) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (!h->init) return fail(CVO_ERR_NOT_INITIALIZED, "cvo not initialized !");    // cvo.cpp:463-466
+    int rc = cvo_set_pcd(h, xyz, feat, n); if (rc) return rc;
+    rc = cvo_align(h); if (rc) return rc;
+    if (transform_out) for (int i = 0; i < 12; ++i) transform_out[i] = (double)h->transform.m[i];   // cvo.cpp:472
+    return CVO_OK;
+}
+int cvo_match_keyframe(cvo_handle h, const float* xyz, const float* feat, int n, double transform_out[12]) {
+    return cvo_match_odometry(h, xyz, feat, n, transform_out);       // cvo.cpp:563-576 is the same body
+}
+
+int cvo_function_inner_product(cvo_handle h, int slot_a, const float* tran_a, int slot_b, cvo_inn_p* out) {
+    if (!h || !out) return fail(CVO_ERR_INVALID, "null argument");
+    Cloud* a = slot_cloud(h, slot_a); Cloud* b = slot_cloud(h, slot_b);
+    if (!a || !b || a->n <= 0 || b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "function_inner_product: empty cloud slot");
+    double r[24];
+    int rc = h->eng.score(*a, tran_a, *b, h->ell, false, r); if (rc) return rc;
+    double sum = r[1]; if (sum == 0) sum = 1;                        // cvo.cpp:455-456
+    out->value = (float)r[0]; out->num = (int)sum; out->num_e = 0;   // cvo.cpp:457
+    return CVO_OK;
+}
+
+int cvo_se3_hessian(cvo_handle h, int slot_a, const float* tran_a, int slot_b, double H[36], int* inliers) {
+    if (!h || !H || !inliers) return fail(CVO_ERR_INVALID, "null argument");
+    Cloud* a = slot_cloud(h, slot_a); Cloud* b = slot_cloud(h, slot_b);
+    if (!a || !b || a->n <= 0 || b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "se3_Hessian: empty cloud slot");
+    double r[24];
+    int rc = h->eng.score(*a, tran_a, *b, h->ell, true, r); if (rc) return rc;
+    *inliers += (int)r[1];                                           // cvo.cpp:708 increments the caller's variable
+    finish_hessian(r + 2, *inliers, H);
+    return CVO_OK;
+}
+
+int cvo_compute_innerproduct(cvo_handle h, cvo_inn_p* inn_pre, cvo_inn_p* inn_post, double post_hessian[36], const float tran[12],
+                             int* inliers, cvo_inn_p* inn_fixed_pcd, cvo_inn_p* inn_moving_pcd, float* cos_angle) {
+    if (!h || !inn_pre || !inn_post || !post_hessian || !tran || !inliers || !inn_fixed_pcd || !inn_moving_pcd || !cos_angle)
+        return fail(CVO_ERR_INVALID, "null argument");
+    int rc;
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, nullptr, CVO_SLOT_FIXED, inn_pre))) return rc;       // cvo.cpp:489
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, tran, CVO_SLOT_FIXED, inn_post))) return rc;         // cvo.cpp:491
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_FIXED, nullptr, CVO_SLOT_FIXED, inn_fixed_pcd))) return rc;  // cvo.cpp:496
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, nullptr, CVO_SLOT_MOVING, inn_moving_pcd))) return rc;   // cvo.cpp:497
+    *cos_angle = inn_post->value / (sqrtf(inn_fixed_pcd->value) * sqrtf(inn_moving_pcd->value));                  // cvo.cpp:498
+    return cvo_se3_hessian(h, CVO_SLOT_MOVING, tran, CVO_SLOT_FIXED, post_hessian, inliers);                      // cvo.cpp:500
+}
+
+int cvo_compute_innerproduct_lc(cvo_handle h, cvo_inn_p* inn_prior, cvo_inn_p* inn_lc_prior, cvo_inn_p* inn_lc_pre, cvo_inn_p* inn_lc_post,
+                                double post_hessian[36], const float prior_tran[12], const float lc_prior_tran[12],
+                                const float lc_prior_tran_2[12], const float lc_tran[12], int* inliers_svd, int* inliers_pnpransac,
+                                cvo_inn_p* inn_fixed_pcd, cvo_inn_p* inn_moving_pcd, float* cos_angle) {
+    if (!h || !inn_prior || !inn_lc_prior || !inn_lc_pre || !inn_lc_post || !post_hessian || !prior_tran || !lc_prior_tran ||
+        !lc_prior_tran_2 || !lc_tran || !inliers_svd || !inliers_pnpransac || !inn_fixed_pcd || !inn_moving_pcd || !cos_angle)
+        return fail(CVO_ERR_INVALID, "null argument");
+    int rc;
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, prior_tran, CVO_SLOT_FIXED, inn_prior))) return rc;          // cvo.cpp:539
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, lc_prior_tran, CVO_SLOT_FIXED, inn_lc_prior))) return rc;    // cvo.cpp:541
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, nullptr, CVO_SLOT_FIXED, inn_lc_pre))) return rc;            // cvo.cpp:543
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, lc_tran, CVO_SLOT_FIXED, inn_lc_post))) return rc;           // cvo.cpp:545
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_FIXED, nullptr, CVO_SLOT_FIXED, inn_fixed_pcd))) return rc;          // cvo.cpp:550
+    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, nullptr, CVO_SLOT_MOVING, inn_moving_pcd))) return rc;       // cvo.cpp:551
+    *cos_angle = inn_lc_post->value / (sqrtf(inn_fixed_pcd->value) * sqrtf(inn_moving_pcd->value));                       // cvo.cpp:552
+    *inliers_svd = 0;                                                                                                     // cvo.cpp:554
+    if ((rc = cvo_se3_hessian(h, CVO_SLOT_MOVING, lc_tran, CVO_SLOT_FIXED, post_hessian, inliers_svd))) return rc;        // cvo.cpp:555
+    double Hdummy[36];
+    *inliers_pnpransac = 0;                                                                                               // cvo.cpp:557
+    return cvo_se3_hessian(h, CVO_SLOT_MOVING, lc_prior_tran_2, CVO_SLOT_FIXED, Hdummy, inliers_pnpransac);               // cvo.cpp:558
+}
+
+int cvo_update_fixed_pcd(cvo_handle h) { if (!h) return fail(CVO_ERR_INVALID, "null handle"); h->fixed = std::move(h->moving); return CVO_OK; }
+int cvo_update_previous_pcd(cvo_handle h) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    h->previous = std::move(h->moving); h->pre_pc_init = true; return CVO_OK;
+}
+int cvo_reset_transform(cvo_handle h, const float odometry[12]) {
+    if (!h || !odometry) return fail(CVO_ERR_INVALID, "null argument");
+    std::memcpy(h->transform.m, odometry, sizeof(float) * 12); return CVO_OK;
+}
+int cvo_reset_keyframe(cvo_handle h, const float odometry[12]) {
+    if (!h || !odometry) return fail(CVO_ERR_INVALID, "null argument");
+    if (!h->pre_pc_init) { h->fixed = std::move(h->moving); }
+    else { h->fixed = std::move(h->previous); cvo_update_previous_pcd(h); }
+    return cvo_reset_transform(h, odometry);
+}
+int cvo_reset_initial(cvo_handle h, const float odometry[12], float init_inverse_out[12]) {
+    if (!h || !odometry) return fail(CVO_ERR_INVALID, "null argument");
+    Aff od; std::memcpy(od.m, odometry, sizeof(od.m));
+    const Aff init = aff_inverse(aff_mul(h->transform, od));          // cvo.cpp:613
+    float L[9]; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) L[r * 3 + c] = init.m[r * 4 + c];
+    polar_rotation(L, h->R);                                         // cvo.cpp:614
+    h->T[0] = init.m[3]; h->T[1] = init.m[7]; h->T[2] = init.m[11];   // cvo.cpp:615
+    if (init_inverse_out) { const Aff back = aff_inverse(init); std::memcpy(init_inverse_out, back.m, sizeof(back.m)); }   // cvo.cpp:617
+    return CVO_OK;
+}
+
+int cvo_get_fixed_and_moving_number(cvo_handle h, int* fixed_num, int* moving_num) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (fixed_num) *fixed_num = h->num_fixed;
+    if (moving_num) *moving_num = h->num_moving;
+    return CVO_OK;
+}
+int cvo_get_iteration_number(cvo_handle h, int* iteration) { if (!h || !iteration) return fail(CVO_ERR_INVALID, "null argument"); *iteration = h->iter; return CVO_OK; }
+int cvo_get_A_nonzero(cvo_handle h, int* nonzero) { if (!h || !nonzero) return fail(CVO_ERR_INVALID, "null argument"); *nonzero = h->A_nonzero; return CVO_OK; }
+int cvo_get_transform(cvo_handle h, float transform[12]) { if (!h || !transform) return fail(CVO_ERR_INVALID, "null argument"); std::memcpy(transform, h->transform.m, sizeof(float) * 12); return CVO_OK; }
+int cvo_get_prev_accum_transform(cvo_handle h, float prev_transform[12], float accum_transform[12]) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (prev_transform) std::memcpy(prev_transform, h->prev_transform.m, sizeof(float) * 12);
+    if (accum_transform) std::memcpy(accum_transform, h->accum_transform.m, sizeof(float) * 12);
+    return CVO_OK;
+}
+int cvo_get_init(cvo_handle h, int* init) { if (!h || !init) return fail(CVO_ERR_INVALID, "null argument"); *init = h->init ? 1 : 0; return CVO_OK; }
+int cvo_get_first_frame(cvo_handle h, int* first_frame) { if (!h || !first_frame) return fail(CVO_ERR_INVALID, "null argument"); *first_frame = h->first_frame ? 1 : 0; return CVO_OK; }
+int cvo_set_first_frame(cvo_handle h, int first_frame) { if (!h) return fail(CVO_ERR_INVALID, "null handle"); h->first_frame = first_frame != 0; return CVO_OK; }
+int cvo_get_state(cvo_handle h, float R[9], float T[3], float* ell) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (R) std::memcpy(R, h->R, sizeof(h->R));
+    if (T) std::memcpy(T, h->T, sizeof(h->T));
+    if (ell) *ell = h->ell;
+    return CVO_OK;
+}
+int cvo_set_state(cvo_handle h, const float R[9], const float T[3], float ell) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (R) std::memcpy(h->R, R, sizeof(h->R));
+    if (T) std::memcpy(h->T, T, sizeof(h->T));
+    h->ell = ell;
+    return CVO_OK;
+}
+int cvo_set_workgroups(cvo_handle h, int workgroups_per_pair) {
+    if (!h || workgroups_per_pair < 0) return fail(CVO_ERR_INVALID, "bad argument");
+    h->eng.wg_request = workgroups_per_pair; return CVO_OK;
+}
+
+// ------------------------------------------------------------------ batches
+int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* out) {
+    if (!out || max_pairs <= 0) return fail(CVO_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    std::unique_ptr<cvo_batch_s> b(new cvo_batch_s());
+    if (p) b->prm = *p; else cvo_default_params(&b->prm);
+    int rc = b->eng.init(device, b->prm); if (rc) return rc;
+    b->max_pairs = max_pairs;
+    b->fixed.resize(max_pairs); b->moving.resize(max_pairs);
+    b->init_states.resize(max_pairs);
+    for (auto& s : b->init_states) fresh_state(s, b->prm.ell);
+    *out = b.release();
+    return CVO_OK;
+}
+int cvo_batch_destroy(cvo_batch b) {
+    if (!b) return CVO_OK;
+    (void)hipSetDevice(b->eng.device);
+    if (b->eng.stream) (void)hipStreamSynchronize(b->eng.stream);
+    b->fixed.clear(); b->moving.clear();
+    b->eng.destroy();
+    delete b;
+    return CVO_OK;
+}
+int cvo_batch_set_pair(cvo_batch b, int p, const float* fixed_xyz, const float* fixed_feat, int n_fixed,
+                       const float* moving_xyz, const float* moving_feat, int n_moving) {
+    if (!b || p < 0 || p >= b->max_pairs) return fail(CVO_ERR_INVALID, "bad pair index");
+    if (!b->fixed[p]) b->fixed[p].reset(new Cloud());
+    if (!b->moving[p]) b->moving[p].reset(new Cloud());
+    int rc = b->eng.upload(*b->fixed[p], fixed_xyz, fixed_feat, n_fixed); if (rc) return rc;
+    rc = b->eng.upload(*b->moving[p], moving_xyz, moving_feat, n_moving); if (rc) return rc;
+    fresh_state(b->init_states[p], b->prm.ell);
+    b->states_dirty = true;
+    return CVO_OK;
+}
+int cvo_batch_set_state(cvo_batch b, int p, const float R[9], const float T[3], float ell) {
+    if (!b || p < 0 || p >= b->max_pairs || !R || !T) return fail(CVO_ERR_INVALID, "bad argument");
+    std::memcpy(b->init_states[p].R, R, sizeof(float) * 9); std::memcpy(b->init_states[p].T, T, sizeof(float) * 3);
+    b->init_states[p].ell = ell;
+    b->states_dirty = true;
+    return CVO_OK;
+}
+int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair) {
+    if (!b || workgroups_per_pair < 0) return fail(CVO_ERR_INVALID, "bad argument");
+    b->eng.wg_request = workgroups_per_pair; return CVO_OK;
+}
+int cvo_batch_reset_states(cvo_batch b) { if (!b) return fail(CVO_ERR_INVALID, "null batch"); b->states_dirty = true; return CVO_OK; }
+
+int cvo_batch_align_async(cvo_batch b, int n_pairs, void* stream) {
+    if (!b || n_pairs <= 0 || n_pairs > b->max_pairs) return fail(CVO_ERR_INVALID, "bad pair count");
+    std::vector<Engine::PairIn> pairs(n_pairs);
+    for (int i = 0; i < n_pairs; ++i) pairs[i] = Engine::PairIn{b->fixed[i].get(), b->moving[i].get()};
+    int rc = b->eng.launch(pairs, b->init_states.data(), b->states_dirty, static_cast<hipStream_t>(stream), false, 0);
+    if (rc) return rc;
+    b->states_dirty = false;      // device states now evolve launch to launch (warm start) until reset
+    b->last_n = n_pairs;
+    return CVO_OK;
+}
+int cvo_batch_wait(cvo_batch b, cvo_pair_result* results, int n) {
+    if (!b) return fail(CVO_ERR_INVALID, "null batch");
+    int rc = b->eng.wait(); if (rc) return rc;
+    if (results) {
+        if (n > b->last_n) return fail(CVO_ERR_INVALID, "more results requested than pairs launched");
+        const PairState* r = b->eng.results();
+        for (int i = 0; i < n; ++i) {
+            std::memcpy(results[i].transform, r[i].transform, sizeof(float) * 12);
+            std::memcpy(results[i].R, r[i].R, sizeof(float) * 9); std::memcpy(results[i].T, r[i].T, sizeof(float) * 3);
+            results[i].ell = r[i].ell; results[i].iter = r[i].iter; results[i].A_nonzero = r[i].A_nonzero;
+            results[i].iterations_run = r[i].iterations_run; results[i].status = r[i].status;
+        }
+    }
+    return CVO_OK;
+}
+int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_total, long long* candidates_total) {
+    if (!b) return fail(CVO_ERR_INVALID, "null batch");
+    if (kernel_ms) *kernel_ms = b->eng.last_ms;
+    long long it = 0, ca = 0;
+    const PairState* r = b->eng.results();
+    for (int i = 0; i < b->last_n; ++i) { it += r[i].iterations_run; ca += r[i].candidates_total; }
+    if (iterations_total) *iterations_total = it;
+    if (candidates_total) *candidates_total = ca;
+    return CVO_OK;
+}
+int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stream) {
+    if (!b || !dst_device || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(b->eng.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->eng.last_stream;
+    hipError_t e = launch_pack_results(static_cast<const PairState*>(b->eng.d_states.p), static_cast<float*>(dst_device), n, s);
+    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pack kernel launch: ") + hipGetErrorString(e));
+    return CVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+/* ============================================================================
+ * include/cvo_hip.h -- C ABI of libcvo_hip.so: the MI355X (gfx950) implementation
+ * of CVO-SLAM's per-frame-pair CVO alignment hot path.
+ *
+ * The reference has no FFI layer: the C++ class `cvo::cvo`
+ * (thirdparty/cvo/include/cvo.hpp:82-282) IS the boundary that local_tracker /
+ * keyframe_graph link against.  Each entry point below replaces one member of
+ * that class (cited per function); a header-only `cvo::cvo` adaptor with the
+ * reference's exact signatures forwards to them.  Images never
+ * cross this ABI: the reference's pcd_generator stays on the host side of the
+ * adaptor and hands the selected cloud over as plain arrays.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are HOST pointers unless the
+ *     name says `_device`.
+ *   - point cloud = n x 3 f32 positions, AoS, 12-byte stride (cloud_t,
+ *     data_type.h:30) + 5 channel-major f32 arrays of n (the column-major
+ *     Eigen::Matrix<float,Dynamic,5> `features`, data_type.h:75).
+ *   - rigid transforms = 3x4 row-major [R | t] (top rows of Eigen::Affine3f).
+ *   - every call returns a status; the reference's functions are `void` and
+ *     print-and-return on "not initialized" (cvo.cpp:463-466), which the adaptor
+ *     reproduces from CVO_ERR_NOT_INITIALIZED.
+ *   - a handle is used by one thread at a time; distinct handles are independent
+ *     (own HIP stream, no globals), like distinct cvo::cvo objects.
+ * ========================================================================== */
+#ifndef CVO_HIP_H
+#define CVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    CVO_OK = 0,
+    CVO_ERR_NOT_INITIALIZED = 1,  /* cvo.cpp:463-466 / 565-568 */
+    CVO_ERR_EMPTY_CLOUD = 2,      /* reference: KD adaptor assert / UB (Q8) */
+    CVO_ERR_HIP = 3,              /* HIP runtime error, message via cvo_last_error() */
+    CVO_ERR_INVALID = 4,          /* bad argument */
+    CVO_ERR_NO_DEVICE = 5,        /* no gfx950 device: the library never falls back to the CPU */
+    CVO_ERR_TIMEOUT = 6           /* in-kernel inter-workgroup wait gave up */
+};
+
+enum { CVO_SLOT_FIXED = 0, CVO_SLOT_MOVING = 1, CVO_SLOT_PREVIOUS = 2 };   /* cvo.hpp:91-94 */
+
+/* Hyper-parameters the reference hard-codes in the ctor (cvo.cpp:35-51). */
+typedef struct cvo_params {
+    float ell;        /* 0.15  initial kernel length-scale        cvo.cpp:35 */
+    float sigma;      /* 0.1                                      cvo.cpp:36 */
+    float sp_thres;   /* 8e-3  sparsification threshold           cvo.cpp:37 */
+    float c;          /* 7.0   so(3) inner-product scale          cvo.cpp:38 */
+    float d;          /* 7.0   R^3 inner-product scale            cvo.cpp:39 */
+    float c_ell;      /* 200   colour kernel length-scale         cvo.cpp:41 */
+    float c_sigma;    /* 1                                        cvo.cpp:42 */
+    int   max_iter;   /* 2000                                     cvo.cpp:48 */
+    float min_step;   /* 0.2                                      cvo.cpp:49 */
+    float eps;        /* 5e-5  stop A                             cvo.cpp:50 */
+    float eps_2;      /* 1e-5  stop B                             cvo.cpp:51 */
+} cvo_params;
+
+/* inn_p, cvo.hpp:52-80 */
+typedef struct cvo_inn_p { float value; int num; int num_e; } cvo_inn_p;
+
+/* one align() iteration as the kernel saw it (parity/diagnostics; optional) */
+typedef struct cvo_trace_row {
+    float  omega[3];
+    float  v[3];
+    int    nnz;
+    int    candidates;   /* pairs that passed the conservative cull (>= nnz) */
+    double B, C, D, E;
+    float  step;
+    float  ell;
+    float  dist;         /* dist_se3 of the applied update, -1 if stop A fired first */
+    int    pad_;
+} cvo_trace_row;
+
+typedef struct cvo_handle_s* cvo_handle;
+
+const char* cvo_last_error(void);                 /* thread-local message of the last failing call */
+int cvo_device_count(void);                       /* number of visible gfx950 devices */
+int cvo_default_params(cvo_params* p);            /* ctor constants, cvo.cpp:35-51 */
+
+/* ---- object lifetime:  cvo::cvo(const string& calib_file) / ~cvo()  cvo.cpp:18-74
+ * (the calib file only feeds pcd_generator, which stays on the adaptor side) */
+int cvo_create(const cvo_params* p /* NULL = defaults */, int device, cvo_handle* out);
+int cvo_destroy(cvo_handle h);
+
+/* ---- set_pcd(RGB, depth)  cvo.cpp:345-386, with the selected cloud handed in.
+ * First call fills FIXED and sets `init`; later calls replace MOVING. */
+int cvo_set_pcd(cvo_handle h, const float* xyz, const float* feat, int n);
+
+/* ---- align()  cvo.cpp:763-821.  Runs entirely on the device from the handle's
+ * R, T, ell (warm start, Q1/Q2) and leaves R, T, ell, transform, iter, A_nonzero
+ * updated.  trace may be NULL. */
+int cvo_align(cvo_handle h);
+int cvo_align_traced(cvo_handle h, cvo_trace_row* trace, int trace_cap, int* trace_len);
+
+/* ---- match_odometry / match_keyframe  cvo.cpp:461-473, 563-576:
+ * set_pcd + align; transform_out = 3x4 row-major double (Affine3d). */
+int cvo_match_odometry(cvo_handle h, const float* xyz, const float* feat, int n, double transform_out[12]);
+int cvo_match_keyframe(cvo_handle h, const float* xyz, const float* feat, int n, double transform_out[12]);
+
+/* ---- function_inner_product(cloud_a, cloud_b)  cvo.cpp:388-459 and
+ * se3_Hessian(cloud_a, cloud_b, inliers)  cvo.cpp:620-759, on the handle's slots;
+ * tran_a (may be NULL) is applied to slot a's positions first, as
+ * compute_innerproduct does at cvo.cpp:485-487.  Both use the handle's CURRENT ell. */
+int cvo_function_inner_product(cvo_handle h, int slot_a, const float* tran_a, int slot_b, cvo_inn_p* out);
+int cvo_se3_hessian(cvo_handle h, int slot_a, const float* tran_a, int slot_b, double H[36], int* inliers /* in/out, accumulated */);
+
+/* ---- compute_innerproduct  cvo.cpp:475-503 */
+int cvo_compute_innerproduct(cvo_handle h, cvo_inn_p* inn_pre, cvo_inn_p* inn_post, double post_hessian[36],
+                             const float tran[12], int* inliers, cvo_inn_p* inn_fixed_pcd,
+                             cvo_inn_p* inn_moving_pcd, float* cos_angle);
+/* ---- compute_innerproduct_lc  cvo.cpp:505-561 */
+int cvo_compute_innerproduct_lc(cvo_handle h, cvo_inn_p* inn_prior, cvo_inn_p* inn_lc_prior, cvo_inn_p* inn_lc_pre,
+                                cvo_inn_p* inn_lc_post, double post_hessian[36], const float prior_tran[12],
+                                const float lc_prior_tran[12], const float lc_prior_tran_2[12],
+                                const float lc_tran[12], int* inliers_svd, int* inliers_pnpransac,
+                                cvo_inn_p* inn_fixed_pcd, cvo_inn_p* inn_moving_pcd, float* cos_angle);
+
+/* ---- cloud-slot state machine  cvo.cpp:578-618 */
+int cvo_update_fixed_pcd(cvo_handle h);                                   /* cvo.cpp:578-582 */
+int cvo_update_previous_pcd(cvo_handle h);                                /* cvo.cpp:584-589 */
+int cvo_reset_keyframe(cvo_handle h, const float odometry[12]);           /* cvo.cpp:591-604 */
+int cvo_reset_transform(cvo_handle h, const float odometry[12]);          /* cvo.cpp:606-609 */
+int cvo_reset_initial(cvo_handle h, const float odometry[12], float init_inverse_out[12]);   /* cvo.cpp:611-618 */
+
+/* ---- getters / public members  cvo.hpp:139-144, 268-270 */
+int cvo_get_fixed_and_moving_number(cvo_handle h, int* fixed_num, int* moving_num);
+int cvo_get_iteration_number(cvo_handle h, int* iteration);
+int cvo_get_A_nonzero(cvo_handle h, int* nonzero);
+int cvo_get_transform(cvo_handle h, float transform[12]);
+int cvo_get_prev_accum_transform(cvo_handle h, float prev_transform[12], float accum_transform[12]);
+int cvo_get_init(cvo_handle h, int* init);
+int cvo_get_first_frame(cvo_handle h, int* first_frame);
+int cvo_set_first_frame(cvo_handle h, int first_frame);
+/* R, T (row-major 3x3, 3) and ell are private in the reference but are carried
+ * state between calls (Q1, Q2); exposed so callers/tests can pin them. */
+int cvo_get_state(cvo_handle h, float R[9], float T[3], float* ell);
+int cvo_set_state(cvo_handle h, const float R[9], const float T[3], float ell);
+/* number of workgroups that cooperate on this handle's alignment (latency knob; 0 = auto) */
+int cvo_set_workgroups(cvo_handle h, int workgroups_per_pair);
+
+/* ======================= batched alignment (independent frame pairs) ===========
+ * keyframe<->keyframe loop-closure candidates (keyframe_graph.cpp:622-731) and
+ * offline batches are independent cvo::cvo objects; a batch runs all of them in
+ * one persistent launch, `workgroups_per_pair` workgroups each. */
+typedef struct cvo_batch_s* cvo_batch;
+
+typedef struct cvo_pair_result {       /* what match_keyframe + the getters return, per pair */
+    float transform[12];               /* cvo::transform after align(), cvo.cpp:817 */
+    float R[9];
+    float T[3];
+    float ell;                         /* ell left behind (Q1) */
+    int   iter;                        /* get_iteration_number (Q4: value of k at the break; max_iter if none) */
+    int   A_nonzero;                   /* get_A_nonzero (Q5) */
+    int   iterations_run;              /* loop trips executed = iter+1 on a break */
+    int   status;                      /* CVO_OK / CVO_ERR_* for this pair */
+} cvo_pair_result;
+
+int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* out);
+int cvo_batch_destroy(cvo_batch b);
+/* upload pair p (host arrays, reference layout); sets R=I, T=0, ell=params.ell (fresh-object semantics) */
+int cvo_batch_set_pair(cvo_batch b, int p, const float* fixed_xyz, const float* fixed_feat, int n_fixed,
+                       const float* moving_xyz, const float* moving_feat, int n_moving);
+/* warm start / carried ell for pair p (reset_initial + Q1) */
+int cvo_batch_set_state(cvo_batch b, int p, const float R[9], const float T[3], float ell);
+int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair /* 0 = auto: fill the CUs */);
+/* restore every pair's (R,T,ell) to what set_pair/set_state last gave it (bench loops re-run the same inputs) */
+int cvo_batch_reset_states(cvo_batch b);
+/* enqueue one persistent launch aligning pairs [0, n_pairs) on `stream` (a hipStream_t, NULL = the batch's own); asynchronous */
+int cvo_batch_align_async(cvo_batch b, int n_pairs, void* stream);
+/* wait for the launch and fetch results (n entries) */
+int cvo_batch_wait(cvo_batch b, cvo_pair_result* results, int n);
+/* device time of the last launch in ms (HIP events on the launch stream), total loop trips it executed */
+int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_total, long long* candidates_total);
+/* pack the last launch's results into a caller-owned DEVICE buffer of n records of
+ * CVO_RESULT_FLOATS floats {transform[12], iter, A_nonzero, iterations_run, status},
+ * enqueued on `stream` (NULL = the launch's stream): the payload of the cross-GPU
+ * RCCL gather without a host round trip. */
+#define CVO_RESULT_FLOATS 16
+int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVO_HIP_H */

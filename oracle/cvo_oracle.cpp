@@ -357,34 +357,58 @@ void compute_flow(orc_cvo* o) {
 // f32 monic coefficients (double arithmetic): real roots of a real cubic = the
 // eigenvalues with zero imaginary part.  coef(0)==0 gives inf/NaN entries, no
 // eigenvalue qualifies, and the caller falls back to min_step.
+// Real roots of the monic cubic t^3 + a t^2 + b t + c (double).  One root by a
+// bracketed Newton iteration (always converges: f(-R) < 0 < f(R) for the Cauchy
+// bound R), the other two from the deflated quadratic (deflation direction chosen
+// by the root's size so no cancellation), each polished on the full cubic.  Plain
+// Cardano loses the sign of the discriminant when the roots differ by many orders
+// of magnitude.
+static int cubic_real_roots(double a, double b, double c, double* roots) {
+    const double R = 1.0 + std::fmax(std::fabs(a), std::fmax(std::fabs(b), std::fabs(c)));
+    double lo = -R, hi = R, x = 0.0;
+    for (int it = 0; it < 200; ++it) {
+        const double f = ((x + a) * x + b) * x + c, df = (3.0 * x + 2.0 * a) * x + b;
+        if (f == 0.0) break;
+        if (f < 0) lo = x; else hi = x;
+        double xn = x - f / df;
+        if (!(df != 0.0) || !(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+        if (std::fabs(xn - x) <= 1e-16 * std::fabs(xn) || xn == x) { x = xn; break; }
+        x = xn;
+    }
+    const double r = x;
+    roots[0] = r;
+    double p, q;                                   // t^2 + p t + q
+    if (std::fabs(r) * std::fabs(r) * std::fabs(r) > std::fabs(c)) { q = -c / r; p = (q - b) / r; }   // large root: divide from the constant term up
+    else { p = a + r; q = b + p * r; }                                              // small root: synthetic division from the top
+    const double disc = p * p - 4.0 * q;
+    if (!(disc >= 0.0)) return 1;
+    const double s = -0.5 * (p + std::copysign(std::sqrt(disc), p));
+    double r2 = s, r3 = (s != 0.0) ? q / s : 0.0;
+    double* rr[2] = {&r2, &r3};
+    for (int k = 0; k < 2; ++k) {
+        double t = *rr[k];
+        for (int it = 0; it < 4; ++it) {
+            const double f = ((t + a) * t + b) * t + c, df = (3.0 * t + 2.0 * a) * t + b;
+            const double tn = t - f / df;
+            if (!(df != 0.0) || !std::isfinite(tn)) break;
+            const double fn = ((tn + a) * tn + b) * tn + c;
+            if (std::fabs(fn) > std::fabs(f)) break;
+            t = tn;
+        }
+        *rr[k] = t;
+    }
+    roots[1] = r2; roots[2] = r3;
+    return 3;
+}
+
 extern "C" float orc_cubic_step(float c3, float c2, float c1, float c0, float min_step) {
-    const float p1f = c2 / c3, p2f = c1 / c3, p3f = c0 / c3;                      // (coef/coef(0)).segment(1,3)
+    const float p1f = c2 / c3, p2f = c1 / c3, p3f = c0 / c3;                      // (coef/coef(0)).segment(1,3), cvo.cpp:86
     float best = std::numeric_limits<float>::max();
     if (std::isfinite(p1f) && std::isfinite(p2f) && std::isfinite(p3f)) {
-        const double a = p1f, b = p2f, c = p3f;
-        const double p = b - a * a / 3.0;
-        const double q = 2.0 * a * a * a / 27.0 - a * b / 3.0 + c;
-        const double disc = q * q / 4.0 + p * p * p / 27.0;
-        double roots[3]; int nr = 0;
-        if (disc > 0) {
-            const double s = std::sqrt(disc);
-            roots[nr++] = std::cbrt(-q / 2.0 + s) + std::cbrt(-q / 2.0 - s) - a / 3.0;
-        } else if (p == 0.0) {
-            roots[nr++] = -a / 3.0;                                               // triple root
-        } else {
-            const double r = 2.0 * std::sqrt(-p / 3.0);
-            double arg = 3.0 * q / (p * r);
-            arg = std::max(-1.0, std::min(1.0, arg));
-            const double phi = std::acos(arg) / 3.0;
-            for (int k = 0; k < 3; ++k) roots[nr++] = r * std::cos(phi - 2.0 * M_PI * k / 3.0) - a / 3.0;
-        }
-        for (int k = 0; k < nr; ++k) {                                            // Newton polish on the monic cubic
-            double t = roots[k];
-            for (int it = 0; it < 3; ++it) {
-                const double f = ((t + a) * t + b) * t + c, df = (3.0 * t + 2.0 * a) * t + b;
-                if (df != 0.0 && std::isfinite(f / df)) t -= f / df;
-            }
-            const float tf = (float)t;
+        double roots[3];
+        const int nr = cubic_real_roots(p1f, p2f, p3f, roots);
+        for (int k = 0; k < nr; ++k) {
+            const float tf = (float)roots[k];
             if (tf > 0 && tf < best) best = tf;                                   // cvo.cpp:326-327
         }
     }

@@ -1,0 +1,51 @@
+"""world_size=2 gloo rehearsal of the multi-GPU path: pairs shard with no data-path
+collective, one all-gather of fixed-size result records."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cvo_slam_amd import shard
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                rg = shard.shard_range(n, r, world)
+                seen += list(rg)
+            assert seen == list(range(n))
+            sizes = [len(shard.shard_range(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert list(shard.shard_range(512, 3, 8)) == list(range(192, 256))     # BASELINE config 4: 64 pairs per GPU
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_pairs, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_range(n_pairs, rank, world)
+    # a rank "aligns" its own pairs: the record of global pair p is a deterministic function of p
+    local = torch.stack([torch.arange(shard.RESULT_FLOATS, dtype=torch.float32) + 100.0 * p for p in mine]) if len(mine) else \
+        torch.zeros((0, shard.RESULT_FLOATS))
+    table = shard.gather_results(local, n_pairs, world)
+    np.save(os.path.join(out_dir, f"table_{rank}.npy"), table.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [8, 13])
+def test_gather_results_world2(tmp_path, n_pairs):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_pairs, str(tmp_path)), nprocs=world, join=True)
+    want = np.stack([np.arange(shard.RESULT_FLOATS, dtype=np.float32) + 100.0 * p for p in range(n_pairs)])
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"table_{r}.npy"), want)   # every rank holds the full table in pair order

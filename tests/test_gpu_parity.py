@@ -1,0 +1,376 @@
+"""Parity of the HIP path (through the C ABI, include/cvo_hip.h) against the oracle and
+the committed golden fixtures.  Tolerance from BASELINE.json's north_star: rotation
+<= 1e-4 rad, translation <= 1e-4 m on the final SE(3); per-iteration quantities are
+compared much tighter because the survivor arithmetic follows the oracle's float
+sequence."""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import make_tf, rot_trans_err
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL = 1e-4     # rad
+TRANS_TOL = 1e-4   # m
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@contextlib.contextmanager
+def env(**kw):
+    old = {k: os.environ.get(k) for k in kw}
+    os.environ.update({k: str(v) for k, v in kw.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def gpu_align(hiplib, fixed, moving, wgs=0, trace_cap=0, params=None):
+    g = hiplib.Cvo(params)
+    g.set_workgroups(wgs)
+    g.set_pcd(*fixed); g.set_pcd(*moving)
+    tr = g.align(trace_cap=trace_cap)
+    return g, tr
+
+
+def oracle_align(oracle, fixed, moving, trace_cap=0, params=None):
+    o = oracle.OracleCvo(params)
+    o.set_pcd(*fixed); o.set_pcd(*moving)
+    rc, tr = o.align(trace_cap=trace_cap)
+    assert rc == 0
+    return o, tr
+
+
+def assert_pose_close(a, b):
+    re, te = rot_trans_err(a, b)
+    assert re <= ROT_TOL and te <= TRANS_TOL, (re, te)
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("name", ["small_pair_11.npz", "small_pair_12.npz", "small_pair_13.npz"])
+@pytest.mark.parametrize("wgs", [1, 3])
+def test_golden_small_pairs_trace_and_pose(hiplib, name, wgs):
+    gd = load(name)
+    g, tr = gpu_align(hiplib, (gd["fixed_xyz"], gd["fixed_feat"]), (gd["moving_xyz"], gd["moving_feat"]), wgs=wgs, trace_cap=400)
+    assert_pose_close(g.transform, gd["final_transform"])
+    assert g.get_iteration_number() == int(gd["iter"])
+    assert g.get_A_nonzero() == int(gd["A_nonzero"])
+    n = len(gd["trace_nnz"])
+    assert len(tr) == n
+    np.testing.assert_array_equal([r["nnz"] for r in tr], gd["trace_nnz"])                       # the same sparse set every iteration
+    np.testing.assert_allclose(np.array([r["omega"] for r in tr]), gd["trace_omega"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(np.array([r["v"] for r in tr]), gd["trace_v"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(np.array([r["BCDE"] for r in tr]), gd["trace_BCDE"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose([r["step"] for r in tr], gd["trace_step"], rtol=1e-5)
+    np.testing.assert_array_equal(np.array([r["ell"] for r in tr], np.float32), gd["trace_ell"])
+    for r in tr:
+        assert r["candidates"] >= r["nnz"]
+    g.close()
+
+
+def test_golden_full_size_pair_pose_and_scores(hiplib):
+    gd = load("tum_pair_0.npz")
+    g, _ = gpu_align(hiplib, (gd["fixed_xyz"], gd["fixed_feat"]), (gd["moving_xyz"], gd["moving_feat"]))
+    assert_pose_close(g.transform, gd["final_transform"])
+    assert g.get_iteration_number() == int(gd["iter"])
+    assert g.get_fixed_and_moving_number() == (gd["fixed_xyz"].shape[0], gd["moving_xyz"].shape[0])
+    sc = g.compute_innerproduct(gd["final_transform"])
+    for key, gk in (("inn_pre", "inn_pre"), ("inn_post", "inn_post"), ("inn_fixed_pcd", "inn_fixed"), ("inn_moving_pcd", "inn_moving")):
+        assert sc[key][1] == int(gd[gk][1]), key                                                  # pair counts are integers: exact
+        assert sc[key][0] == pytest.approx(float(gd[gk][0]), rel=1e-6), key
+    assert sc["inliers"] == int(gd["inliers"])
+    assert sc["cos_angle"] == pytest.approx(float(gd["cos_angle"]), rel=1e-6)
+    # the reference keeps an f32 Hessian summed in arbitrary order (cvo.cpp:622,707): relative 1e-3
+    np.testing.assert_allclose(sc["post_hessian"], gd["post_hessian"], rtol=1e-3, atol=1e-3 * np.abs(gd["post_hessian"]).max())
+    g.close()
+
+
+# ----------------------------------------------------------------------------- live oracle
+@pytest.mark.parametrize("seed,n", [(101, 64), (102, 257), (103, 700), (104, 1500)])
+def test_seeded_pairs_vs_oracle(hiplib, oracle, seed, n):
+    from cvo_slam_amd import synth
+    p = synth.make_small_pair(seed, n=n)
+    fixed = (p.fixed.xyz, p.fixed.feat)
+    moving = (p.moving.xyz[: max(8, n - 13)], p.moving.feat[:, : max(8, n - 13)])               # ragged: N != M
+    o, otr = oracle_align(oracle, fixed, moving, trace_cap=2000)
+    g, gtr = gpu_align(hiplib, fixed, moving, trace_cap=2000)
+    ost = o.get_state()
+    assert_pose_close(g.transform, ost["transform"])
+    assert g.get_iteration_number() == ost["iter"] and g.get_A_nonzero() == ost["A_nonzero"]
+    assert [r["nnz"] for r in gtr] == [r["nnz"] for r in otr]
+    st = g.get_state()
+    assert st["ell"] == np.float32(ost["ell"])
+    np.testing.assert_allclose(st["R"], ost["R"], atol=1e-6); np.testing.assert_allclose(st["T"], ost["T"], atol=1e-6)
+    g.close()
+
+
+def test_workgroup_counts_tiles_and_overflow_fallback_agree(hiplib, oracle):
+    """The same alignment under every decomposition knob: workgroups per pair (incl. a
+    non-power-of-two and more workgroups than 64-row blocks), LDS tile smaller than the
+    cloud (multi-tile streaming) and a candidate capacity so small that every row takes
+    the dense fallback.  All must land on the oracle's pose and sparse-set sizes."""
+    from cvo_slam_amd import synth
+    p = synth.make_small_pair(55, n=900)
+    fixed, moving = (p.fixed.xyz, p.fixed.feat), (p.moving.xyz, p.moving.feat)
+    o, otr = oracle_align(oracle, fixed, moving, trace_cap=2000)
+    want_nnz = [r["nnz"] for r in otr]
+    ost = o.get_state()
+    configs = [dict(wgs=1), dict(wgs=2), dict(wgs=7), dict(wgs=32), dict(wgs=1, CVO_HIP_TILE=128), dict(wgs=4, CVO_HIP_TILE=252),
+               dict(wgs=1, CVO_HIP_CAND_CAP=4), dict(wgs=5, CVO_HIP_CAND_CAP=1, CVO_HIP_TILE=64)]
+    for cfg in configs:
+        envs = {k: v for k, v in cfg.items() if k.startswith("CVO_")}
+        with env(**envs):
+            g, gtr = gpu_align(hiplib, fixed, moving, wgs=cfg["wgs"], trace_cap=2000)
+        assert [r["nnz"] for r in gtr] == want_nnz, cfg
+        re, te = rot_trans_err(g.transform, ost["transform"])
+        assert re <= 1e-6 and te <= 1e-6, (cfg, re, te)
+        assert g.get_iteration_number() == ost["iter"], cfg
+        g.close()
+
+
+def test_full_size_pair_fresh_vs_oracle(hiplib, oracle):
+    from cvo_slam_amd import synth
+    p = synth.make_pair(3)
+    fixed, moving = (p.fixed.xyz, p.fixed.feat), (p.moving.xyz, p.moving.feat)
+    o = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8)
+    o.set_pcd(*fixed); o.set_pcd(*moving); rc, _ = o.align(); assert rc == 0
+    g, _ = gpu_align(hiplib, fixed, moving)
+    assert_pose_close(g.transform, o.get_state()["transform"])
+    assert g.get_iteration_number() == o.get_state()["iter"]
+    # size-independent properties at full size: <a,b> is symmetric in its pair set, self inner product counts >= n
+    ab = g.function_inner_product(hiplib.api.SLOT_MOVING, None, hiplib.api.SLOT_FIXED)
+    ba = g.function_inner_product(hiplib.api.SLOT_FIXED, None, hiplib.api.SLOT_MOVING)
+    assert ab[1] == ba[1] and ab[0] == pytest.approx(ba[0], rel=1e-6)
+    aa = g.function_inner_product(hiplib.api.SLOT_FIXED, None, hiplib.api.SLOT_FIXED)
+    assert aa[1] >= p.fixed.n and aa[0] >= p.fixed.n * 0.01 * (1 - 1e-6)                         # every point pairs with itself: k*ck = sigma^2
+    g.close()
+
+
+# ----------------------------------------------------------------------------- scores
+def test_score_block_vs_oracle(hiplib, oracle):
+    from cvo_slam_amd import synth
+    p = synth.make_small_pair(77, n=800)
+    fixed, moving = (p.fixed.xyz, p.fixed.feat), (p.moving.xyz, p.moving.feat)
+    o, _ = oracle_align(oracle, fixed, moving)
+    g, _ = gpu_align(hiplib, fixed, moving)
+    tf = o.get_state()["transform"]
+    rc, so = o.compute_innerproduct(tf); assert rc == 0
+    sg = g.compute_innerproduct(tf)
+    for key in ("inn_pre", "inn_post", "inn_fixed_pcd", "inn_moving_pcd"):
+        assert sg[key][1] == so[key][1] and sg[key][2] == 0
+        assert sg[key][0] == pytest.approx(so[key][0], rel=1e-6)
+    assert sg["inliers"] == so["inliers"]
+    assert sg["cos_angle"] == pytest.approx(so["cos_angle"], rel=1e-6)
+    np.testing.assert_allclose(sg["post_hessian"], so["post_hessian"], rtol=1e-3, atol=1e-3 * np.abs(so["post_hessian"]).max())
+    # un-regularised Hessian against the oracle's f64 accumulation of the same terms
+    rc, Ho, inl_o, Hraw = o.se3_hessian(oracle.SLOT_MOVING, tf, oracle.SLOT_FIXED)
+    Hg, inl_g = g.se3_hessian(hiplib.api.SLOT_MOVING, tf, hiplib.api.SLOT_FIXED)
+    assert inl_g == inl_o
+    # loop-closure score block (cvo.cpp:505-561)
+    t1, t2, t3 = make_tf([0, 1, 0], 0.01, [0.01, 0, 0]), make_tf([1, 0, 0], 0.02, [0, 0.01, 0]), make_tf([0, 0, 1], 0.015, [0, 0, 0.01])
+    rc, lo = o.compute_innerproduct_lc(t1, t2, t3, tf); assert rc == 0
+    lg = g.compute_innerproduct_lc(t1, t2, t3, tf)
+    for key in ("inn_prior", "inn_lc_prior", "inn_lc_pre", "inn_lc_post", "inn_fixed_pcd", "inn_moving_pcd"):
+        assert lg[key][1] == lo[key][1]
+        assert lg[key][0] == pytest.approx(lo[key][0], rel=1e-6)
+    assert (lg["inliers_svd"], lg["inliers_pnpransac"]) == (lo["inliers_svd"], lo["inliers_pnpransac"])
+    assert lg["cos_angle"] == pytest.approx(lo["cos_angle"], rel=1e-6)
+    g.close()
+
+
+def test_empty_overlap_scores(hiplib, oracle):
+    # no pair within the radius: value 0, num forced to 1 (cvo.cpp:455-456), Hessian = identity (cvo.cpp:755)
+    gd = load("small_pair_11.npz")
+    g = hiplib.Cvo(); g.set_pcd(gd["fixed_xyz"], gd["fixed_feat"]); g.set_pcd(gd["moving_xyz"] + np.array([10, 0, 0], np.float32), gd["moving_feat"])
+    assert g.function_inner_product(hiplib.api.SLOT_MOVING, None, hiplib.api.SLOT_FIXED) == (0.0, 1, 0)
+    H, inl = g.se3_hessian(hiplib.api.SLOT_MOVING, None, hiplib.api.SLOT_FIXED)
+    assert inl == 0
+    np.testing.assert_array_equal(H, np.eye(6))
+    tr = g.align(trace_cap=4)                                              # and align stops at k=0 with the pose untouched
+    assert len(tr) == 1 and tr[0]["nnz"] == 0 and tr[0]["step"] == pytest.approx(0.2)
+    assert g.get_iteration_number() == 0
+    np.testing.assert_array_equal(g.transform, np.eye(3, 4, dtype=np.float32))
+    g.close()
+
+
+# ----------------------------------------------------------------------------- error behaviour
+def test_error_conventions(hiplib):
+    gd = load("small_pair_11.npz")
+    g = hiplib.Cvo()
+    with pytest.raises(hiplib.CvoError) as e:                                                    # cvo.cpp:463-466: "cvo not initialized !"
+        g.match_odometry(gd["moving_xyz"], gd["moving_feat"])
+    assert e.value.code == 1 and "not initialized" in str(e.value)
+    assert not g.init
+    g.set_pcd(gd["fixed_xyz"], gd["fixed_feat"])
+    assert g.init and g.first_frame
+    with pytest.raises(hiplib.CvoError) as e:                                                    # no moving cloud yet (Q8)
+        g.align()
+    assert e.value.code == 2
+    with pytest.raises(hiplib.CvoError) as e:
+        g.match_keyframe(np.zeros((0, 3), np.float32), np.zeros((5, 0), np.float32))              # empty moving cloud
+    assert e.value.code == 2
+    with pytest.raises(hiplib.CvoError) as e:
+        g.set_pcd(np.zeros((70000, 3), np.float32), np.zeros((5, 70000), np.float32))
+    assert e.value.code == 4
+    g.first_frame = False
+    assert not g.first_frame
+    g.close()
+
+
+def test_max_iter_leaves_iter_stale(hiplib, oracle):
+    # Q4: `iter` is only written on a break; hitting MAX_ITER leaves the previous value
+    gd = load("small_pair_12.npz")
+    pg = hiplib.default_params(); pg.max_iter = 5
+    po_ = oracle.default_params(); po_.max_iter = 5
+    fixed, moving = (gd["fixed_xyz"], gd["fixed_feat"]), (gd["moving_xyz"], gd["moving_feat"])
+    g, gtr = gpu_align(hiplib, fixed, moving, trace_cap=16, params=pg)
+    o, otr = oracle_align(oracle, fixed, moving, trace_cap=16, params=po_)
+    assert len(gtr) == len(otr) == 5
+    assert g.get_iteration_number() == 0 == o.get_state()["iter"]
+    assert_pose_close(g.transform, o.get_state()["transform"])
+    g.close()
+
+
+# ----------------------------------------------------------------------------- tracker call sequence
+def test_tracker_sequence_replay(hiplib, oracle):
+    """The call sequence of LocalTracker (local_tracker.cpp:228-251, 356-431, 506; SURVEY
+    Appendix B) on two objects, three frames: warm starts (Q2), carried ell (Q1), slot moves."""
+    from cvo_slam_amd import synth
+    rng = np.random.default_rng(4)
+    base = synth.make_small_pair(91, n=600)
+    frames = [(base.fixed.xyz, base.fixed.feat)]
+    for k in range(3):                                                     # frames drifting away from the keyframe
+        tf = make_tf(rng.normal(size=3), 0.01 * (k + 1), 0.01 * (k + 1) * rng.normal(size=3)).astype(np.float64)
+        xyz = ((base.moving.xyz.astype(np.float64) - tf[:, 3]) @ tf[:, :3]).astype(np.float32)
+        frames.append((xyz, base.moving.feat))
+
+    def run(make):
+        odo, kf = make(), make()
+        out = []
+        odo.set_pcd(*frames[0]); kf.set_pcd(*frames[0])                    # :228,:231
+        t_odo = odo.match_odometry(*frames[1])                             # :233
+        s = odo.compute_innerproduct(np.asarray(t_odo, np.float32))        # :251
+        out.append((t_odo, s))
+        odo.update_fixed_pcd()                                             # :277
+        kf.first_frame = False; kf.reset_transform(np.asarray(t_odo, np.float32))   # :330-333
+        for f in frames[2:]:
+            t_odo = odo.match_odometry(*f)                                 # :356
+            s1 = odo.compute_innerproduct(np.asarray(t_odo, np.float32))   # :375
+            odo.update_fixed_pcd()                                         # :403
+            guess = kf.reset_initial(np.asarray(t_odo, np.float32))        # :407
+            t_kf = kf.match_keyframe(*f)                                   # :415
+            s2 = kf.compute_innerproduct(np.asarray(t_kf, np.float32))     # :431
+            kf.update_previous_pcd()                                       # :506
+            out.append((t_odo, s1)); out.append((t_kf, s2)); out.append((guess, None))
+        return out
+
+    class OAdapter:                                                        # same method names over the oracle
+        def __init__(self): self.o = oracle.OracleCvo(); self.first_frame = True
+        def set_pcd(self, x, f): self.o.set_pcd(x, f)
+        def match_odometry(self, x, f): rc, t = self.o.match(x, f); assert rc == 0; return t
+        match_keyframe = match_odometry
+        def compute_innerproduct(self, t): rc, s = self.o.compute_innerproduct(t); assert rc == 0; return s
+        def update_fixed_pcd(self): self.o.update_fixed_pcd()
+        def update_previous_pcd(self): self.o.update_previous_pcd()
+        def reset_transform(self, t): self.o.reset_transform(t)
+        def reset_initial(self, t): return self.o.reset_initial(t)
+
+    want = run(OAdapter)
+    got = run(hiplib.Cvo)
+    assert len(want) == len(got)
+    for (tw, sw), (tg, sg) in zip(want, got):
+        assert_pose_close(tg, tw)
+        if sw is not None:
+            assert sg["inn_post"][1] == sw["inn_post"][1] and sg["inliers"] == sw["inliers"]
+            assert sg["inn_post"][0] == pytest.approx(sw["inn_post"][0], rel=1e-5)
+            assert sg["cos_angle"] == pytest.approx(sw["cos_angle"], rel=1e-5)
+
+
+def test_reset_keyframe_slot_moves(hiplib):
+    gd = load("small_pair_13.npz")
+    A, B = (gd["fixed_xyz"], gd["fixed_feat"]), (gd["moving_xyz"], gd["moving_feat"])
+    S = hiplib.api
+    g = hiplib.Cvo(); g.set_pcd(*A); g.set_pcd(*B)
+    r1 = g.function_inner_product(S.SLOT_MOVING, None, S.SLOT_FIXED)
+    g.update_fixed_pcd()
+    with pytest.raises(hiplib.CvoError):
+        g.function_inner_product(S.SLOT_MOVING, None, S.SLOT_FIXED)        # MOVING moved away
+    g.set_pcd(*A)
+    r2 = g.function_inner_product(S.SLOT_FIXED, None, S.SLOT_MOVING)
+    assert r1[1] == r2[1]
+    g.update_previous_pcd(); g.set_pcd(*B)
+    odom = make_tf([0, 0, 1], 0.01, [0.01, 0, 0])
+    g.reset_keyframe(odom)                                                 # FIXED <- PREVIOUS, MOVING -> PREVIOUS, transform <- odom
+    np.testing.assert_array_equal(g.transform, odom)
+    g.function_inner_product(S.SLOT_FIXED, None, S.SLOT_PREVIOUS)
+    g.close()
+
+
+# ----------------------------------------------------------------------------- batches
+def test_batch_matches_single_objects_and_warm_start(hiplib, oracle):
+    from cvo_slam_amd import synth
+    pairs = [synth.make_small_pair(200 + i, n=n) for i, n in enumerate((300, 450, 64, 900, 300, 777))]
+    B = hiplib.CvoBatch(len(pairs))
+    for i, p in enumerate(pairs):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+    warm = make_tf([0, 1, 0], 0.004, [0.002, 0, -0.001])
+    B.set_state(4, warm[:, :3], warm[:, 3], 0.06)                          # reset_initial-style warm start + carried ell (Q1, Q2)
+    res = B.align(len(pairs))
+    info = B.last_launch()
+    assert info["kernel_ms"] > 0 and info["iterations_total"] == sum(r["iterations_run"] for r in res)
+    for i, (p, r) in enumerate(zip(pairs, res)):
+        assert r["status"] == 0
+        o = oracle.OracleCvo()
+        o.set_pcd(p.fixed.xyz, p.fixed.feat); o.set_pcd(p.moving.xyz, p.moving.feat)
+        if i == 4:
+            o.set_state(warm[:, :3], warm[:, 3], 0.06)
+        rc, _ = o.align(); assert rc == 0
+        st = o.get_state()
+        assert_pose_close(r["transform"], st["transform"])
+        assert r["iter"] == st["iter"] and r["A_nonzero"] == st["A_nonzero"] and r["iterations_run"] == st["iter"] + 1
+        assert r["ell"] == np.float32(st["ell"])
+    # a second launch without reset continues from the converged state: one or two trips, pose unchanged
+    res2 = B.align(len(pairs))
+    for r, r2 in zip(res, res2):
+        assert r2["iterations_run"] <= 3
+        re, te = rot_trans_err(r["transform"], r2["transform"])
+        assert re <= 1e-4 and te <= 1e-4
+    # reset_states restores the initial states: identical results again
+    B.reset_states()
+    res3 = B.align(len(pairs))
+    for r, r3 in zip(res, res3):
+        np.testing.assert_array_equal(r["transform"], r3["transform"])
+        assert r["iterations_run"] == r3["iterations_run"]
+    B.close()
+
+
+def test_batch_results_to_device_records(hiplib):
+    import torch
+    from cvo_slam_amd import shard, synth
+    pairs = [synth.make_small_pair(300 + i, n=200) for i in range(3)]
+    B = hiplib.CvoBatch(3)
+    for i, p in enumerate(pairs):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+    B.align_async(3)
+    out = torch.zeros((3, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda")
+    B.results_to_device(out.data_ptr(), 3)
+    res = B.wait(3)
+    torch.cuda.synchronize()
+    rec = out.cpu().numpy()
+    for i, r in enumerate(res):
+        np.testing.assert_array_equal(rec[i, :12].reshape(3, 4), r["transform"])
+        assert (int(rec[i, 12]), int(rec[i, 13]), int(rec[i, 14]), int(rec[i, 15])) == (r["iter"], r["A_nonzero"], r["iterations_run"], r["status"])
+    table = shard.gather_results(out, 3, 1)
+    assert table.shape == (3, shard.RESULT_FLOATS)
+    B.close()
