@@ -44,7 +44,8 @@ class TraceRow(C.Structure):
 
 class PairResult(C.Structure):
     _fields_ = [("transform", C.c_float * 12), ("R", C.c_float * 9), ("T", C.c_float * 3), ("ell", C.c_float),
-                ("iter", C.c_int), ("A_nonzero", C.c_int), ("iterations_run", C.c_int), ("status", C.c_int)]
+                ("iter", C.c_int), ("A_nonzero", C.c_int), ("iterations_run", C.c_int), ("status", C.c_int),
+                ("rebuilds", C.c_int), ("dense_fallbacks", C.c_int)]
 
 
 # every symbol include/cvo_hip.h declares (tests check the .so exports exactly these)
@@ -57,7 +58,7 @@ ABI_SYMBOLS = [
     "cvo_get_first_frame", "cvo_set_first_frame", "cvo_get_state", "cvo_set_state", "cvo_set_workgroups",
     "cvo_batch_create", "cvo_batch_destroy", "cvo_batch_set_pair", "cvo_batch_set_state", "cvo_batch_set_workgroups",
     "cvo_batch_reset_states", "cvo_batch_align_async", "cvo_batch_wait", "cvo_batch_last_launch",
-    "cvo_batch_results_to_device",
+    "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds",
 ]
 
 _lib = None
@@ -117,6 +118,7 @@ def load_library():
     L.cvo_batch_wait.argtypes = [vp, C.POINTER(PairResult), C.c_int]
     L.cvo_batch_last_launch.argtypes = [vp, fp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.cvo_batch_results_to_device.argtypes = [vp, vp, C.c_int, vp]
+    L.cvo_batch_last_phase_seconds.argtypes = [vp, dp]
     _lib = L
     return L
 
@@ -338,7 +340,7 @@ class CvoBatch:
         _check(self.L.cvo_batch_wait(self.h, res, n))
         return [dict(transform=np.array(r.transform[:], np.float32).reshape(3, 4), R=np.array(r.R[:], np.float32).reshape(3, 3),
                      T=np.array(r.T[:], np.float32), ell=r.ell, iter=r.iter, A_nonzero=r.A_nonzero,
-                     iterations_run=r.iterations_run, status=r.status) for r in res]
+                     iterations_run=r.iterations_run, status=r.status, rebuilds=r.rebuilds, dense_fallbacks=r.dense_fallbacks) for r in res]
 
     def align(self, n_pairs: int):
         self.align_async(n_pairs)
@@ -348,6 +350,10 @@ class CvoBatch:
         ms = C.c_float(0); it = C.c_longlong(0); ca = C.c_longlong(0)
         _check(self.L.cvo_batch_last_launch(self.h, C.byref(ms), C.byref(it), C.byref(ca)))
         return dict(kernel_ms=ms.value, iterations_total=it.value, candidates_total=ca.value)
+
+    def last_phase_seconds(self):
+        out = np.zeros(10); _check(self.L.cvo_batch_last_phase_seconds(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return dict(zip(("cull", "candidates", "reduce1", "linesearch", "reduce2", "epilogue", "rb_sweep", "rb_scan", "rb_extract", "c2_rowsums"), out.tolist()))
 
     def results_to_device(self, dst_device_ptr: int, n: int, stream: int | None = None):
         _check(self.L.cvo_batch_results_to_device(self.h, C.c_void_p(dst_device_ptr), n, C.c_void_p(stream) if stream else None))

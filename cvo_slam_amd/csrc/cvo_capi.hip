@@ -81,6 +81,7 @@ DevParams to_dev(const cvo_params& p) {
     DevParams d;
     d.sigma = p.sigma; d.sp_thres = p.sp_thres; d.c = p.c; d.d = p.d; d.c_ell = p.c_ell; d.c_sigma = p.c_sigma;
     d.min_step = p.min_step; d.eps = p.eps; d.eps_2 = p.eps_2; d.max_iter = p.max_iter;
+    d.skin = 0.25f;
     return d;
 }
 
@@ -103,11 +104,12 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
-    DevBuf d_descs, d_states, d_ybuf, d_jlist, d_alist, d_cnt, d_xch, d_trace, d_tracelen, d_partials;
+    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_bits, d_pre, d_cnt, d_flat_i, d_flat_j, d_rec0, d_rec1, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
     PinBuf h_descs, h_states, h_stage, h_partials;
     int wg_request = 0;          // 0 = auto
     int tile_request = 0;        // 0 = auto
-    int cap_request = 0;
+    int capf_request = 0;        // flat capacity per row (0 = auto)
+    int block_request = 0;       // threads per workgroup (0 = auto)
     float last_ms = 0.f;
     bool launched = false;
 
@@ -118,7 +120,9 @@ struct Engine {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
         P = to_dev(prm);
-        if (const char* e = std::getenv("CVO_HIP_CAND_CAP")) cap_request = std::atoi(e);
+        if (const char* e = std::getenv("CVO_HIP_FLAT_CAP")) capf_request = std::atoi(e);
+        if (const char* e = std::getenv("CVO_HIP_BLOCK")) block_request = std::atoi(e);
+        if (const char* e = std::getenv("CVO_HIP_SKIN")) P.skin = (float)std::atof(e);
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
         return CVO_OK;
@@ -126,7 +130,7 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jlist, &d_alist, &d_cnt, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_bits, &d_pre, &d_cnt, &d_flat_i, &d_flat_j, &d_rec0, &d_rec1, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -159,10 +163,11 @@ struct Engine {
 
     struct PairIn { const Cloud* fixed; const Cloud* moving; };
 
-    int pick_workgroups(int n_pairs) const {
+    int pick_workgroups(int n_pairs, int nf_max) const {
         int G = wg_request;
         if (G <= 0) { G = 1; while (G * 2 * n_pairs <= num_cus && G < 32) G *= 2; }
-        G = std::max(1, std::min(G, num_cus));
+        const int g_min = (nf_max + MAX_ROWS_PER_WG - 1) / MAX_ROWS_PER_WG;     // a workgroup owns at most MAX_ROWS_PER_WG rows
+        G = std::max(std::max(1, g_min), std::min(G, num_cus));
         return G;
     }
 
@@ -176,15 +181,16 @@ struct Engine {
         hipStream_t s = on_stream ? on_stream : stream;
         int nf_max = 0, nm_max = 0;
         for (const PairIn& p : pairs) { nf_max = std::max(nf_max, p.fixed ? p.fixed->n : 0); nm_max = std::max(nm_max, p.moving ? p.moving->n : 0); }
-        const int G = pick_workgroups(n);
+        const int G = pick_workgroups(n, nf_max);
         const int slots = std::max(1, std::min(n, num_cus / G));
         const int grid = slots * G;
         const int nf_pad = round_up(std::max(nf_max, 1), 64), nm_pad = round_up(std::max(nm_max, 1), 64);
-        int cap = cap_request;
-        if (cap <= 0) { cap = 128; while (cap < nm_max / 6 && cap < 2048) cap *= 2; }
-        int tile = tile_request > 0 ? round_up(tile_request, 4) : std::min(round_up(std::max(nm_max, 4), 4), 8192);
+        int capf = capf_request;
+        if (capf <= 0) capf = std::max(96, nm_max / 12);                                 // flat lists, average per row
+        int tile = tile_request > 0 ? round_up(tile_request, 32) : std::min(round_up(std::max(nm_max, 32), 32), 8192);
         const int rows_per = (nf_max + G - 1) / G;
-        int block = rows_per > 1024 ? 1024 : (rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64)));
+        int block = rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64));
+        if (block_request > 0) block = std::max(64, std::min(512, round_up(block_request, 64)));
         int rpt = std::max(1, std::min(4, (rows_per + block - 1) / block));
 
         int rc;
@@ -193,9 +199,19 @@ struct Engine {
         if ((rc = d_states.ensure(sizeof(PairState) * n))) return rc;
         if ((rc = h_states.ensure(sizeof(PairState) * n))) return rc;
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
-        if ((rc = d_jlist.ensure(sizeof(uint16_t) * (size_t)n * cap * nf_pad))) return rc;
-        if ((rc = d_alist.ensure(sizeof(float) * (size_t)n * cap * nf_pad))) return rc;
+        const size_t plane = (size_t)(nf_pad + G) * capf;
+        const int rows_pad = round_up(std::max(rows_per, 1), 64);
+        const size_t bits_words = (size_t)G * ((nm_max + 31) / 32) * rows_pad;
+        if ((rc = d_ybuild.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
+        if ((rc = d_bits.ensure(sizeof(uint32_t) * (size_t)n * bits_words))) return rc;
+        if ((rc = d_pre.ensure(sizeof(uint16_t) * (size_t)n * bits_words))) return rc;
         if ((rc = d_cnt.ensure(sizeof(int) * (size_t)n * nf_pad))) return rc;
+        if ((rc = d_flat_i.ensure(sizeof(uint16_t) * (size_t)n * plane))) return rc;
+        if ((rc = d_flat_j.ensure(sizeof(uint16_t) * (size_t)n * plane))) return rc;
+        if ((rc = d_rec0.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
+        if ((rc = d_rec1.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
+        if ((rc = d_surv0.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
+        if ((rc = d_surv1.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
         const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n * 2 * G * XCH_WORDS;
         if ((rc = d_xch.ensure(xch_bytes))) return rc;
         if (want_trace) {
@@ -210,11 +226,18 @@ struct Engine {
             D.moving = pairs[i].moving ? pairs[i].moving->rec() : nullptr;
             D.nf = pairs[i].fixed ? pairs[i].fixed->n : 0;
             D.nm = pairs[i].moving ? pairs[i].moving->n : 0;
-            D.nf_pad = nf_pad; D.cap = cap; D.nm_pad = nm_pad;
+            D.nf_pad = nf_pad; D.rows_pad = rows_pad; D.capf = capf; D.nm_pad = nm_pad;
             D.ybuf = static_cast<float4*>(d_ybuf.p) + (size_t)i * G * nm_pad;
-            D.jlist = static_cast<uint16_t*>(d_jlist.p) + (size_t)i * cap * nf_pad;
-            D.alist = static_cast<float*>(d_alist.p) + (size_t)i * cap * nf_pad;
+            D.ybuild = static_cast<float4*>(d_ybuild.p) + (size_t)i * G * nm_pad;
+            D.bits = static_cast<uint32_t*>(d_bits.p) + (size_t)i * bits_words;
+            D.pre = static_cast<uint16_t*>(d_pre.p) + (size_t)i * bits_words;
             D.cnt = static_cast<int*>(d_cnt.p) + (size_t)i * nf_pad;
+            D.flat_i = static_cast<uint16_t*>(d_flat_i.p) + (size_t)i * plane;
+            D.flat_j = static_cast<uint16_t*>(d_flat_j.p) + (size_t)i * plane;
+            D.rec0 = static_cast<float4*>(d_rec0.p) + (size_t)i * plane;
+            D.rec1 = static_cast<float4*>(d_rec1.p) + (size_t)i * plane;
+            D.surv0 = static_cast<float4*>(d_surv0.p) + (size_t)i * plane;
+            D.surv1 = static_cast<float4*>(d_surv1.p) + (size_t)i * plane;
             D.xch = static_cast<unsigned long long*>(d_xch.p) + (size_t)i * 2 * G * XCH_WORDS;
             D.state = static_cast<PairState*>(d_states.p) + i;
             D.trace = (want_trace && i == 0) ? static_cast<TraceRow*>(d_trace.p) : nullptr;
@@ -699,6 +722,7 @@ int cvo_batch_wait(cvo_batch b, cvo_pair_result* results, int n) {
             std::memcpy(results[i].R, r[i].R, sizeof(float) * 9); std::memcpy(results[i].T, r[i].T, sizeof(float) * 3);
             results[i].ell = r[i].ell; results[i].iter = r[i].iter; results[i].A_nonzero = r[i].A_nonzero;
             results[i].iterations_run = r[i].iterations_run; results[i].status = r[i].status;
+            results[i].rebuilds = r[i].rebuilds; results[i].dense_fallbacks = r[i].dense_fallbacks;
         }
     }
     return CVO_OK;
@@ -711,6 +735,13 @@ int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_t
     for (int i = 0; i < b->last_n; ++i) { it += r[i].iterations_run; ca += r[i].candidates_total; }
     if (iterations_total) *iterations_total = it;
     if (candidates_total) *candidates_total = ca;
+    return CVO_OK;
+}
+int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]) {
+    if (!b || !seconds) return fail(CVO_ERR_INVALID, "null argument");
+    const PairState* r = b->eng.results();
+    for (int q = 0; q < 10; ++q) seconds[q] = 0;
+    for (int i = 0; i < b->last_n; ++i) for (int q = 0; q < 10; ++q) seconds[q] += 1e-8 * (double)r[i].phase_ticks[q];
     return CVO_OK;
 }
 int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stream) {

@@ -11,10 +11,12 @@ namespace cvohip {
 // lane fetches a whole point with two 16-B loads and consecutive lanes stay
 // coalesced.
 constexpr int REC = 8;
+constexpr int MAX_ROWS_PER_WG = 4096;   // fixed-cloud rows one workgroup can own (LDS row-offset table)
 
 struct DevParams {           // cvo.cpp:35-51
     float sigma, sp_thres, c, d, c_ell, c_sigma, min_step, eps, eps_2;
     int max_iter;
+    float skin;              // candidate lists are built with radius (1+skin)*r and reused until the cloud has moved skin*r
 };
 
 // per-pair state, read at kernel start and written back at the end (Q1, Q2)
@@ -24,11 +26,16 @@ struct PairState {
     float ell;
     float transform[12];      // in: cvo::transform before the call; out: final [R^T | -R^T T] (cvo.cpp:817)
     float prev_transform[12]; // out: transform of the last executed iteration (cvo.cpp:815)
-    int iter;            // value of k at the break (stale if max_iter is hit, Q4)
-    int A_nonzero;       // nnz of the last iteration (Q5)
+    int iter;                 // value of k at the break (stale if max_iter is hit, Q4)
+    int A_nonzero;            // nnz of the last iteration (Q5)
     int iterations_run;
     int status;
+    int rebuilds;             // dense culls executed
+    int dense_fallbacks;      // rebuilds whose candidates did not fit the lists (dense per-row path taken)
     long long candidates_total;
+    // wall time (100 MHz ticks) workgroup 0 of the pair spent per phase:
+    // transform+cull+compaction, candidates, reduce/exchange 1, line-search sums, reduce/exchange 2, epilogue
+    unsigned long long phase_ticks[10];   // [6..8]: inside a rebuild: dense cull, row-offset scan, list extraction
 };
 
 struct TraceRow {        // == cvo_trace_row (include/cvo_hip.h)
@@ -51,13 +58,21 @@ struct PairDesc {
     const float* fixed;      // [nf][REC]
     const float* moving;     // [nm][REC]
     int nf, nm;
-    int nf_pad;              // row stride of jlist/alist (multiple of 64)
-    int cap;                 // candidate capacity per row
-    float4* ybuf;            // [G][nm_pad]  transformed moving points {y0,y1,y2,g0}
-    int nm_pad;
-    uint16_t* jlist;         // [cap][nf_pad] candidate column indices, ascending per row
-    float* alist;            // [cap][nf_pad] kernel value of each candidate (0 = not a survivor)
-    int* cnt;                // [nf_pad]      candidates found per row (may exceed cap => dense fallback)
+    int nf_pad, nm_pad;      // multiples of 64
+    int rows_pad;            // rows_per rounded up to 64: row stride of the hit bitmap
+    int capf;                // flat capacity per row, on average (a workgroup owning r rows may hold r*capf candidates)
+    float4* ybuf;            // [G][nm_pad]     transformed moving points {y0,y1,y2,g0}
+    float4* ybuild;          // [G][nm_pad]     the positions the candidate lists were built at
+    uint32_t* bits;          // [G][ceil(nm/32)][rows_pad]  hit bitmap of the last cull (bit 31 = first column of a group)
+    uint16_t* pre;           // same shape: number of hits of the row in earlier groups (the word's offset in its row)
+    int* cnt;                // [nf_pad]        candidates found per row
+    // flat arrays: plane = (nf_pad + G) * capf entries; workgroup g owns [g*rows_per*capf, (g+1)*rows_per*capf)
+    uint16_t* flat_i;        // compacted candidates: local row index ...
+    uint16_t* flat_j;        // ... and column; a row's candidates are contiguous, columns ascending
+    float4* rec0;            // per candidate, this iteration: {a*(x cross y), a*(y-x).x}
+    float4* rec1;            //                                {a*(y-x).y, a*(y-x).z, a, 0}   (all 0 when not in A)
+    float4* surv0;           // survivors compacted per wave chunk, in candidate order: {x_i, a}
+    float4* surv1;           //                                                         {y_j, 0}
     unsigned long long* xch; // [2][G][XCH_WORDS]
     PairState* state;
     TraceRow* trace;         // optional
@@ -74,7 +89,7 @@ struct ScoreDesc {
     int use_tran;
     float ell;
     int want_hessian;        // 0: inner product only, 1: Hessian terms too
-    double* out;             // [24]: 0 = sum_A, 1 = count, 2..22 = 21 upper-triangle Hessian terms (f64 of f32 row sums)
+    double* out;
 };
 
 }  // namespace cvohip

@@ -63,23 +63,38 @@ CVO_HD float gate_d2c(float c_ell, float sp_thres, float c_sigma) { return (floa
 // The reference takes f32 eigenvalues of the companion matrix of the monic cubic
 // and keeps those with imag()==0; the real roots are computed here in closed form
 // (double) from the same f32 monic coefficients.
-// Real roots of the monic cubic t^3 + a t^2 + b t + c (double).  One root by a
-// bracketed Newton iteration (always converges: f(-R) < 0 < f(R) for the Cauchy
-// bound R), the other two from the deflated quadratic (deflation direction chosen
+// Real roots of the monic cubic t^3 + a t^2 + b t + c (double).  One root by Newton
+// from 0, falling back to a bracketed Newton iteration (always converges: f(-R) < 0 < f(R)
+// for the Cauchy bound R), the other two from the deflated quadratic (deflation direction chosen
 // by the root's size so no cancellation), each polished on the full cubic.  Plain
 // Cardano loses the sign of the discriminant when the roots differ by many orders
 // of magnitude.
 CVO_HD int cubic_real_roots(double a, double b, double c, double* roots) {
-    const double R = 1.0 + fmax(fabs(a), fmax(fabs(b), fabs(c)));
-    double lo = -R, hi = R, x = 0.0;
-    for (int it = 0; it < 200; ++it) {
+    // fast path: plain Newton from t = 0 (the step the line search wants is normally the small
+    // root next to 0); accepted only if it converges, otherwise the bracketed iteration below.
+    double x = 0.0;
+    bool conv = false;
+    for (int it = 0; it < 12; ++it) {
         const double f = ((x + a) * x + b) * x + c, df = (3.0 * x + 2.0 * a) * x + b;
-        if (f == 0.0) break;
-        if (f < 0) lo = x; else hi = x;
-        double xn = x - f / df;
-        if (!(df != 0.0) || !(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        if (fabs(xn - x) <= 1e-16 * fabs(xn) || xn == x) { x = xn; break; }
+        if (f == 0.0) { conv = true; break; }
+        const double xn = x - f / df;
+        if (!(df != 0.0) || !isfinite(xn)) break;
+        if (fabs(xn - x) <= 1e-15 * fabs(xn)) { x = xn; conv = true; break; }
         x = xn;
+    }
+    if (!conv) {
+        const double R = 1.0 + fmax(fabs(a), fmax(fabs(b), fabs(c)));
+        double lo = -R, hi = R;
+        x = 0.0;
+        for (int it = 0; it < 200; ++it) {
+            const double f = ((x + a) * x + b) * x + c, df = (3.0 * x + 2.0 * a) * x + b;
+            if (f == 0.0) break;
+            if (f < 0) lo = x; else hi = x;
+            double xn = x - f / df;
+            if (!(df != 0.0) || !(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+            if (fabs(xn - x) <= 1e-16 * fabs(xn) || xn == x) { x = xn; break; }
+            x = xn;
+        }
     }
     const double r = x;
     roots[0] = r;
@@ -93,12 +108,10 @@ CVO_HD int cubic_real_roots(double a, double b, double c, double* roots) {
     double* rr[2] = {&r2, &r3};
     for (int k = 0; k < 2; ++k) {
         double t = *rr[k];
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 2; ++it) {          // the deflated roots are already good to ~1e-15; two Newton steps on the full cubic
             const double f = ((t + a) * t + b) * t + c, df = (3.0 * t + 2.0 * a) * t + b;
             const double tn = t - f / df;
             if (!(df != 0.0) || !isfinite(tn)) break;
-            const double fn = ((tn + a) * tn + b) * tn + c;
-            if (fabs(fn) > fabs(f)) break;
             t = tn;
         }
         *rr[k] = t;
@@ -155,12 +168,21 @@ CVO_HD float dist_se3(const float* dR, const float* dT) {
     const double w[3] = {0.5 * ((double)dR[7] - dR[5]), 0.5 * ((double)dR[2] - dR[6]), 0.5 * ((double)dR[3] - dR[1])};
     const double s = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     const double c = 0.5 * ((double)dR[0] + dR[4] + dR[8] - 1.0);
-    const double theta = atan2(s, c);
+    // theta = atan2(s, c) and the V^-1 coefficient 1/theta^2 - (1+cos)/(2 theta sin): for the small
+    // per-iteration rotations (s < 0.1, c > 0) both come from their series (error < 1e-13), no trig
+    double theta, coef;
+    if (s < 0.1 && c > 0.0) {
+        const double s2 = s * s;
+        theta = s * (1.0 + s2 * (1.0 / 6.0 + s2 * (3.0 / 40.0 + s2 * (15.0 / 336.0 + s2 * (105.0 / 3456.0)))));   // asin(s)
+        const double t2 = theta * theta;
+        coef = 1.0 / 12.0 + t2 * (1.0 / 720.0 + t2 * (1.0 / 30240.0 + t2 * (1.0 / 1209600.0)));
+    } else {
+        theta = atan2(s, c);
+        coef = (theta < 1e-4) ? 1.0 / 12.0 + theta * theta / 720.0
+                              : 1.0 / (theta * theta) - (1.0 + cos(theta)) / (2.0 * theta * sin(theta));
+    }
     double phi[3] = {w[0], w[1], w[2]};
     if (s > 1e-300) { const double f = theta / s; for (int k = 0; k < 3; ++k) phi[k] *= f; }
-    double coef;
-    if (theta < 1e-4) coef = 1.0 / 12.0 + theta * theta / 720.0;
-    else coef = 1.0 / (theta * theta) - (1.0 + cos(theta)) / (2.0 * theta * sin(theta));
     const double t[3] = {dT[0], dT[1], dT[2]};
     const double pxt[3] = {phi[1] * t[2] - phi[2] * t[1], phi[2] * t[0] - phi[0] * t[2], phi[0] * t[1] - phi[1] * t[0]};
     const double ppxt[3] = {phi[1] * pxt[2] - phi[2] * pxt[1], phi[2] * pxt[0] - phi[0] * pxt[2], phi[0] * pxt[1] - phi[1] * pxt[0]};

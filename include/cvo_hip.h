@@ -158,6 +158,8 @@ typedef struct cvo_pair_result {       /* what match_keyframe + the getters retu
     int   A_nonzero;                   /* get_A_nonzero (Q5) */
     int   iterations_run;              /* loop trips executed = iter+1 on a break */
     int   status;                      /* CVO_OK / CVO_ERR_* for this pair */
+    int   rebuilds;                    /* dense O(N*M) culls executed (candidate lists are reused between them) */
+    int   dense_fallbacks;             /* culls whose candidates overflowed the lists (slow per-row path taken) */
 } cvo_pair_result;
 
 int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* out);
@@ -176,6 +178,11 @@ int cvo_batch_align_async(cvo_batch b, int n_pairs, void* stream);
 int cvo_batch_wait(cvo_batch b, cvo_pair_result* results, int n);
 /* device time of the last launch in ms (HIP events on the launch stream), total loop trips it executed */
 int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_total, long long* candidates_total);
+/* where the last launch spent its time: seconds summed over pairs (as seen by workgroup 0 of each
+ * pair) in the phases {transform + list rebuild, candidates, reduce/exchange 1, line-search sums,
+ * reduce/exchange 2, scalar epilogue, then inside rebuilds: dense cull, row-offset scan, list extraction,
+ * unused} */
+int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]);
 /* pack the last launch's results into a caller-owned DEVICE buffer of n records of
  * CVO_RESULT_FLOATS floats {transform[12], iter, A_nonzero, iterations_run, status},
  * enqueued on `stream` (NULL = the launch's stream): the payload of the cross-GPU

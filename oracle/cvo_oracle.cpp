@@ -357,23 +357,38 @@ void compute_flow(orc_cvo* o) {
 // f32 monic coefficients (double arithmetic): real roots of a real cubic = the
 // eigenvalues with zero imaginary part.  coef(0)==0 gives inf/NaN entries, no
 // eigenvalue qualifies, and the caller falls back to min_step.
-// Real roots of the monic cubic t^3 + a t^2 + b t + c (double).  One root by a
-// bracketed Newton iteration (always converges: f(-R) < 0 < f(R) for the Cauchy
-// bound R), the other two from the deflated quadratic (deflation direction chosen
+// Real roots of the monic cubic t^3 + a t^2 + b t + c (double).  One root by Newton
+// from 0, falling back to a bracketed Newton iteration (always converges: f(-R) < 0 < f(R)
+// for the Cauchy bound R), the other two from the deflated quadratic (deflation direction chosen
 // by the root's size so no cancellation), each polished on the full cubic.  Plain
 // Cardano loses the sign of the discriminant when the roots differ by many orders
 // of magnitude.
 static int cubic_real_roots(double a, double b, double c, double* roots) {
-    const double R = 1.0 + std::fmax(std::fabs(a), std::fmax(std::fabs(b), std::fabs(c)));
-    double lo = -R, hi = R, x = 0.0;
-    for (int it = 0; it < 200; ++it) {
+    // fast path: plain Newton from t = 0 (the step the line search wants is normally the small
+    // root next to 0); accepted only if it converges, otherwise the bracketed iteration below.
+    double x = 0.0;
+    bool conv = false;
+    for (int it = 0; it < 12; ++it) {
         const double f = ((x + a) * x + b) * x + c, df = (3.0 * x + 2.0 * a) * x + b;
-        if (f == 0.0) break;
-        if (f < 0) lo = x; else hi = x;
-        double xn = x - f / df;
-        if (!(df != 0.0) || !(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        if (std::fabs(xn - x) <= 1e-16 * std::fabs(xn) || xn == x) { x = xn; break; }
+        if (f == 0.0) { conv = true; break; }
+        const double xn = x - f / df;
+        if (!(df != 0.0) || !std::isfinite(xn)) break;
+        if (std::fabs(xn - x) <= 1e-15 * std::fabs(xn)) { x = xn; conv = true; break; }
         x = xn;
+    }
+    if (!conv) {
+        const double R = 1.0 + std::fmax(std::fabs(a), std::fmax(std::fabs(b), std::fabs(c)));
+        double lo = -R, hi = R;
+        x = 0.0;
+        for (int it = 0; it < 200; ++it) {
+            const double f = ((x + a) * x + b) * x + c, df = (3.0 * x + 2.0 * a) * x + b;
+            if (f == 0.0) break;
+            if (f < 0) lo = x; else hi = x;
+            double xn = x - f / df;
+            if (!(df != 0.0) || !(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+            if (std::fabs(xn - x) <= 1e-16 * std::fabs(xn) || xn == x) { x = xn; break; }
+            x = xn;
+        }
     }
     const double r = x;
     roots[0] = r;
@@ -387,12 +402,10 @@ static int cubic_real_roots(double a, double b, double c, double* roots) {
     double* rr[2] = {&r2, &r3};
     for (int k = 0; k < 2; ++k) {
         double t = *rr[k];
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 2; ++it) {          // the deflated roots are already good to ~1e-15; two Newton steps on the full cubic
             const double f = ((t + a) * t + b) * t + c, df = (3.0 * t + 2.0 * a) * t + b;
             const double tn = t - f / df;
             if (!(df != 0.0) || !std::isfinite(tn)) break;
-            const double fn = ((tn + a) * tn + b) * tn + c;
-            if (std::fabs(fn) > std::fabs(f)) break;
             t = tn;
         }
         *rr[k] = t;

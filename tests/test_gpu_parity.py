@@ -118,8 +118,9 @@ def test_seeded_pairs_vs_oracle(hiplib, oracle, seed, n):
 def test_workgroup_counts_tiles_and_overflow_fallback_agree(hiplib, oracle):
     """The same alignment under every decomposition knob: workgroups per pair (incl. a
     non-power-of-two and more workgroups than 64-row blocks), LDS tile smaller than the
-    cloud (multi-tile streaming) and a candidate capacity so small that every row takes
-    the dense fallback.  All must land on the oracle's pose and sparse-set sizes."""
+    cloud (multi-tile streaming), flat candidate capacities so small that the dense
+    per-row fallback runs, and candidate-list skins from 0 (cull every iteration)
+    to 150 % (one cull per ell).  All must land on the oracle's pose and sparse-set sizes."""
     from cvo_slam_amd import synth
     p = synth.make_small_pair(55, n=900)
     fixed, moving = (p.fixed.xyz, p.fixed.feat), (p.moving.xyz, p.moving.feat)
@@ -127,7 +128,8 @@ def test_workgroup_counts_tiles_and_overflow_fallback_agree(hiplib, oracle):
     want_nnz = [r["nnz"] for r in otr]
     ost = o.get_state()
     configs = [dict(wgs=1), dict(wgs=2), dict(wgs=7), dict(wgs=32), dict(wgs=1, CVO_HIP_TILE=128), dict(wgs=4, CVO_HIP_TILE=252),
-               dict(wgs=1, CVO_HIP_CAND_CAP=4), dict(wgs=5, CVO_HIP_CAND_CAP=1, CVO_HIP_TILE=64)]
+               dict(wgs=1, CVO_HIP_FLAT_CAP=4), dict(wgs=5, CVO_HIP_FLAT_CAP=1, CVO_HIP_TILE=64), dict(wgs=3, CVO_HIP_FLAT_CAP=1),
+               dict(wgs=2, CVO_HIP_SKIN=0.0), dict(wgs=2, CVO_HIP_SKIN=0.02), dict(wgs=4, CVO_HIP_SKIN=1.5)]
     for cfg in configs:
         envs = {k: v for k, v in cfg.items() if k.startswith("CVO_")}
         with env(**envs):
