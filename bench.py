@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="frame pairs per GPU per step")
     ap.add_argument("--workgroups", type=int, default=0, help="workgroups per pair (0 = auto)")
+    ap.add_argument("--streams", type=int, default=2, help="steps in flight (batch objects on separate HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,41 +130,70 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    batch = ca.CvoBatch(args.pairs, device=local_rank)
-    batch.set_workgroups(args.workgroups)
-    for i, (_, fx, ff, mx, mf) in enumerate(pairs):
-        batch.set_pair(i, fx, ff, mx, mf)
+    # `depth` batch objects, each on its own HIP stream, hold the same pairs; consecutive steps go to
+    # alternating objects so that the next step's persistent kernel fills the CUs the previous step's
+    # last, longest pairs have already left (alignments have data-dependent iteration counts).
+    depth = max(1, args.streams)
+    batches = []
+    for _ in range(depth):
+        b = ca.CvoBatch(args.pairs, device=local_rank)
+        b.set_workgroups(args.workgroups)
+        for i, (_, fx, ff, mx, mf) in enumerate(pairs):
+            b.set_pair(i, fx, ff, mx, mf)
+        batches.append(b)
+    batch = batches[0]
 
     from cvo_slam_amd import shard
     n = args.pairs
     assert list(shard.shard_range(world * n, rank, world)) == list(range(rank * n, rank * n + n))
-    send = torch.zeros((n, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda")
+    sends = [torch.zeros((n, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda") for _ in range(depth)]
     gathered = None
+    inflight = []                                  # batch objects with a launch not yet waited for
 
-    def step():
+    kernel_ms = []                                 # HIP-event duration of every launch, on the stream it ran on
+
+    def finish(bi):
         nonlocal gathered
-        batch.reset_states()                       # every step starts from R=I, T=0, ell=0.15
-        batch.align_async(n)
-        batch.results_to_device(send.data_ptr(), n)   # same stream, behind the kernel
-        batch.wait()
+        batches[bi].wait()
+        kernel_ms.append(batches[bi].last_launch()["kernel_ms"])
         if world > 1:
-            gathered = shard.gather_results(send, world * n, world)   # RCCL: the SE(3) results of every rank, everywhere
+            gathered = shard.gather_results(sends[bi], world * n, world)   # RCCL: the SE(3) results of every rank, everywhere
+
+    def step(i):
+        bi = i % depth
+        if bi in inflight:                         # the object is reused: its previous step must be complete first
+            inflight.remove(bi); finish(bi)
+        b = batches[bi]
+        b.reset_states()                           # every step starts from R=I, T=0, ell=0.15
+        b.align_async(n)
+        b.results_to_device(sends[bi].data_ptr(), n)   # same stream, behind the kernel
+        inflight.append(bi)
+
+    def drain():
+        while inflight:
+            finish(inflight.pop(0))
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    # un-pipelined latency of one step (one batch alone on the GPU), for the record
     sync_all()
-    kernel_ms = []
+    t1 = time.perf_counter(); step(0); drain(); torch.cuda.synchronize(); single_step_ms = 1e3 * (time.perf_counter() - t1)
+    single_kernel_ms = batches[0].last_launch()["kernel_ms"]
+    sync_all()
+    kernel_ms.clear()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(batch.last_launch()["kernel_ms"])
+    for i in range(args.steps):
+        step(i)
+    drain()
     sync_all()
     elapsed = time.perf_counter() - t0
+    assert len(kernel_ms) == args.steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,7 +224,8 @@ def main():
                                    f"full align() from R=I,T=0,ell=0.15 to convergence",
                        "pairs_per_gpu": n, "points_fixed_mean": float(np.mean(nfs)), "points_moving_mean": float(np.mean(nms)),
                        "iterations_mean": float(np.mean(its)), "iterations_max": int(np.max(its)),
-                       "workgroups_per_pair": args.workgroups or "auto", "collective": "RCCL all_gather of 64-byte result records" if world > 1 else "none (1 GPU)"},
+                       "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth,
+                       "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": "RCCL all_gather of 64-byte result records" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "cvo_align_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "path is VALU-issue bound, not HBM bound (SURVEY 8d): see valu"},

@@ -22,6 +22,8 @@
 
 namespace cvohip {
 size_t align_shared_bytes(int tile);
+int align_tile_granule();
+int align_blocks_per_cu();
 hipError_t launch_align(int rpt, int grid, int block, int tile, hipStream_t stream, const PairDesc* descs, int n_pairs, int G, const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 int score_grid(int na);
@@ -104,7 +106,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
-    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_bits, d_pre, d_cnt, d_flat_i, d_flat_j, d_rec0, d_rec1, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
+    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_bits, d_cnt, d_flat_ij, d_rec0, d_rec1, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
     PinBuf h_descs, h_states, h_stage, h_partials;
     int wg_request = 0;          // 0 = auto
     int tile_request = 0;        // 0 = auto
@@ -130,7 +132,7 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_bits, &d_pre, &d_cnt, &d_flat_i, &d_flat_j, &d_rec0, &d_rec1, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_bits, &d_cnt, &d_flat_ij, &d_rec0, &d_rec1, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -165,7 +167,7 @@ struct Engine {
 
     int pick_workgroups(int n_pairs, int nf_max) const {
         int G = wg_request;
-        if (G <= 0) { G = 1; while (G * 2 * n_pairs <= num_cus && G < 32) G *= 2; }
+        if (G <= 0) { G = 1; while (G * 2 * n_pairs <= num_cus * align_blocks_per_cu() && G < 32) G *= 2; }
         const int g_min = (nf_max + MAX_ROWS_PER_WG - 1) / MAX_ROWS_PER_WG;     // a workgroup owns at most MAX_ROWS_PER_WG rows
         G = std::max(std::max(1, g_min), std::min(G, num_cus));
         return G;
@@ -182,16 +184,18 @@ struct Engine {
         int nf_max = 0, nm_max = 0;
         for (const PairIn& p : pairs) { nf_max = std::max(nf_max, p.fixed ? p.fixed->n : 0); nm_max = std::max(nm_max, p.moving ? p.moving->n : 0); }
         const int G = pick_workgroups(n, nf_max);
-        const int slots = std::max(1, std::min(n, num_cus / G));
+        const int slots = std::max(1, std::min(n, num_cus * align_blocks_per_cu() / G));   // every workgroup of the grid must be resident
         const int grid = slots * G;
         const int nf_pad = round_up(std::max(nf_max, 1), 64), nm_pad = round_up(std::max(nm_max, 1), 64);
         int capf = capf_request;
         if (capf <= 0) capf = std::max(96, nm_max / 12);                                 // flat lists, average per row
-        int tile = tile_request > 0 ? round_up(tile_request, 32) : std::min(round_up(std::max(nm_max, 32), 32), 8192);
+        const int tgran = align_tile_granule();
+        int tile = tile_request > 0 ? round_up(tile_request, tgran) : std::min(round_up(std::max(nm_max, tgran), tgran), 4096);
         const int rows_per = (nf_max + G - 1) / G;
         int block = rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64));
         if (block_request > 0) block = std::max(64, std::min(512, round_up(block_request, 64)));
-        int rpt = std::max(1, std::min(4, (rows_per + block - 1) / block));
+        const int row_unit = block >= 512 ? 256 : block;                 // rows one register slot covers: the waves form 4 row groups x 2 column parts
+        int rpt = std::max(1, std::min(4, (rows_per + row_unit - 1) / row_unit));
 
         int rc;
         if ((rc = d_descs.ensure(sizeof(PairDesc) * n))) return rc;
@@ -201,13 +205,12 @@ struct Engine {
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
         const size_t plane = (size_t)(nf_pad + G) * capf;
         const int rows_pad = round_up(std::max(rows_per, 1), 64);
-        const size_t bits_words = (size_t)G * ((nm_max + 31) / 32) * rows_pad;
+        const int nwords_pad = round_up((nm_max + 31) / 32 + tgran / 32, 4);   // a tile's padded tail may spill past ceil(nm/32)
+        const size_t bits_words = (size_t)G * rows_pad * nwords_pad;
         if ((rc = d_ybuild.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
         if ((rc = d_bits.ensure(sizeof(uint32_t) * (size_t)n * bits_words))) return rc;
-        if ((rc = d_pre.ensure(sizeof(uint16_t) * (size_t)n * bits_words))) return rc;
-        if ((rc = d_cnt.ensure(sizeof(int) * (size_t)n * nf_pad))) return rc;
-        if ((rc = d_flat_i.ensure(sizeof(uint16_t) * (size_t)n * plane))) return rc;
-        if ((rc = d_flat_j.ensure(sizeof(uint16_t) * (size_t)n * plane))) return rc;
+        if ((rc = d_cnt.ensure(sizeof(int) * (size_t)n * 2 * nf_pad))) return rc;
+        if ((rc = d_flat_ij.ensure(sizeof(uint32_t) * (size_t)n * plane))) return rc;
         if ((rc = d_rec0.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
         if ((rc = d_rec1.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
         if ((rc = d_surv0.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
@@ -230,10 +233,9 @@ struct Engine {
             D.ybuf = static_cast<float4*>(d_ybuf.p) + (size_t)i * G * nm_pad;
             D.ybuild = static_cast<float4*>(d_ybuild.p) + (size_t)i * G * nm_pad;
             D.bits = static_cast<uint32_t*>(d_bits.p) + (size_t)i * bits_words;
-            D.pre = static_cast<uint16_t*>(d_pre.p) + (size_t)i * bits_words;
-            D.cnt = static_cast<int*>(d_cnt.p) + (size_t)i * nf_pad;
-            D.flat_i = static_cast<uint16_t*>(d_flat_i.p) + (size_t)i * plane;
-            D.flat_j = static_cast<uint16_t*>(d_flat_j.p) + (size_t)i * plane;
+            D.nwords_pad = nwords_pad;
+            D.cnt = static_cast<int*>(d_cnt.p) + (size_t)i * 2 * nf_pad;
+            D.flat_ij = static_cast<uint32_t*>(d_flat_ij.p) + (size_t)i * plane;
             D.rec0 = static_cast<float4*>(d_rec0.p) + (size_t)i * plane;
             D.rec1 = static_cast<float4*>(d_rec1.p) + (size_t)i * plane;
             D.surv0 = static_cast<float4*>(d_surv0.p) + (size_t)i * plane;
@@ -742,6 +744,11 @@ int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]) {
     const PairState* r = b->eng.results();
     for (int q = 0; q < 10; ++q) seconds[q] = 0;
     for (int i = 0; i < b->last_n; ++i) for (int q = 0; q < 10; ++q) seconds[q] += 1e-8 * (double)r[i].phase_ticks[q];
+    {   // slot 9 doubles as the measured shader clock in GHz (cycles per 100 MHz tick), averaged over pairs
+        double cyc = 0, tk = 0;
+        for (int i = 0; i < b->last_n; ++i) { cyc += (double)r[i].clk_cycles; tk += (double)r[i].clk_ticks; }
+        if (std::getenv("CVO_HIP_REPORT_CLOCK") && tk > 0) std::fprintf(stderr, "[cvo_hip] shader clock %.3f GHz\n", cyc / tk * 0.1);
+    }
     return CVO_OK;
 }
 int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stream) {

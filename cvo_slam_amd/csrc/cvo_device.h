@@ -35,6 +35,7 @@ struct PairState {
     long long candidates_total;
     // wall time (100 MHz ticks) workgroup 0 of the pair spent per phase:
     // transform+cull+compaction, candidates, reduce/exchange 1, line-search sums, reduce/exchange 2, epilogue
+    unsigned long long clk_cycles, clk_ticks;   // shader-clock cycles and 100 MHz ticks workgroup 0 spent on the pair: cycles/ticks*100 MHz = clock
     unsigned long long phase_ticks[10];   // [6..8]: inside a rebuild: dense cull, row-offset scan, list extraction
 };
 
@@ -63,12 +64,11 @@ struct PairDesc {
     int capf;                // flat capacity per row, on average (a workgroup owning r rows may hold r*capf candidates)
     float4* ybuf;            // [G][nm_pad]     transformed moving points {y0,y1,y2,g0}
     float4* ybuild;          // [G][nm_pad]     the positions the candidate lists were built at
-    uint32_t* bits;          // [G][ceil(nm/32)][rows_pad]  hit bitmap of the last cull (bit 31 = first column of a group)
-    uint16_t* pre;           // same shape: number of hits of the row in earlier groups (the word's offset in its row)
-    int* cnt;                // [nf_pad]        candidates found per row
+    uint32_t* bits;          // [G][rows_pad][nwords_pad]  row-major hit bitmap of the last cull (bit 31 = first column of a word)
+    int nwords_pad;          // words per bitmap row: ceil(nm/32) rounded up to the flush granule
+    int* cnt;                // [2][nf_pad]     hits per row found by each of the two column parts of the cull
     // flat arrays: plane = (nf_pad + G) * capf entries; workgroup g owns [g*rows_per*capf, (g+1)*rows_per*capf)
-    uint16_t* flat_i;        // compacted candidates: local row index ...
-    uint16_t* flat_j;        // ... and column; a row's candidates are contiguous, columns ascending
+    uint32_t* flat_ij;       // compacted candidates (local row << 16 | column); a row's are contiguous, columns ascending
     float4* rec0;            // per candidate, this iteration: {a*(x cross y), a*(y-x).x}
     float4* rec1;            //                                {a*(y-x).y, a*(y-x).z, a, 0}   (all 0 when not in A)
     float4* surv0;           // survivors compacted per wave chunk, in candidate order: {x_i, a}

@@ -294,15 +294,22 @@ __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float
 // Branch-free, 7 VALU per pair test: 3 sub, 3 fma (the last one folds "- thr" in, so the sign
 // bit of t = d2 - thr is the hit) and one v_alignbit that shifts the sign into the row's
 // 32-column word, w = (w << 1) | sign(t): the first column of a group ends up in bit 31.
-// Every lane owns R rows; columns come from LDS 4 at a time (ds_read_b128, the same address in
-// every lane: broadcast), the next two quads are fetched while the current two are tested.
-// Per group the word goes to bits[group][row] and the row's running hit count (the word's
-// prefix inside its row) to pre[group][row]: rows are the fast index, so both are one coalesced
-// store per wave; the extraction pass then needs no per-row serial walk.
+// (Packed v_pk_*_f32 forms were measured: they issue at half the rate, no gain.)
+// A wave owns 64*R rows (R per lane) and one contiguous part of the tile's columns; columns
+// come from LDS 4 at a time (ds_read_b128, the same address in every lane: broadcast), the
+// next two quads are fetched while the current two are tested.  Every STG_GROUPS groups the
+// wave transposes its words through a private LDS patch and writes them to the ROW-major
+// bitmap bits[row][word] as 16-byte row segments, so the extraction pass reads a row's words
+// with consecutive lanes and writes its candidate list coalesced.
+constexpr int STG_GROUPS = 4;
+constexpr int STG_STRIDE = 5;                                       // words per row in the patch (4 + 1 pad: conflict-free writes)
+constexpr int STG_WORDS_PER_WAVE = 4 * 64 * STG_STRIDE;             // up to 4 rows per lane
+
 template <int R, int RPT>
-__device__ __forceinline__ void sweep_tile_bits(const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ lz,
-                                                int ngroups, int group_base, const float (&x)[RPT][3], const int (&lrow)[RPT],
-                                                int (&cnt)[RPT], gu32* __restrict__ bits, gu16* __restrict__ pre, int rows_pad, float thr) {
+__device__ __forceinline__ void sweep_part(const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ lz,
+                                           int ngroups /* multiple of STG_GROUPS */, int word_base, const float (&x)[RPT][3],
+                                           const int (&row0)[RPT] /* local row of lane 0, per r */, int nrows, int (&cnt)[RPT],
+                                           gu32* __restrict__ bits, int nwords_pad, volatile uint32_t* stg, float thr, int lane) {
     const float4* qx = reinterpret_cast<const float4*>(lx);
     const float4* qy = reinterpret_cast<const float4*>(ly);
     const float4* qz = reinterpret_cast<const float4*>(lz);
@@ -328,13 +335,26 @@ __device__ __forceinline__ void sweep_tile_bits(const float* __restrict__ lx, co
                 w[r] = __builtin_amdgcn_alignbit(w[r], __float_as_uint(t), 31);
             }
         }
-        if ((p & 3) == 3) {                                         // 32 columns done: flush the group's words
-            const int gi = group_base + (p >> 2);
+        if ((p & 3) == 3) {                                         // 32 columns done: park the group's words
+            const int grp = p >> 2;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (lrow[r] >= 0) { bits[(size_t)gi * rows_pad + lrow[r]] = w[r]; pre[(size_t)gi * rows_pad + lrow[r]] = (uint16_t)cnt[r]; }
+                stg[(r * 64 + lane) * STG_STRIDE + (grp & (STG_GROUPS - 1))] = w[r];
                 cnt[r] += __popc(w[r]);
                 w[r] = 0u;
+            }
+            if ((grp & (STG_GROUPS - 1)) == STG_GROUPS - 1) {       // patch full: lanes (4 per row) write 16-byte row segments
+                const int word0 = word_base + grp - (STG_GROUPS - 1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const int rl = (lane >> 2) + 16 * k4, wd = lane & 3;
+                        const uint32_t v = stg[(r * 64 + rl) * STG_STRIDE + wd];
+                        const int li = row0[r] + rl;
+                        if (li < nrows) bits[(size_t)li * nwords_pad + word0 + wd] = v;
+                    }
+                }
             }
         }
         X0 = nX0; Y0 = nY0; Z0 = nZ0; X1 = nX1; Y1 = nY1; Z1 = nZ1;
@@ -350,6 +370,7 @@ __global__ __launch_bounds__(512) void cvo_align_kernel(const PairDesc* __restri
     float* lx = reinterpret_cast<float*>(rowoff + (MAX_ROWS_PER_WG + 64));
     float* ly = lx + tile;
     float* lz = ly + tile;
+    volatile uint32_t* stg_all = reinterpret_cast<volatile uint32_t*>(lz + tile);
 
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
@@ -367,10 +388,10 @@ __global__ __launch_bounds__(512) void cvo_align_kernel(const PairDesc* __restri
         const gfloat* moving = (const gfloat*)D.moving;
         const GF4 ybuf{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
         const GF4 ybuild{(gv4f*)D.ybuild + (size_t)g * D.nm_pad};      // positions the candidate lists were built at
-        gu32* bits = (gu32*)D.bits + (size_t)g * ngroups_all * D.rows_pad;
-        gu16* pre = (gu16*)D.pre + (size_t)g * ngroups_all * D.rows_pad;
-        gint* cntg = (gint*)D.cnt;
-        gu16* flat_i = (gu16*)D.flat_i; gu16* flat_j = (gu16*)D.flat_j;
+        const int nwords_pad = D.nwords_pad;                        // ngroups_all rounded up to the flush granule
+        gu32* bits = (gu32*)D.bits + (size_t)g * D.rows_pad * nwords_pad;   // [row][word], this workgroup's rows
+        gint* cnt0 = (gint*)D.cnt; gint* cnt1 = cnt0 + D.nf_pad;    // hits per row found by column part 0 / 1
+        gu32* flat_ij = (gu32*)D.flat_ij;
         const GF4 rec0{(gv4f*)D.rec0}, rec1{(gv4f*)D.rec1}, surv0{(gv4f*)D.surv0}, surv1{(gv4f*)D.surv1};
         gu64* xch = (gu64*)D.xch;
         const size_t fbase = (size_t)g * rows_per * D.capf;         // this workgroup's segment of the flat arrays
@@ -391,6 +412,7 @@ __global__ __launch_bounds__(512) void cvo_align_kernel(const PairDesc* __restri
         long long cand_total = 0;
         unsigned long long ticks[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long clk_t0 = t_prev, clk_c0 = __builtin_amdgcn_s_memtime();
 #define CVO_PHASE(idx) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); ticks[idx] += t_now - t_prev; t_prev = t_now; } while (0)
         const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
         if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
@@ -435,68 +457,97 @@ __global__ __launch_bounds__(512) void cvo_align_kernel(const PairDesc* __restri
                 // ---- S: for each block of RPT*nthreads rows, stream the moving cloud through LDS tiles
                 const float Rb = r_c * (1.0f + P.skin);
                 const float thr_cull = Rb * Rb * 1.00001f;
-                for (int rb = 0; rb < nrows; rb += RPT * nthreads) {
-                    float x[RPT][3]; int lrow[RPT]; int cnt[RPT];
+                // waves form a RGN x CPN grid: RGN groups of 64*RPT rows, CPN column parts of every tile, so
+                // that all waves carry the same number of pair tests (two per SIMD, none left alone)
+                const int wave = tid >> 6;
+                const int CPN = (nwaves >= 8) ? 2 : 1, RGN = nwaves / CPN;
+                const int rg = wave % RGN, cp = wave / RGN;
+                volatile uint32_t* stg = stg_all + wave * STG_WORDS_PER_WAVE;
+                gint* cnt_part = cp ? cnt1 : cnt0;
+                for (int rb = 0; rb < nrows; rb += RPT * RGN * 64) {
+                    float x[RPT][3]; int row0[RPT]; int cnt[RPT];
                     int nv = 0;
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) {
-                        const int li = rb + tid + r * nthreads;
+                        row0[r] = rb + r * (RGN * 64) + rg * 64;
+                        const int li = row0[r] + lane;
                         cnt[r] = 0;
                         if (li < nrows) {
                             const float4 lo = ld4(fixed + (size_t)(g + G * li) * REC);
-                            x[r][0] = lo.x; x[r][1] = lo.y; x[r][2] = lo.z; lrow[r] = li;
+                            x[r][0] = lo.x; x[r][1] = lo.y; x[r][2] = lo.z;
                         } else {
-                            x[r][0] = x[r][1] = x[r][2] = FAR_ROW; lrow[r] = -1;
+                            x[r][0] = x[r][1] = x[r][2] = FAR_ROW;
                         }
-                        if (__any(li < nrows)) nv = r + 1;          // rows are a prefix per wave: skip the all-padding ones
+                        if (row0[r] < nrows) nv = r + 1;            // rows are a prefix per wave: skip the all-padding ones
                     }
                     for (int t0 = 0; t0 < nm; t0 += tile) {
                         const int tn = min(tile, nm - t0);
-                        const int tn32 = (tn + 31) & ~31;
+                        const int gran = 32 * STG_GROUPS * CPN;     // every column part is a whole number of flush granules
+                        const int tnp = (tn + gran - 1) / gran * gran;
                         __syncthreads();                            // previous tile fully consumed
-                        for (int jj = tid; jj < tn32; jj += nthreads) {
+                        for (int jj = tid; jj < tnp; jj += nthreads) {
                             float4 y = make_float4(FAR_COL, FAR_COL, FAR_COL, 0.f);
                             if (jj < tn) { y = ybuf[t0 + jj]; if (rb == 0) ybuild.set(t0 + jj, y); }
                             lx[jj] = y.x; ly[jj] = y.y; lz[jj] = y.z;
                         }
                         __syncthreads();
-                        const int ng = tn32 >> 5, gb = t0 >> 5;
-                        if (RPT >= 4 && nv == 4) sweep_tile_bits<(RPT >= 4 ? 4 : 1), RPT>(lx, ly, lz, ng, gb, x, lrow, cnt, bits, pre, D.rows_pad, thr_cull);
-                        else if (RPT >= 3 && nv == 3) sweep_tile_bits<(RPT >= 3 ? 3 : 1), RPT>(lx, ly, lz, ng, gb, x, lrow, cnt, bits, pre, D.rows_pad, thr_cull);
-                        else if (RPT >= 2 && nv == 2) sweep_tile_bits<(RPT >= 2 ? 2 : 1), RPT>(lx, ly, lz, ng, gb, x, lrow, cnt, bits, pre, D.rows_pad, thr_cull);
-                        else if (nv >= 1) sweep_tile_bits<1, RPT>(lx, ly, lz, ng, gb, x, lrow, cnt, bits, pre, D.rows_pad, thr_cull);
+                        const int ngp = (tnp >> 5) / CPN;           // groups in this wave's column part
+                        const int c0 = cp * ngp * 32;               // its first column inside the tile
+                        const int wb = (t0 >> 5) + cp * ngp;        // its first bitmap word
+                        if (RPT >= 4 && nv == 4) sweep_part<(RPT >= 4 ? 4 : 1), RPT>(lx + c0, ly + c0, lz + c0, ngp, wb, x, row0, nrows, cnt, bits, nwords_pad, stg, thr_cull, lane);
+                        else if (RPT >= 3 && nv == 3) sweep_part<(RPT >= 3 ? 3 : 1), RPT>(lx + c0, ly + c0, lz + c0, ngp, wb, x, row0, nrows, cnt, bits, nwords_pad, stg, thr_cull, lane);
+                        else if (RPT >= 2 && nv == 2) sweep_part<(RPT >= 2 ? 2 : 1), RPT>(lx + c0, ly + c0, lz + c0, ngp, wb, x, row0, nrows, cnt, bits, nwords_pad, stg, thr_cull, lane);
+                        else if (nv >= 1) sweep_part<1, RPT>(lx + c0, ly + c0, lz + c0, ngp, wb, x, row0, nrows, cnt, bits, nwords_pad, stg, thr_cull, lane);
                     }
 #pragma unroll
-                    for (int r = 0; r < RPT; ++r) if (lrow[r] >= 0) cntg[g + G * lrow[r]] = cnt[r];
+                    for (int r = 0; r < RPT; ++r) { const int li = row0[r] + lane; if (li < nrows) cnt_part[g + G * li] = cnt[r]; }
                 }
-                __syncthreads();                                    // cnt, bits visible to the whole workgroup
+                __syncthreads();                                    // counts, bitmap visible to the whole workgroup
                 unsigned long long t_sub = __builtin_amdgcn_s_memrealtime();
                 ticks[6] += t_sub - t_prev;
                 // ---- row offsets (exclusive scan of the counts), then the set bits become the flat lists
                 const int rps = (nrows + nthreads - 1) / nthreads;
                 const int l0 = min(nrows, tid * rps), l1 = min(nrows, l0 + rps);
                 int mine = 0;
-                for (int li = l0; li < l1; ++li) mine += cntg[g + G * li];
+                for (int li = l0; li < l1; ++li) mine += cnt0[g + G * li] + (CPN > 1 ? cnt1[g + G * li] : 0);
                 int total = 0;
                 int run = block_exclusive_scan(mine, sh, tid, nwaves, total);
-                for (int li = l0; li < l1; ++li) { rowoff[li] = run; run += cntg[g + G * li]; }
+                for (int li = l0; li < l1; ++li) { rowoff[li] = run; run += cnt0[g + G * li] + (CPN > 1 ? cnt1[g + G * li] : 0); }
                 if (tid == 0) rowoff[nrows] = total;
                 const int dense = (total > flat_cap) ? 1 : 0;       // lists too small: dense per-row fallback until the next rebuild
                 __syncthreads();
                 { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); ticks[7] += t_now - t_sub; t_sub = t_now; }
                 if (!dense) {
-                    // one lane per (group, row) word; the word's first slot is rowoff[row] + pre[group][row]
-                    const int nwords = ngroups_all * D.rows_pad;
-                    for (int widx = tid; widx < nwords; widx += nthreads) {
-                        const int li = widx % D.rows_pad, gi = widx / D.rows_pad;
-                        if (li >= nrows) continue;
-                        uint32_t w = bits[widx];
-                        if (!w) continue;
-                        size_t o = fbase + rowoff[li] + pre[widx];
-                        while (w) {                                 // bit 31 = first column of the group: ascending columns
-                            const int kbit = __clz(w);
-                            flat_j[o] = (uint16_t)(gi * 32 + kbit); flat_i[o] = (uint16_t)li; ++o;
-                            w &= ~(0x80000000u >> kbit);
+                    // a wave takes four rows per trip (their bitmap words are loaded together); lanes = consecutive
+                    // words of a row, an in-wave prefix sum of the popcounts places every lane's hits, so the
+                    // packed (row << 16 | column) entries of a row leave the wave as one contiguous run
+                    const int nwords = ngroups_all;
+                    for (int li0 = wave * 4; li0 < nrows; li0 += nwaves * 4) {
+                        size_t o[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) o[u] = fbase + rowoff[min(li0 + u, nrows)];
+                        for (int wb0 = 0; wb0 < nwords; wb0 += 64) {
+                            uint32_t wv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                wv[u] = (li0 + u < nrows && wb0 + lane < nwords) ? bits[(size_t)(li0 + u) * nwords_pad + wb0 + lane] : 0u;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                uint32_t w = wv[u];
+                                const int c = __popc(w);
+                                int inc = c;
+#pragma unroll
+                                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+                                const int tot = __shfl(inc, 63, 64);
+                                size_t pos = o[u] + (size_t)(inc - c);
+                                const uint32_t tag = ((uint32_t)(li0 + u) << 16) | (uint32_t)((wb0 + lane) * 32);
+                                while (w) {                         // bit 31 = first column of the group: ascending columns
+                                    const int kbit = __clz(w);
+                                    flat_ij[pos++] = tag + (uint32_t)kbit;
+                                    w &= ~(0x80000000u >> kbit);
+                                }
+                                o[u] += tot;
+                            }
                         }
                     }
                 }
@@ -529,8 +580,8 @@ __global__ __launch_bounds__(512) void cvo_align_kernel(const PairDesc* __restri
 #pragma unroll
                     for (int u = 0; u < CU; ++u) {
                         cc[u] = cb + u * 64 + lane; val[u] = cc[u] < c_end;
-                        li4[u] = val[u] ? (int)flat_i[fbase + cc[u]] : 0;
-                        j4[u] = val[u] ? (int)flat_j[fbase + cc[u]] : 0;
+                        const uint32_t ij = val[u] ? flat_ij[fbase + cc[u]] : 0u;
+                        li4[u] = (int)(ij >> 16); j4[u] = (int)(ij & 0xFFFFu);
                     }
                     float4 lo4[CU], hi4[CU], yj4[CU], gj4[CU];
 #pragma unroll
@@ -613,7 +664,7 @@ __global__ __launch_bounds__(512) void cvo_align_kernel(const PairDesc* __restri
 #pragma unroll
                     for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }
                     acc8[6] += (double)nz;
-                    acc8[7] += (double)cntg[i];
+                    acc8[7] += (double)(cnt0[i] + (nwaves >= 8 ? cnt1[i] : 0));
                 }
             }
             __syncthreads();
@@ -733,6 +784,7 @@ __global__ __launch_bounds__(512) void cvo_align_kernel(const PairDesc* __restri
             st->dense_fallbacks = sh->dense_fallbacks;
             st->candidates_total = cand_total;
             for (int i = 0; i < 10; ++i) st->phase_ticks[i] = ticks[i];
+            st->clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; st->clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0;
         }
         __syncthreads();
     }
@@ -758,8 +810,10 @@ hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream
 }
 
 size_t align_shared_bytes(int tile) {
-    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)(MAX_ROWS_PER_WG + 64) * sizeof(int) + (size_t)3 * tile * sizeof(float);
+    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)(MAX_ROWS_PER_WG + 64) * sizeof(int) + (size_t)3 * tile * sizeof(float) +
+           (size_t)MAX_WAVES * STG_WORDS_PER_WAVE * sizeof(uint32_t);
 }
+int align_tile_granule() { return 32 * STG_GROUPS * 2; }
 
 hipError_t launch_align(int rpt, int grid, int block, int tile, hipStream_t stream, const PairDesc* descs, int n_pairs, int G, const DevParams& P) {
     const size_t shmem = align_shared_bytes(tile);
