@@ -38,6 +38,9 @@
 
 namespace cvohip {
 
+#ifndef CVO_WAVES_PER_SIMD
+#define CVO_WAVES_PER_SIMD 2      // 2: 256 VGPRs, one 512-thread workgroup per CU (measured faster); 4: 128 VGPRs, two per CU
+#endif
 constexpr int MAX_WAVES = 8;        // workgroups are at most 512 threads: 256 VGPRs per lane, no spills in the survivor phases
 constexpr float FAR_ROW = 3.0e18f;    // coordinates of padding rows / columns: d2 overflows, never < threshold
 constexpr float FAR_COL = -3.0e18f;
@@ -363,7 +366,7 @@ __device__ __forceinline__ void sweep_part(const float* __restrict__ lx, const f
 
 // ---------------------------------------------------------------- the kernel
 template <int RPT>
-__global__ __launch_bounds__(512) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, DevParams P) {
+__global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, DevParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Shared* sh = reinterpret_cast<Shared*>(smem);
     int* rowoff = reinterpret_cast<int*>(smem + ((sizeof(Shared) + 15) & ~size_t(15)));
@@ -808,6 +811,8 @@ hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream
     hipLaunchKernelGGL(cvo_pack_results_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, st, out, n);
     return hipGetLastError();
 }
+
+int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
 
 size_t align_shared_bytes(int tile) {
     return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)(MAX_ROWS_PER_WG + 64) * sizeof(int) + (size_t)3 * tile * sizeof(float) +
