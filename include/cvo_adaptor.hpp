@@ -1,0 +1,142 @@
+// cvo_adaptor.hpp -- drop-in replacement of the reference's `cvo::cvo` class
+// (thirdparty/cvo/include/cvo.hpp:82-282) that forwards to libcvo_hip.so.
+//
+// Use: in the CVO-SLAM tree replace `#include "cvo.hpp"` by this header (or install it as
+// thirdparty/cvo/include/cvo.hpp), drop thirdparty/cvo/src/cvo.cpp from the `cvo` target and link
+// `cvo_hip`.  local_tracker.cpp / keyframe_graph.cpp compile unchanged: every
+// public member and signature they use is here (cvo.hpp:139-144, 216-276).
+//
+// Needs the reference's own dependencies (Eigen3, OpenCV core) and its pcd_generator
+// (thirdparty/cvo/include/pcd_generator.hpp), which stays on the CPU side of the boundary:
+// images -> selected pixels -> cloud is SURVEY 8f "next-1", not part of this hot path.
+// NOT compiled in the build container (no Eigen/OpenCV there); the dependency-free twin that IS
+// compiled and run is cvo_slam_amd/csrc/cvo_hip.hpp.
+#ifndef CVO_H
+#define CVO_H
+
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <opencv2/core/mat.hpp>
+
+#include "data_type.h"        // reference: cvo::frame, cvo::point_cloud, cvo::camera_info
+#include "pcd_generator.hpp"  // reference: image -> point cloud (CPU)
+#include "cvo_hip.h"
+
+namespace cvo {
+
+class inn_p {   // cvo.hpp:52-80
+public:
+    float value; int num; int num_e;
+    void copy(const inn_p& r) { value = r.value; num = r.num; num_e = r.num_e; }
+    inn_p(const inn_p& r) : value(r.value), num(r.num), num_e(r.num_e) {}
+    inn_p(float v, int n, int n_e) : value(v), num(n), num_e(n_e) {}
+    inn_p() {}
+};
+
+class cvo {
+    cvo_handle h_ = nullptr;
+    camera_info cam_info;
+    std::unique_ptr<frame> ptr_fixed_fr, ptr_moving_fr, ptr_previous_fr;   // kept for get_*_selected_points
+    bool pre_pc_init = false;
+
+    static void to12(const Eigen::Affine3f& a, float m[12]) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) m[r * 4 + c] = a.matrix()(r, c); }
+    static void from12(const float m[12], Eigen::Affine3f& a) { a = Eigen::Affine3f::Identity(); for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) a.matrix()(r, c) = m[r * 4 + c]; }
+    void sync() {
+        float t[12], p[12], ac[12];
+        cvo_get_transform(h_, t); cvo_get_prev_accum_transform(h_, p, ac);
+        from12(t, transform); from12(p, prev_transform); from12(ac, accum_transform);
+        int i = 0; cvo_get_init(h_, &i); init = i != 0; cvo_get_iteration_number(h_, &iter);
+    }
+    // pcd_generator on the CPU (cvo.cpp:348-366), then hand the cloud over.  Eigen's N x 5 feature matrix is
+    // column-major (data_type.h:75): features.data() already is 5 channel-major arrays of N.
+    void generate_and_upload(const cv::Mat& RGB_img, const cv::Mat& dep_img, frame* fr) {
+        pcd_generator pcd_gen; pcd_gen.set_calib(cam_info);
+        point_cloud pc;
+        pcd_gen.load_image(RGB_img, dep_img, fr);
+        pcd_gen.create_pointcloud(1, fr, &pc);
+        static_assert(sizeof(Eigen::Vector3f) == 12, "cloud_t must be 12-byte AoS");
+        cvo_set_pcd(h_, pc.num_points ? pc.positions[0].data() : nullptr, pc.features.data(), pc.num_points);
+    }
+    static void to(const cvo_inn_p& a, inn_p& b) { b.value = a.value; b.num = a.num; b.num_e = a.num_e; }
+
+public:
+    bool first_frame = true;          // cvo.hpp:139
+    bool init = false;                // cvo.hpp:140
+    int iter = 0;                     // cvo.hpp:141
+    Eigen::Affine3f transform = Eigen::Affine3f::Identity(), prev_transform = Eigen::Affine3f::Identity(),
+                    accum_transform = Eigen::Affine3f::Identity();   // cvo.hpp:142-144
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+
+    cvo(const std::string& calib_file) : ptr_fixed_fr(new frame) {     // cvo.cpp:18-71
+        cv::FileStorage fSettings(calib_file, cv::FileStorage::READ);
+        cam_info.fx = fSettings["Camera.fx"]; cam_info.fy = fSettings["Camera.fy"];
+        cam_info.cx = fSettings["Camera.cx"]; cam_info.cy = fSettings["Camera.cy"];
+        cam_info.scaling_factor = fSettings["DepthMapFactor"];
+        if (cvo_create(nullptr, 0, &h_) != CVO_OK) std::cerr << "cvo_create: " << cvo_last_error() << "\n";
+    }
+    ~cvo() { cvo_destroy(h_); }
+
+    void set_pcd(const cv::Mat& RGB_img, const cv::Mat& dep_img) {      // cvo.cpp:345-386
+        if (!init) { generate_and_upload(RGB_img, dep_img, ptr_fixed_fr.get()); sync(); return; }
+        ptr_moving_fr.reset(new frame);
+        generate_and_upload(RGB_img, dep_img, ptr_moving_fr.get());
+    }
+    void align() { if (cvo_align(h_) != CVO_OK) std::cerr << "cvo align: " << cvo_last_error() << "\n"; sync(); }   // cvo.cpp:763-821
+
+    void match_odometry(const cv::Mat& RGB_img, const cv::Mat& dep_img, Eigen::Affine3d& transformd) {   // cvo.cpp:461-473
+        if (init == false) { std::cout << "cvo not initialized !" << "\n"; return; }
+        set_pcd(RGB_img, dep_img);
+        align();
+        transformd = transform.cast<double>();
+    }
+    void match_keyframe(const cv::Mat& RGB_img, const cv::Mat& dep_img, Eigen::Affine3d& transformd) {   // cvo.cpp:563-576
+        match_odometry(RGB_img, dep_img, transformd);
+    }
+
+    void compute_innerproduct(inn_p& inn_pre, inn_p& inn_post, Eigen::Matrix<double, 6, 6>& post_hessian, Eigen::Affine3f& tran,
+                              int& inliers, inn_p& inn_fixed_pcd, inn_p& inn_moving_pcd, float& cos_angle) {   // cvo.cpp:475-503
+        float t[12]; to12(tran, t); double H[36]; cvo_inn_p a, b, c, d;
+        if (cvo_compute_innerproduct(h_, &a, &b, H, t, &inliers, &c, &d, &cos_angle) != CVO_OK) { std::cerr << cvo_last_error() << "\n"; return; }
+        to(a, inn_pre); to(b, inn_post); to(c, inn_fixed_pcd); to(d, inn_moving_pcd);
+        for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) post_hessian(r, q) = H[r * 6 + q];
+    }
+    void compute_innerproduct_lc(inn_p& inn_prior, inn_p& inn_lc_prior, inn_p& inn_lc_pre, inn_p& inn_lc_post,
+                                 Eigen::Matrix<double, 6, 6>& post_hessian, Eigen::Affine3f& prior_tran, Eigen::Affine3f& lc_prior_tran,
+                                 Eigen::Affine3f& lc_prior_tran_2, Eigen::Affine3f& lc_tran, int& inliers_svd, int& inliers_pnpransac,
+                                 inn_p& inn_fixed_pcd, inn_p& inn_moving_pcd, float& cos_angle) {               // cvo.cpp:505-561
+        float p[12], l1[12], l2[12], lt[12]; to12(prior_tran, p); to12(lc_prior_tran, l1); to12(lc_prior_tran_2, l2); to12(lc_tran, lt);
+        double H[36]; cvo_inn_p a, b, c, d, e, f;
+        if (cvo_compute_innerproduct_lc(h_, &a, &b, &c, &d, H, p, l1, l2, lt, &inliers_svd, &inliers_pnpransac, &e, &f, &cos_angle) != CVO_OK) {
+            std::cerr << cvo_last_error() << "\n"; return;
+        }
+        to(a, inn_prior); to(b, inn_lc_prior); to(c, inn_lc_pre); to(d, inn_lc_post); to(e, inn_fixed_pcd); to(f, inn_moving_pcd);
+        for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) post_hessian(r, q) = H[r * 6 + q];
+    }
+
+    void update_fixed_pcd() { ptr_fixed_fr = std::move(ptr_moving_fr); cvo_update_fixed_pcd(h_); }                 // cvo.cpp:578-582
+    void update_previous_pcd() { ptr_previous_fr = std::move(ptr_moving_fr); pre_pc_init = true; cvo_update_previous_pcd(h_); }   // :584-589
+    void reset_keyframe(Eigen::Affine3f& odometry) {                                                               // :591-604
+        if (!pre_pc_init) ptr_fixed_fr = std::move(ptr_moving_fr);
+        else { ptr_fixed_fr = std::move(ptr_previous_fr); ptr_previous_fr = std::move(ptr_moving_fr); }
+        float t[12]; to12(odometry, t); cvo_reset_keyframe(h_, t); sync();
+    }
+    void reset_transform(Eigen::Affine3f& odometry) { float t[12]; to12(odometry, t); cvo_reset_transform(h_, t); sync(); }   // :606-609
+    Eigen::Affine3f reset_initial(Eigen::Affine3f& odometry) {                                                     // :611-618
+        float t[12], o[12]; to12(odometry, t); cvo_reset_initial(h_, t, o);
+        Eigen::Affine3f out; from12(o, out); return out;
+    }
+
+    void get_fixed_and_moving_number(int& fixed_num, int& moving_num) { cvo_get_fixed_and_moving_number(h_, &fixed_num, &moving_num); }
+    void get_iteration_number(int& iteration) { cvo_get_iteration_number(h_, &iteration); }
+    void get_A_nonzero(int& nonzero) { cvo_get_A_nonzero(h_, &nonzero); }
+    void get_fixed_frame_selected_points(std::vector<cv::Point2f>& pts) { pts = ptr_fixed_fr->selected_points; }
+    void get_moving_frame_selected_points(std::vector<cv::Point2f>& pts) { pts = ptr_moving_fr->selected_points; }
+};
+
+}  // namespace cvo
+#endif  // CVO_H
