@@ -214,6 +214,12 @@ def main():
         achieved_gbs = bytes_launch / (k_ms * 1e-3) / 1e9
         achieved_tf = flops_launch / (k_ms * 1e-3) / 1e12
         value = world * n * args.steps / elapsed
+        traffic = None                                  # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_run.sh)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = float(json.load(f)["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
         out = {
             "metric": "CVO frame-pair alignments/sec (640x480, ~3k pts/cloud)",
             "value": value, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -227,7 +233,7 @@ def main():
                        "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth,
                        "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": "RCCL all_gather of 64-byte result records" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "cvo_align_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                         "traffic": traffic, "kernel": "cvo_align_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "path is VALU-issue bound, not HBM bound (SURVEY 8d): see valu"},
             "valu": {"achieved": achieved_tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / FP32_VALU_PEAK_TF,
                      "algorithmic_flops_per_launch": flops_launch, "pair_tests_per_s": flops_launch / 8.0 / (k_ms * 1e-3)},
