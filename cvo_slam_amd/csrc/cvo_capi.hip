@@ -21,10 +21,11 @@
 #include "cvo_math.hpp"
 
 namespace cvohip {
-size_t align_shared_bytes(int tile);
+size_t align_shared_bytes(int tile, int y_points);
 int align_tile_granule();
 int align_blocks_per_cu();
-hipError_t launch_align(int rpt, int grid, int block, int tile, hipStream_t stream, const PairDesc* descs, int n_pairs, int G, const DevParams& P);
+hipError_t launch_align(int rpt, int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+                        const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 int score_grid(int na);
 int score_nout();
@@ -106,7 +107,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
-    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_bits, d_cnt, d_flat_ij, d_rec0, d_rec1, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
+    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_bits, d_cnt, d_flat_ij, d_jT, d_ckT, d_dcT, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
     PinBuf h_descs, h_states, h_stage, h_partials;
     int wg_request = 0;          // 0 = auto
     int tile_request = 0;        // 0 = auto
@@ -132,7 +133,7 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_bits, &d_cnt, &d_flat_ij, &d_rec0, &d_rec1, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_bits, &d_cnt, &d_flat_ij, &d_jT, &d_ckT, &d_dcT, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -211,8 +212,12 @@ struct Engine {
         if ((rc = d_bits.ensure(sizeof(uint32_t) * (size_t)n * bits_words))) return rc;
         if ((rc = d_cnt.ensure(sizeof(int) * (size_t)n * 2 * nf_pad))) return rc;
         if ((rc = d_flat_ij.ensure(sizeof(uint32_t) * (size_t)n * plane))) return rc;
-        if ((rc = d_rec0.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
-        if ((rc = d_rec1.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
+        int capn = 64; while (capn < nm_max / 8 && capn < 4096) capn *= 2;   // longest transposed row: 512 at 3k points, 2048 at 10k
+        if (const char* e = std::getenv("CVO_HIP_ROW_CAP")) capn = std::max(1, std::atoi(e));
+        const size_t tplane = (size_t)G * capn * rows_pad;
+        if ((rc = d_jT.ensure(sizeof(uint16_t) * (size_t)n * tplane))) return rc;
+        if ((rc = d_ckT.ensure(sizeof(float) * (size_t)n * tplane))) return rc;
+        if ((rc = d_dcT.ensure(sizeof(float) * (size_t)n * tplane))) return rc;
         if ((rc = d_surv0.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
         if ((rc = d_surv1.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
         const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n * 2 * G * XCH_WORDS;
@@ -236,8 +241,10 @@ struct Engine {
             D.nwords_pad = nwords_pad;
             D.cnt = static_cast<int*>(d_cnt.p) + (size_t)i * 2 * nf_pad;
             D.flat_ij = static_cast<uint32_t*>(d_flat_ij.p) + (size_t)i * plane;
-            D.rec0 = static_cast<float4*>(d_rec0.p) + (size_t)i * plane;
-            D.rec1 = static_cast<float4*>(d_rec1.p) + (size_t)i * plane;
+            D.capn = capn;
+            D.jT = static_cast<uint16_t*>(d_jT.p) + (size_t)i * tplane;
+            D.ckT = static_cast<float*>(d_ckT.p) + (size_t)i * tplane;
+            D.dcT = static_cast<float*>(d_dcT.p) + (size_t)i * tplane;
             D.surv0 = static_cast<float4*>(d_surv0.p) + (size_t)i * plane;
             D.surv1 = static_cast<float4*>(d_surv1.p) + (size_t)i * plane;
             D.xch = static_cast<unsigned long long*>(d_xch.p) + (size_t)i * 2 * G * XCH_WORDS;
@@ -253,7 +260,10 @@ struct Engine {
         }
         if (G > 1) HIP_TRY(hipMemsetAsync(d_xch.p, 0, xch_bytes, s));
         HIP_TRY(hipEventRecord(ev0, s));
-        hipError_t e = launch_align(rpt, grid, block, tile, s, static_cast<const PairDesc*>(d_descs.p), n, G, P);
+        // keep the transformed moving cloud resident in LDS (16 B per point) when it fits beside the rest
+        int y_points = 0;
+        if (align_shared_bytes(tile, nm_pad) <= (size_t)156 * 1024 && !std::getenv("CVO_HIP_NO_YLDS")) y_points = nm_pad;
+        hipError_t e = launch_align(rpt, grid, block, tile, y_points, s, static_cast<const PairDesc*>(d_descs.p), n, G, P);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));
         HIP_TRY(hipMemcpyAsync(h_states.p, d_states.p, sizeof(PairState) * n, hipMemcpyDeviceToHost, s));

@@ -69,8 +69,10 @@ struct PairDesc {
     int* cnt;                // [2][nf_pad]     hits per row found by each of the two column parts of the cull
     // flat arrays: plane = (nf_pad + G) * capf entries; workgroup g owns [g*rows_per*capf, (g+1)*rows_per*capf)
     uint32_t* flat_ij;       // compacted candidates (local row << 16 | column); a row's are contiguous, columns ascending
-    float4* rec0;            // per candidate, this iteration: {a*(x cross y), a*(y-x).x}
-    float4* rec1;            //                                {a*(y-x).y, a*(y-x).z, a, 0}   (all 0 when not in A)
+    int capn;                // longest row the transposed lists hold (longer => dense fallback)
+    uint16_t* jT;            // [G][capn][rows_pad]  transposed lists: column of entry n of local row li
+    float* ckT;              // same shape: colour factor ck of the pair (filled by the first pass over a new list)
+    float* dcT;              // same shape: colour distance d2c (+inf = failed the colour gate)
     float4* surv0;           // survivors compacted per wave chunk, in candidate order: {x_i, a}
     float4* surv1;           //                                                         {y_j, 0}
     unsigned long long* xch; // [2][G][XCH_WORDS]

@@ -57,7 +57,10 @@ struct __attribute__((aligned(16))) Shared {
     float ell_build;
     float fred[MAX_WAVES];
     int wsum[MAX_WAVES];
-    int wcnt[MAX_WAVES];   // survivors each wave compacted in C1
+    int wcnt[MAX_WAVES];   // survivors each wave compacted in the candidate phase
+    int wtot[MAX_WAVES];   // candidates each wave owns (sum of its rows' list lengths)
+    int wbase[MAX_WAVES];  // start of the wave's survivor segment (exclusive prefix of wtot)
+    int lmax;              // longest candidate list of this workgroup's rows
     int list_valid;
     int dense_mode;        // candidates did not fit the lists: per-row dense fallback until the next rebuild
     int total;             // candidates in this workgroup's flat list
@@ -68,6 +71,11 @@ struct __attribute__((aligned(16))) Shared {
     int cand;
     int rebuilds;
     int dense_fallbacks;
+    int rebuild;           // this iteration rebuilds the candidate lists
+    float omega[3];        // this iteration's twist (f32, cvo.cpp:234-235)
+    float v[3];
+    float dist;
+    DevParams P;
 };
 
 // Pointers read out of a PairDesc are generic to the compiler, which then emits FLAT loads/stores
@@ -236,6 +244,18 @@ __device__ __forceinline__ float se_kernel_value(const float* xi, const float* f
     return a > G.sp ? a : 0.f;
 }
 
+// The same decision for a listed candidate whose colour part (d2c < d2c_thres passed, ck) was
+// settled when the list was first used: only the geometric half of cvo.cpp:166-175 is left.
+__device__ __forceinline__ float se_kernel_value_pre(const float* xi, const float4 yj, float ck, float d2c, const Gates& G) {
+    const float e0 = xi[0] - yj.x, e1 = xi[1] - yj.y, e2 = xi[2] - yj.z;
+    float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;                  // nanoflann.hpp:403-406
+    if (!(d2 < G.d2_thres)) return 0.f;
+    if (d2 * G.q_il + d2c * G.q_ic > G.q_lim) return 0.f;
+    const float k = (float)((double)G.s2 * exp_small((double)(-d2) * G.inv_den_l));
+    const float a = ck * k;
+    return a > G.sp ? a : 0.f;
+}
+
 __device__ __forceinline__ Gates make_gates(float l, const DevParams& P) {
     Gates G;
     G.s2 = P.sigma * P.sigma;                                       // se_kernel(ell, sigma*sigma), cvo.cpp:189
@@ -364,50 +384,519 @@ __device__ __forceinline__ void sweep_part(const float* __restrict__ lx, const f
     }
 }
 
-// ---------------------------------------------------------------- the kernel
-template <int RPT>
-__global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, DevParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Shared* sh = reinterpret_cast<Shared*>(smem);
-    int* rowoff = reinterpret_cast<int*>(smem + ((sizeof(Shared) + 15) & ~size_t(15)));
-    float* lx = reinterpret_cast<float*>(rowoff + (MAX_ROWS_PER_WG + 64));
-    float* ly = lx + tile;
-    float* lz = ly + tile;
-    volatile uint32_t* stg_all = reinterpret_cast<volatile uint32_t*>(lz + tile);
+// ---------------------------------------------------------------- the kernel, phase by phase
+// Every phase is its own non-inlined function: each gets its own register allocation (the whole
+// iteration as one function spilled ~150 VGPRs into the candidate loop), and nothing but a few
+// scalars lives across phases -- the iteration state is in LDS (Shared).  Arguments arrive in
+// VGPRs; they are wave-uniform and are moved back to SGPRs (readfirstlane) first thing.
+extern __shared__ __attribute__((aligned(16))) unsigned char cvo_smem[];
 
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+struct Lds {
+    Shared* sh; int* rowoff; float* lx; float* ly; float* lz; volatile uint32_t* stg_all; float4* ylds;
+};
+__device__ __forceinline__ Lds lds_layout(int tile) {
+    Lds L;
+    L.sh = reinterpret_cast<Shared*>(cvo_smem);
+    L.rowoff = reinterpret_cast<int*>(cvo_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
+    L.lx = reinterpret_cast<float*>(L.rowoff + (MAX_ROWS_PER_WG + 64));
+    L.ly = L.lx + tile; L.lz = L.ly + tile;
+    L.stg_all = reinterpret_cast<volatile uint32_t*>(L.lz + tile);
+    L.ylds = reinterpret_cast<float4*>(const_cast<uint32_t*>(L.stg_all) + MAX_WAVES * STG_WORDS_PER_WAVE);
+    return L;
+}
+
+// one pair as seen by workgroup g of its G: rows are dealt round-robin (local row li <-> fixed point g + G*li):
+// near surfaces have many more neighbours per row than far ones, bands of rows would be unbalanced
+struct Ctx {
+    const gfloat* fixed; const gfloat* moving;
+    int nf, nm, nrows, rows_per, rows_pad, ngroups_all, nwords_pad, capn, nm_pad, flat_cap, g, G;
+    GF4 ybuf, ybuild, surv0, surv1;
+    gu32* bits; gint* cnt0; gint* cnt1; gu32* flat_ij; gu16* jT; gfloat* ckT; gfloat* dcT; gu64* xch;
+    size_t fbase;
+};
+__device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
+    const PairDesc& D = *Dp;
+    Ctx c;
+    c.g = g; c.G = G;
+    c.nf = D.nf; c.nm = D.nm; c.nm_pad = D.nm_pad; c.rows_pad = D.rows_pad; c.nwords_pad = D.nwords_pad; c.capn = D.capn;
+    c.rows_per = (c.nf + G - 1) / G;
+    c.nrows = (g < c.nf) ? (c.nf - g + G - 1) / G : 0;
+    c.ngroups_all = (c.nm + 31) >> 5;
+    c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
+    c.ybuf = GF4{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
+    c.ybuild = GF4{(gv4f*)D.ybuild + (size_t)g * D.nm_pad};
+    c.surv0 = GF4{(gv4f*)D.surv0}; c.surv1 = GF4{(gv4f*)D.surv1};
+    c.bits = (gu32*)D.bits + (size_t)g * D.rows_pad * D.nwords_pad;
+    c.cnt0 = (gint*)D.cnt; c.cnt1 = c.cnt0 + D.nf_pad;
+    c.flat_ij = (gu32*)D.flat_ij;
+    c.jT = (gu16*)D.jT + (size_t)g * D.capn * D.rows_pad;
+    c.ckT = (gfloat*)D.ckT + (size_t)g * D.capn * D.rows_pad;
+    c.dcT = (gfloat*)D.dcT + (size_t)g * D.capn * D.rows_pad;
+    c.xch = (gu64*)D.xch;
+    c.fbase = (size_t)g * c.rows_per * D.capf;
+    c.flat_cap = c.rows_per * D.capf;
+    return c;
+}
+
+// ---- T: transform_pcd (cvo.cpp:336-341) into ybuf (+ the LDS-resident copy); how far has any point moved since
+// the candidate lists were built (exact displacement of the very positions the tests use); rebuild decision.
+__device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
+    const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    float M[12];
+    {
+        float R[9], T[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = sh->R[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[i] = sh->T[i];
+        make_transform(R, T, M);                                    // update_tf, cvo.cpp:770
+    }
+    const bool have_list = sh->list_valid != 0;
+    float dmax2 = 0.f;
+    for (int j = tid; j < c.nm; j += nthreads) {
+        const float4 lo = ld4(c.moving + (size_t)j * REC);
+        float y0, y1, y2;
+        apply_transform(M, lo.x, lo.y, lo.z, y0, y1, y2);
+        c.ybuf.set(j, make_float4(y0, y1, y2, lo.w));
+        if (y_lds) L.ylds[j] = make_float4(y0, y1, y2, lo.w);
+        if (have_list) {
+            const float4 yb = c.ybuild[j];
+            const float e0 = y0 - yb.x, e1 = y1 - yb.y, e2 = y2 - yb.z;
+            dmax2 = fmaxf(dmax2, __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)));
+        }
+    }
+    dmax2 = block_max(dmax2, sh, tid, nwaves);                      // also makes ybuf / ylds visible to the workgroup
+    if (tid == 0) {
+        const float ell = sh->ell;
+        const float r_c = sqrtf(gate_d2_align(ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
+        // the lists hold every pair within Rb of the build positions; a pair within r_c now was within
+        // r_c + (its point's displacement) then.  Every workgroup of the pair computes the same bits here.
+        sh->rebuild = (!have_list || (sh->ell_build != ell) || (r_c + sqrtf(dmax2) * 1.0001f + 1.0e-5f) * 1.00001f > sh->Rb) ? 1 : 0;
+        for (int i = 0; i < 12; ++i) sh->M[i] = M[i];
+    }
+    __syncthreads();
+}
+
+// ---- S: dense cull into the row-major hit bitmap + per-row hit counts
+template <int RPT>
+__device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
+    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
+    const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
+    const float Rb = r_c * (1.0f + sh->P.skin);
+    const float thr_cull = Rb * Rb * 1.00001f;
+    // waves form a RGN x CPN grid: RGN groups of 64*RPT rows, CPN column parts of every tile, so
+    // that all waves carry the same number of pair tests (two per SIMD, none left alone)
+    const int CPN = (nwaves >= 8) ? 2 : 1, RGN = nwaves / CPN;
+    const int rg = wave % RGN, cp = wave / RGN;
+    volatile uint32_t* stg = L.stg_all + wave * STG_WORDS_PER_WAVE;
+    gint* cnt_part = cp ? c.cnt1 : c.cnt0;
+    for (int rb = 0; rb < c.nrows; rb += RPT * RGN * 64) {
+        float x[RPT][3]; int row0[RPT]; int cnt[RPT];
+        int nv = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            row0[r] = rb + r * (RGN * 64) + rg * 64;
+            const int li = row0[r] + lane;
+            cnt[r] = 0;
+            if (li < c.nrows) {
+                const float4 lo = ld4(c.fixed + (size_t)(g + G * li) * REC);
+                x[r][0] = lo.x; x[r][1] = lo.y; x[r][2] = lo.z;
+            } else {
+                x[r][0] = x[r][1] = x[r][2] = FAR_ROW;
+            }
+            if (row0[r] < c.nrows) nv = r + 1;                      // rows are a prefix per wave: skip the all-padding ones
+        }
+        for (int t0 = 0; t0 < c.nm; t0 += tile) {
+            const int tn = min(tile, c.nm - t0);
+            const int gran = 32 * STG_GROUPS * CPN;                 // every column part is a whole number of flush granules
+            const int tnp = (tn + gran - 1) / gran * gran;
+            __syncthreads();                                        // previous tile fully consumed
+            for (int jj = tid; jj < tnp; jj += nthreads) {
+                float4 y = make_float4(FAR_COL, FAR_COL, FAR_COL, 0.f);
+                if (jj < tn) { y = c.ybuf[t0 + jj]; if (rb == 0) c.ybuild.set(t0 + jj, y); }
+                L.lx[jj] = y.x; L.ly[jj] = y.y; L.lz[jj] = y.z;
+            }
+            __syncthreads();
+            const int ngp = (tnp >> 5) / CPN;                       // groups in this wave's column part
+            const int c0 = cp * ngp * 32;                           // its first column inside the tile
+            const int wb = (t0 >> 5) + cp * ngp;                    // its first bitmap word
+            if (RPT >= 4 && nv == 4) sweep_part<(RPT >= 4 ? 4 : 1), RPT>(L.lx + c0, L.ly + c0, L.lz + c0, ngp, wb, x, row0, c.nrows, cnt, c.bits, c.nwords_pad, stg, thr_cull, lane);
+            else if (RPT >= 3 && nv == 3) sweep_part<(RPT >= 3 ? 3 : 1), RPT>(L.lx + c0, L.ly + c0, L.lz + c0, ngp, wb, x, row0, c.nrows, cnt, c.bits, c.nwords_pad, stg, thr_cull, lane);
+            else if (RPT >= 2 && nv == 2) sweep_part<(RPT >= 2 ? 2 : 1), RPT>(L.lx + c0, L.ly + c0, L.lz + c0, ngp, wb, x, row0, c.nrows, cnt, c.bits, c.nwords_pad, stg, thr_cull, lane);
+            else if (nv >= 1) sweep_part<1, RPT>(L.lx + c0, L.ly + c0, L.lz + c0, ngp, wb, x, row0, c.nrows, cnt, c.bits, c.nwords_pad, stg, thr_cull, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) { const int li = row0[r] + lane; if (li < c.nrows) cnt_part[g + G * li] = cnt[r]; }
+    }
+    if (tid == 0) sh->Rb = Rb;
+    __syncthreads();                                                // counts, bitmap visible to the whole workgroup
+}
+
+// ---- X: row offsets (exclusive scan of the counts), the set bits become row-major lists, which are transposed
+// into jT[n][row] for the candidate phase
+__device__ __noinline__ void phase_lists(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
+    const Lds L = lds_layout(tile); Shared* sh = L.sh; int* rowoff = L.rowoff;
+    const Ctx c = make_ctx(Dp, g, G);
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
+    const int nrows = c.nrows;
+    const int CPN = (nwaves >= 8) ? 2 : 1;
+    const int rps = (nrows + nthreads - 1) / nthreads;
+    const int l0 = min(nrows, tid * rps), l1 = min(nrows, l0 + rps);
+    int mine = 0;
+    for (int li = l0; li < l1; ++li) mine += c.cnt0[g + G * li] + (CPN > 1 ? c.cnt1[g + G * li] : 0);
+    int total = 0;
+    int run = block_exclusive_scan(mine, sh, tid, nwaves, total);
+    for (int li = l0; li < l1; ++li) { rowoff[li] = run; run += c.cnt0[g + G * li] + (CPN > 1 ? c.cnt1[g + G * li] : 0); }
+    if (tid == 0) rowoff[nrows] = total;
+    const int dense = (total > c.flat_cap) ? 1 : 0;                 // lists too small: dense per-row fallback until the next rebuild
+    __syncthreads();
+    if (!dense) {
+        // a wave takes four rows per trip (their bitmap words are loaded together); lanes = consecutive
+        // words of a row, an in-wave prefix sum of the popcounts places every lane's hits, so the
+        // packed (row << 16 | column) entries of a row leave the wave as one contiguous run
+        const int nwords = c.ngroups_all;
+        for (int li0 = wave * 4; li0 < nrows; li0 += nwaves * 4) {
+            size_t o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = c.fbase + rowoff[min(li0 + u, nrows)];
+            for (int wb0 = 0; wb0 < nwords; wb0 += 64) {
+                uint32_t wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    wv[u] = (li0 + u < nrows && wb0 + lane < nwords) ? c.bits[(size_t)(li0 + u) * c.nwords_pad + wb0 + lane] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint32_t w = wv[u];
+                    const int cw = __popc(w);
+                    int inc = cw;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+                    const int tot = __shfl(inc, 63, 64);
+                    size_t pos = o[u] + (size_t)(inc - cw);
+                    const uint32_t tag = ((uint32_t)(li0 + u) << 16) | (uint32_t)((wb0 + lane) * 32);
+                    while (w) {                                     // bit 31 = first column of the group: ascending columns
+                        const int kbit = __clz(w);
+                        c.flat_ij[pos++] = tag + (uint32_t)kbit;
+                        w &= ~(0x80000000u >> kbit);
+                    }
+                    o[u] += tot;
+                }
+            }
+        }
+    }
+    __syncthreads();                                                // flat_ij complete
+    // transpose through a per-wave LDS patch (64 rows x 16 entries): reads are 64-byte row segments, writes are
+    // 128-byte runs over 64 consecutive rows.  A wave owns the 64-row blocks wave, wave+nwaves, ... -- the rows it
+    // walks in the candidate phase.
+    int my_tot = 0, my_lmax = 0;
+    if (!dense) {
+        volatile uint32_t* patch = L.stg_all + wave * STG_WORDS_PER_WAVE;      // 64 x 17 words
+        for (int lb = wave * 64; lb < nrows; lb += nwaves * 64) {
+            const int li = lb + lane;
+            const int len = (li < nrows) ? rowoff[li + 1] - rowoff[li] : 0;
+            int lmaxb = len, ltot = len;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { lmaxb = max(lmaxb, __shfl_xor(lmaxb, off, 64)); ltot += __shfl_xor(ltot, off, 64); }
+            my_tot += ltot; my_lmax = max(my_lmax, lmaxb);
+            for (int n0 = 0; n0 < min(lmaxb, c.capn); n0 += 16) {
+#pragma unroll
+                for (int k16 = 0; k16 < 16; ++k16) {
+                    const int r = (lane >> 4) + 4 * k16, e = lane & 15;
+                    const int lr = lb + r;
+                    uint32_t v = 0u;
+                    if (lr < nrows) { const int o = rowoff[lr]; if (n0 + e < rowoff[lr + 1] - o) v = c.flat_ij[c.fbase + o + n0 + e]; }
+                    patch[r * 17 + e] = v;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t v = patch[lane * 17 + e];
+                    if (n0 + e < len && n0 + e < c.capn) c.jT[(size_t)(n0 + e) * c.rows_pad + li] = (uint16_t)(v & 0xFFFFu);
+                }
+            }
+        }
+    }
+    if (lane == 0) { sh->wtot[wave] = my_tot; sh->wsum[wave] = my_lmax; }
+    __syncthreads();
+    if (tid == 0) {
+        int lmax_all = 0, run_w = 0;
+        for (int w = 0; w < nwaves; ++w) { lmax_all = max(lmax_all, sh->wsum[w]); sh->wbase[w] = run_w; run_w += sh->wtot[w]; }
+        const int dense2 = dense | (lmax_all > c.capn ? 1 : 0);     // a row longer than the transposed lists hold
+        sh->ell_build = sh->ell; sh->list_valid = 1;
+        sh->dense_mode = dense2; sh->total = total; sh->lmax = lmax_all;
+        sh->rebuilds += 1; sh->dense_fallbacks += dense2 ? 1 : 0;
+    }
+    __syncthreads();
+}
+
+// ---- C: exact kernel values + compute_flow row sums (cvo.cpp:202-231), reduced over the workgroup and the pair's workgroups
+__device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
+    const Lds L = lds_layout(tile); Shared* sh = L.sh; const int* rowoff = L.rowoff;
+    const Ctx c = make_ctx(Dp, g, G);
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
+    const int nrows = c.nrows;
+    const Gates gates = make_gates(sh->ell, sh->P);
+    const bool dense_mode = sh->dense_mode != 0, fresh_list = sh->rebuild != 0;
+    const int total = sh->total;
+    const float inv_c = 1 / sh->P.c, inv_d = 1 / sh->P.d;
+    double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // omega[3], v[3], nnz, candidates
+    if (!dense_mode) {
+        // one lane per ROW, walking the row's candidate list (transposed: the lanes of a wave read entry n of 64
+        // consecutive rows as one coalesced run).  The point gather y_j comes from the LDS-resident cloud, x_i and the
+        // row sums live in registers, so a candidate costs no scattered global access and the f32 sums add up in column
+        // order (cvo.cpp:213-223) without a second pass.  Survivors {x_i,a},{y_j} are compacted per wave (ballot +
+        // prefix popcount) for the line-search phase.
+        const size_t sbase = c.fbase + sh->wbase[wave];
+        int wcount = 0;
+        for (int lb = wave * 64; lb < nrows; lb += nwaves * 64) {
+            const int li = lb + lane;
+            const bool rowok = li < nrows;
+            const int len = rowok ? rowoff[li + 1] - rowoff[li] : 0;
+            int lw = len;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
+            float xi[3] = {0.f, 0.f, 0.f}, fi[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            if (rowok) {
+                const gfloat* xr = c.fixed + (size_t)(g + G * li) * REC;
+                const float4 lo = ld4(xr);
+                xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; fi[0] = lo.w;
+                if (fresh_list) { const float4 hi = ld4(xr + 4); fi[1] = hi.x; fi[2] = hi.y; fi[3] = hi.z; fi[4] = hi.w; }
+            }
+            float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
+            // the lists stream from HBM / Infinity Cache: entries n+PF .. n+2PF-1 are in flight while n .. n+PF-1 are evaluated
+            constexpr int PF = 4;
+            int jq[PF]; float ckq[PF], dcq[PF];
+            auto fetch = [&](int n0, int (&jo)[PF], float (&cko)[PF], float (&dco)[PF]) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const bool in = n0 + u < len;
+                    const size_t at = (size_t)(n0 + u) * c.rows_pad + li;
+                    jo[u] = in ? (int)c.jT[at] : 0;
+                    cko[u] = (in && !fresh_list) ? c.ckT[at] : 0.f;
+                    dco[u] = (in && !fresh_list) ? c.dcT[at] : 0.f;
+                }
+            };
+            fetch(0, jq, ckq, dcq);
+            for (int n0 = 0; n0 < lw; n0 += PF) {
+                int jn[PF]; float ckn[PF], dcn[PF];
+                fetch(n0 + PF, jn, ckn, dcn);
+                // the PF entries are independent until their results are added to the row sums: evaluate them side by
+                // side (four exp / gate chains in flight per lane), then fold them in column order
+                float av[PF]; float4 yv4[PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int n = n0 + u;
+                    const int j = jq[u]; float ck = ckq[u], d2c = dcq[u];
+                    av[u] = 0.f; yv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n < len) {
+                        const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
+                        yv4[u] = yj;
+                        if (fresh_list) {
+                            // colour gate and factor (cvo.cpp:169-173) depend on the two points only: done by the first pass
+                            // over a new list and kept.  A pair that fails the gate gets d2c = +inf, ck = 0: the pre-test in
+                            // se_kernel_value_pre then rejects it for good.
+                            const float4 gh = ld4(c.moving + (size_t)j * REC + 4);
+                            const float fb[5] = {yj.w, gh.x, gh.y, gh.z, gh.w};
+                            d2c = feat_d2(fi, fb);
+                            if (d2c < gates.d2c_thres && !(d2c * gates.q_ic > gates.q_lim))
+                                ck = (float)((double)gates.csig2 * exp_small((double)(-d2c) * gates.inv_den_c));
+                            else { ck = 0.f; d2c = __builtin_inff(); }
+                            const size_t cur = (size_t)n * c.rows_pad + li;
+                            c.ckT[cur] = ck; c.dcT[cur] = d2c;
+                        }
+                        av[u] = se_kernel_value_pre(xi, yj, ck, d2c, gates);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const float a = av[u];
+                    if (a > 0.f) {
+                        const float yv[3] = {yv4[u].x, yv4[u].y, yv4[u].z};
+                        float cr[3]; cross3(xi, yv, cr);            // cvo.cpp:216
+                        sw[0] += a * cr[0]; sw[1] += a * cr[1]; sw[2] += a * cr[2];
+                        sv[0] += a * (yv[0] - xi[0]); sv[1] += a * (yv[1] - xi[1]); sv[2] += a * (yv[2] - xi[2]);   // cvo.cpp:217
+                    }
+                    const unsigned long long mask = __ballot(a > 0.f);
+                    if (a > 0.f) {
+                        const size_t pos = sbase + wcount + __popcll(mask & ((1ull << lane) - 1ull));
+                        c.surv0.set(pos, make_float4(xi[0], xi[1], xi[2], a)); c.surv1.set(pos, make_float4(yv4[u].x, yv4[u].y, yv4[u].z, 0.f));
+                    }
+                    wcount += __popcll(mask);
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) { jq[u] = jn[u]; ckq[u] = ckn[u]; dcq[u] = dcn[u]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }   // cvo.cpp:222-223
+        }
+        if (lane == 0) { sh->wcnt[wave] = wcount; acc8[6] = (double)wcount; }
+        if (tid == 0) acc8[7] = (double)total;
+    } else {
+        for (int li = tid; li < nrows; li += nthreads) {            // dense fallback: every column of the row
+            const int i = g + G * li;
+            const float4 lo = ld4(c.fixed + (size_t)i * REC), hi = ld4(c.fixed + (size_t)i * REC + 4);
+            const float xi[3] = {lo.x, lo.y, lo.z};
+            const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
+            float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
+            int nz = 0;
+            for (int j = 0; j < c.nm; ++j) {
+                const float4 yj = c.ybuf[j];
+                const float a = se_kernel_value(xi, fi, yj, ld4(c.moving + (size_t)j * REC + 4), gates);
+                if (a > 0.f) {
+                    const float yv[3] = {yj.x, yj.y, yj.z};
+                    float cr[3]; cross3(xi, yv, cr);
+                    sw[0] += a * cr[0]; sw[1] += a * cr[1]; sw[2] += a * cr[2];
+                    sv[0] += a * (yv[0] - xi[0]); sv[1] += a * (yv[1] - xi[1]); sv[2] += a * (yv[2] - xi[2]);
+                    ++nz;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }
+            acc8[6] += (double)nz;
+            acc8[7] += (double)(c.cnt0[i] + (nwaves >= 8 ? c.cnt1[i] : 0));
+        }
+    }
+    __syncthreads();
+    block_reduce<8>(acc8, sh, tid, nwaves);
+    if (G > 1) {
+        if (tid < 64) { if (!group_exchange<8>(sh, c.xch, G, g, 2u * (unsigned)k + 1u, lane)) sh->status = 6; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        for (int q = 0; q < 3; ++q) { sh->omega[q] = (float)sh->vals[q]; sh->v[q] = (float)sh->vals[3 + q]; }   // cvo.cpp:234-235
+        sh->nnz = (int)sh->vals[6]; sh->cand = (int)sh->vals[7];
+    }
+    __syncthreads();
+}
+
+// ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
+__device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int k_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), k = uni(k_in);
+    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    float omega[3], v[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { omega[q] = sh->omega[q]; v[q] = sh->v[q]; }
+    const LsConsts ls = make_ls(omega, v, sh->ell);
+    double acc4[4] = {0, 0, 0, 0};
+    if (!sh->dense_mode) {
+        for (int w = 0; w < nwaves; ++w) {                          // every wave's survivor segment, all lanes striding it
+            const int cnt_w = sh->wcnt[w];
+            const size_t sb = c.fbase + (size_t)sh->wbase[w];
+            for (int q = tid; q < cnt_w; q += nthreads) {
+                const float4 s0 = c.surv0[sb + q], s1 = c.surv1[sb + q];
+                const float xi[3] = {s0.x, s0.y, s0.z};
+                ls_terms(xi, s1, s0.w, ls, acc4[0], acc4[1], acc4[2], acc4[3]);
+            }
+        }
+    } else {
+        const Gates gates = make_gates(sh->ell, sh->P);
+        for (int li = tid; li < c.nrows; li += nthreads) {
+            const int i = g + G * li;
+            const float4 lo = ld4(c.fixed + (size_t)i * REC), hi = ld4(c.fixed + (size_t)i * REC + 4);
+            const float xi[3] = {lo.x, lo.y, lo.z};
+            const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
+            double Bi = 0, Ci = 0, Di = 0, Ei = 0;
+            for (int j = 0; j < c.nm; ++j) {
+                const float4 yj = c.ybuf[j];
+                const float A_ij = se_kernel_value(xi, fi, yj, ld4(c.moving + (size_t)j * REC + 4), gates);
+                if (A_ij > 0.f) ls_terms(xi, yj, A_ij, ls, Bi, Ci, Di, Ei);
+            }
+            acc4[0] += Bi; acc4[1] += Ci; acc4[2] += Di; acc4[3] += Ei;
+        }
+    }
+    __syncthreads();
+    block_reduce<4>(acc4, sh, tid, nwaves);
+    if (G > 1) {
+        if (tid < 64) { if (!group_exchange<4>(sh, c.xch, G, g, 2u * (unsigned)k + 2u, lane)) sh->status = 6; }
+        __syncthreads();
+    }
+}
+
+// ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
+__device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int tile_in, int k_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), tile = uni(tile_in), k = uni(k_in);
+    Shared* sh = lds_layout(tile).sh;
+    if (threadIdx.x == 0) {
+        const DevParams& P = sh->P;
+        const double B = sh->vals[0], C = sh->vals[1], Dd = sh->vals[2], E = sh->vals[3];
+        float omega[3], v[3];
+        for (int q = 0; q < 3; ++q) { omega[q] = sh->omega[q]; v[q] = sh->v[q]; }
+        const float ell = sh->ell;
+        const float c3 = (float)(4.0 * float(E)), c2 = (float)(3.0 * float(Dd)), c1 = (float)(2.0 * float(C)), c0 = float(B);   // cvo.cpp:318
+        const float step = cubic_step(c3, c2, c1, c0, P.min_step);
+        float dist = -1.f;
+        int stop = 0;
+        if (norm3f(omega) < P.eps && norm3f(v) < P.eps) {                               // cvo.cpp:782
+            stop = 1;
+        } else {
+            float dR[9], dT[3], R[9], T[3], RdT[3], Rn[9];
+            for (int i = 0; i < 9; ++i) R[i] = sh->R[i];
+            for (int i = 0; i < 3; ++i) T[i] = sh->T[i];
+            exp_sek3(omega, v, step, dR, dT);                                           // cvo.cpp:793
+            mat3_vec(R, dT, RdT);
+            for (int q = 0; q < 3; ++q) sh->T[q] = RdT[q] + T[q];                        // cvo.cpp:800
+            mat3_mul(R, dR, Rn);
+            for (int i = 0; i < 9; ++i) sh->R[i] = Rn[i];                                // cvo.cpp:801
+            dist = dist_se3(dR, dT);
+            if (dist < P.eps_2) stop = 1;                                               // cvo.cpp:804
+        }
+        if (stop) sh->iter_at_break = k;
+        else {
+            float l = ell;                                                              // cvo.cpp:810-812
+            l = (k > 2) ? (float)0.10 : l;
+            l = (k > 9) ? (float)0.06 : l;
+            l = (k > 19) ? (float)0.03 : l;
+            sh->ell = l;
+        }
+        sh->stop = stop; sh->step = step; sh->dist = dist;
+        const PairDesc& D = *Dp;
+        if (g == 0 && D.trace && k < D.trace_cap) {
+            TraceRow& tr = D.trace[k];
+            for (int q = 0; q < 3; ++q) { tr.omega[q] = omega[q]; tr.v[q] = v[q]; }
+            tr.nnz = sh->nnz; tr.candidates = sh->cand; tr.B = B; tr.C = C; tr.D = Dd; tr.E = E;
+            tr.step = step; tr.ell = ell; tr.dist = dist; tr.pad_ = 0;
+            *D.trace_len = k + 1;
+        }
+    }
+    __syncthreads();
+}
+
+template <int RPT>
+__global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, DevParams P) {
+    Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
+    const int tid = threadIdx.x;
     const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
+    if (tid == 0) sh->P = P;
 
     for (int p = slot; p < n_pairs; p += slots) {
-        const PairDesc D = descs[p];
-        const int nf = D.nf, nm = D.nm;
-        // rows are dealt round-robin to the pair's workgroups (local row li <-> fixed point g + G*li):
-        // near surfaces have many more neighbours per row than far ones, bands of rows would be unbalanced
+        const PairDesc* Dp = descs + p;
+        const int nf = Dp->nf, nm = Dp->nm;
         const int rows_per = (nf + G - 1) / G;
-        const int nrows = (g < nf) ? (nf - g + G - 1) / G : 0;
-        const int ngroups_all = (nm + 31) >> 5;                     // 32-column groups of the hit bitmap
-        const gfloat* fixed = (const gfloat*)D.fixed;
-        const gfloat* moving = (const gfloat*)D.moving;
-        const GF4 ybuf{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
-        const GF4 ybuild{(gv4f*)D.ybuild + (size_t)g * D.nm_pad};      // positions the candidate lists were built at
-        const int nwords_pad = D.nwords_pad;                        // ngroups_all rounded up to the flush granule
-        gu32* bits = (gu32*)D.bits + (size_t)g * D.rows_pad * nwords_pad;   // [row][word], this workgroup's rows
-        gint* cnt0 = (gint*)D.cnt; gint* cnt1 = cnt0 + D.nf_pad;    // hits per row found by column part 0 / 1
-        gu32* flat_ij = (gu32*)D.flat_ij;
-        const GF4 rec0{(gv4f*)D.rec0}, rec1{(gv4f*)D.rec1}, surv0{(gv4f*)D.surv0}, surv1{(gv4f*)D.surv1};
-        gu64* xch = (gu64*)D.xch;
-        const size_t fbase = (size_t)g * rows_per * D.capf;         // this workgroup's segment of the flat arrays
-        const int flat_cap = rows_per * D.capf;
-
         if (tid == 0) {
-            const PairState* st = D.state;
+            const PairState* st = Dp->state;
             for (int i = 0; i < 9; ++i) sh->R[i] = st->R[i];
             for (int i = 0; i < 3; ++i) sh->T[i] = st->T[i];
             for (int i = 0; i < 12; ++i) sh->M[i] = st->transform[i];
             sh->ell = st->ell;
             sh->stop = 0; sh->status = 0; sh->iter_at_break = st->iter; sh->nnz = 0; sh->cand = 0;
-            sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->dense_fallbacks = 0;
+            sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
 
@@ -421,350 +910,24 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
         if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
 
         for (; ok_pair && k < P.max_iter; ++k) {
-            // ---- update_tf (cvo.cpp:770): every lane forms the same 3x4 transform
-            float M[12];
-            {
-                float R[9], T[3];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) R[i] = sh->R[i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) T[i] = sh->T[i];
-                make_transform(R, T, M);
+            phase_transform(Dp, g, G, tile, y_lds);
+            if (sh->rebuild) {
+                const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
+                phase_cull<RPT>(Dp, g, G, tile);
+                const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
+                phase_lists(Dp, g, G, tile);
+                const unsigned long long t_c = __builtin_amdgcn_s_memrealtime();
+                ticks[6] += t_b - t_a; ticks[8] += t_c - t_b;
             }
-            const float ell = sh->ell;
-            const Gates gates = make_gates(ell, P);
-            const float r_c = sqrtf(gates.d2_thres);
-
-            // ---- T: transform_pcd (cvo.cpp:336-341) into ybuf; on the way, how far has any point moved
-            // since the candidate lists were built?  (exact displacement of the very positions the tests use)
-            const bool have_list = sh->list_valid != 0;
-            float dmax2 = 0.f;
-            for (int j = tid; j < nm; j += nthreads) {
-                const float4 lo = ld4(moving + (size_t)j * REC);
-                float y0, y1, y2;
-                apply_transform(M, lo.x, lo.y, lo.z, y0, y1, y2);
-                ybuf.set(j, make_float4(y0, y1, y2, lo.w));
-                if (have_list) {
-                    const float4 yb = ybuild[j];
-                    const float e0 = y0 - yb.x, e1 = y1 - yb.y, e2 = y2 - yb.z;
-                    dmax2 = fmaxf(dmax2, __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)));
-                }
-            }
-            dmax2 = block_max(dmax2, sh, tid, nwaves);              // also makes ybuf visible to the workgroup
-            // the lists hold every pair within Rb of the build positions; a pair within r_c now was within
-            // r_c + (its point's displacement) then.  Every workgroup of the pair computes the same bits here.
-            const bool rebuild = !have_list || (sh->ell_build != ell) ||
-                                 (r_c + sqrtf(dmax2) * 1.0001f + 1.0e-5f) * 1.00001f > sh->Rb;
-
-            if (rebuild) {
-                // ---- S: for each block of RPT*nthreads rows, stream the moving cloud through LDS tiles
-                const float Rb = r_c * (1.0f + P.skin);
-                const float thr_cull = Rb * Rb * 1.00001f;
-                // waves form a RGN x CPN grid: RGN groups of 64*RPT rows, CPN column parts of every tile, so
-                // that all waves carry the same number of pair tests (two per SIMD, none left alone)
-                const int wave = tid >> 6;
-                const int CPN = (nwaves >= 8) ? 2 : 1, RGN = nwaves / CPN;
-                const int rg = wave % RGN, cp = wave / RGN;
-                volatile uint32_t* stg = stg_all + wave * STG_WORDS_PER_WAVE;
-                gint* cnt_part = cp ? cnt1 : cnt0;
-                for (int rb = 0; rb < nrows; rb += RPT * RGN * 64) {
-                    float x[RPT][3]; int row0[RPT]; int cnt[RPT];
-                    int nv = 0;
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        row0[r] = rb + r * (RGN * 64) + rg * 64;
-                        const int li = row0[r] + lane;
-                        cnt[r] = 0;
-                        if (li < nrows) {
-                            const float4 lo = ld4(fixed + (size_t)(g + G * li) * REC);
-                            x[r][0] = lo.x; x[r][1] = lo.y; x[r][2] = lo.z;
-                        } else {
-                            x[r][0] = x[r][1] = x[r][2] = FAR_ROW;
-                        }
-                        if (row0[r] < nrows) nv = r + 1;            // rows are a prefix per wave: skip the all-padding ones
-                    }
-                    for (int t0 = 0; t0 < nm; t0 += tile) {
-                        const int tn = min(tile, nm - t0);
-                        const int gran = 32 * STG_GROUPS * CPN;     // every column part is a whole number of flush granules
-                        const int tnp = (tn + gran - 1) / gran * gran;
-                        __syncthreads();                            // previous tile fully consumed
-                        for (int jj = tid; jj < tnp; jj += nthreads) {
-                            float4 y = make_float4(FAR_COL, FAR_COL, FAR_COL, 0.f);
-                            if (jj < tn) { y = ybuf[t0 + jj]; if (rb == 0) ybuild.set(t0 + jj, y); }
-                            lx[jj] = y.x; ly[jj] = y.y; lz[jj] = y.z;
-                        }
-                        __syncthreads();
-                        const int ngp = (tnp >> 5) / CPN;           // groups in this wave's column part
-                        const int c0 = cp * ngp * 32;               // its first column inside the tile
-                        const int wb = (t0 >> 5) + cp * ngp;        // its first bitmap word
-                        if (RPT >= 4 && nv == 4) sweep_part<(RPT >= 4 ? 4 : 1), RPT>(lx + c0, ly + c0, lz + c0, ngp, wb, x, row0, nrows, cnt, bits, nwords_pad, stg, thr_cull, lane);
-                        else if (RPT >= 3 && nv == 3) sweep_part<(RPT >= 3 ? 3 : 1), RPT>(lx + c0, ly + c0, lz + c0, ngp, wb, x, row0, nrows, cnt, bits, nwords_pad, stg, thr_cull, lane);
-                        else if (RPT >= 2 && nv == 2) sweep_part<(RPT >= 2 ? 2 : 1), RPT>(lx + c0, ly + c0, lz + c0, ngp, wb, x, row0, nrows, cnt, bits, nwords_pad, stg, thr_cull, lane);
-                        else if (nv >= 1) sweep_part<1, RPT>(lx + c0, ly + c0, lz + c0, ngp, wb, x, row0, nrows, cnt, bits, nwords_pad, stg, thr_cull, lane);
-                    }
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) { const int li = row0[r] + lane; if (li < nrows) cnt_part[g + G * li] = cnt[r]; }
-                }
-                __syncthreads();                                    // counts, bitmap visible to the whole workgroup
-                unsigned long long t_sub = __builtin_amdgcn_s_memrealtime();
-                ticks[6] += t_sub - t_prev;
-                // ---- row offsets (exclusive scan of the counts), then the set bits become the flat lists
-                const int rps = (nrows + nthreads - 1) / nthreads;
-                const int l0 = min(nrows, tid * rps), l1 = min(nrows, l0 + rps);
-                int mine = 0;
-                for (int li = l0; li < l1; ++li) mine += cnt0[g + G * li] + (CPN > 1 ? cnt1[g + G * li] : 0);
-                int total = 0;
-                int run = block_exclusive_scan(mine, sh, tid, nwaves, total);
-                for (int li = l0; li < l1; ++li) { rowoff[li] = run; run += cnt0[g + G * li] + (CPN > 1 ? cnt1[g + G * li] : 0); }
-                if (tid == 0) rowoff[nrows] = total;
-                const int dense = (total > flat_cap) ? 1 : 0;       // lists too small: dense per-row fallback until the next rebuild
-                __syncthreads();
-                { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); ticks[7] += t_now - t_sub; t_sub = t_now; }
-                if (!dense) {
-                    // a wave takes four rows per trip (their bitmap words are loaded together); lanes = consecutive
-                    // words of a row, an in-wave prefix sum of the popcounts places every lane's hits, so the
-                    // packed (row << 16 | column) entries of a row leave the wave as one contiguous run
-                    const int nwords = ngroups_all;
-                    for (int li0 = wave * 4; li0 < nrows; li0 += nwaves * 4) {
-                        size_t o[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) o[u] = fbase + rowoff[min(li0 + u, nrows)];
-                        for (int wb0 = 0; wb0 < nwords; wb0 += 64) {
-                            uint32_t wv[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                wv[u] = (li0 + u < nrows && wb0 + lane < nwords) ? bits[(size_t)(li0 + u) * nwords_pad + wb0 + lane] : 0u;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                uint32_t w = wv[u];
-                                const int c = __popc(w);
-                                int inc = c;
-#pragma unroll
-                                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
-                                const int tot = __shfl(inc, 63, 64);
-                                size_t pos = o[u] + (size_t)(inc - c);
-                                const uint32_t tag = ((uint32_t)(li0 + u) << 16) | (uint32_t)((wb0 + lane) * 32);
-                                while (w) {                         // bit 31 = first column of the group: ascending columns
-                                    const int kbit = __clz(w);
-                                    flat_ij[pos++] = tag + (uint32_t)kbit;
-                                    w &= ~(0x80000000u >> kbit);
-                                }
-                                o[u] += tot;
-                            }
-                        }
-                    }
-                }
-                if (tid == 0) {
-                    sh->Rb = Rb; sh->ell_build = ell; sh->list_valid = 1;
-                    sh->dense_mode = dense; sh->total = total;
-                    sh->rebuilds += 1; sh->dense_fallbacks += dense ? 1 : 0;
-                }
-                __syncthreads();
-                ticks[8] += __builtin_amdgcn_s_memrealtime() - t_sub;
-            }
-            const int total = sh->total;
-            const bool dense_mode = sh->dense_mode != 0;
             CVO_PHASE(0);
-
-            // ---- C: exact kernel values + compute_flow row sums (cvo.cpp:202-231)
-            const float inv_c = 1 / P.c, inv_d = 1 / P.d;
-            double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // omega[3], v[3], nnz, candidates
-            unsigned long long t_c2 = 0;
-            constexpr int CU = 2;
-            const int CW = (((total + nwaves - 1) / nwaves) + 64 * CU - 1) / (64 * CU) * (64 * CU);   // candidates per wave chunk
-            if (!dense_mode) {
-                // C1: one lane per candidate, a contiguous chunk per wave; survivors are compacted (ballot +
-                // prefix popcount keeps candidate order) into the wave's segment for the line-search phase
-                const int wave = tid >> 6;
-                const int c_begin = min(total, wave * CW), c_end = min(total, c_begin + CW);
-                int wcount = 0;
-                for (int cb = c_begin; cb < c_end; cb += 64 * CU) {  // CU candidates per lane per trip: their gathers are in flight together
-                    int cc[CU]; bool val[CU]; int li4[CU], j4[CU];
-#pragma unroll
-                    for (int u = 0; u < CU; ++u) {
-                        cc[u] = cb + u * 64 + lane; val[u] = cc[u] < c_end;
-                        const uint32_t ij = val[u] ? flat_ij[fbase + cc[u]] : 0u;
-                        li4[u] = (int)(ij >> 16); j4[u] = (int)(ij & 0xFFFFu);
-                    }
-                    float4 lo4[CU], hi4[CU], yj4[CU], gj4[CU];
-#pragma unroll
-                    for (int u = 0; u < CU; ++u) {
-                        const gfloat* xr = fixed + (size_t)(g + G * li4[u]) * REC;
-                        lo4[u] = ld4(xr); hi4[u] = ld4(xr + 4);
-                        yj4[u] = ybuf[j4[u]]; gj4[u] = ld4(moving + (size_t)j4[u] * REC + 4);
-                    }
-#pragma unroll
-                    for (int u = 0; u < CU; ++u) {
-                        float a = 0.f;
-                        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, s0 = q0, s1 = q0;
-                        if (val[u]) {
-                            const float xi[3] = {lo4[u].x, lo4[u].y, lo4[u].z};
-                            const float fi[5] = {lo4[u].w, hi4[u].x, hi4[u].y, hi4[u].z, hi4[u].w};
-                            a = se_kernel_value(xi, fi, yj4[u], gj4[u], gates);
-                            if (a > 0.f) {
-                                const float yv[3] = {yj4[u].x, yj4[u].y, yj4[u].z};
-                                float cr[3]; cross3(xi, yv, cr);    // cvo.cpp:216
-                                q0 = make_float4(a * cr[0], a * cr[1], a * cr[2], a * (yv[0] - xi[0]));   // cvo.cpp:217
-                                q1 = make_float4(a * (yv[1] - xi[1]), a * (yv[2] - xi[2]), a, 0.f);
-                                s0 = make_float4(xi[0], xi[1], xi[2], a);
-                                s1 = make_float4(yv[0], yv[1], yv[2], 0.f);
-                            }
-                            rec0.set(fbase + cc[u], q0); rec1.set(fbase + cc[u], q1);
-                        }
-                        const unsigned long long mask = __ballot(a > 0.f);
-                        if (a > 0.f) {
-                            const int pos = wcount + __popcll(mask & ((1ull << lane) - 1ull));
-                            surv0.set(fbase + c_begin + pos, s0); surv1.set(fbase + c_begin + pos, s1);
-                        }
-                        wcount += __popcll(mask);
-                    }
-                }
-                if (lane == 0) { sh->wcnt[wave] = wcount; acc8[6] = (double)wcount; }
-                if (tid == 0) acc8[7] = (double)total;
-                __syncthreads();
-                t_c2 = __builtin_amdgcn_s_memrealtime();
-                for (int li = tid; li < nrows; li += nthreads) {    // C2: one lane per row, f32 sums in column order
-                    float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
-                    const int c1 = rowoff[li + 1];
-                    int c = rowoff[li];
-                    for (; c + 4 <= c1; c += 4) {                   // non-members hold +0: adding them changes nothing
-                        float4 a0[4], a1[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { a0[u] = rec0[fbase + c + u]; a1[u] = rec1[fbase + c + u]; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            sw[0] += a0[u].x; sw[1] += a0[u].y; sw[2] += a0[u].z;
-                            sv[0] += a0[u].w; sv[1] += a1[u].x; sv[2] += a1[u].y;
-                        }
-                    }
-                    for (; c < c1; ++c) {
-                        const float4 a0 = rec0[fbase + c], a1 = rec1[fbase + c];
-                        sw[0] += a0.x; sw[1] += a0.y; sw[2] += a0.z;
-                        sv[0] += a0.w; sv[1] += a1.x; sv[2] += a1.y;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }   // cvo.cpp:222-223
-                }
-            } else {
-                for (int li = tid; li < nrows; li += nthreads) {    // dense fallback: every column of the row
-                    const int i = g + G * li;
-                    const float4 lo = ld4(fixed + (size_t)i * REC), hi = ld4(fixed + (size_t)i * REC + 4);
-                    const float xi[3] = {lo.x, lo.y, lo.z};
-                    const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
-                    float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
-                    int nz = 0;
-                    for (int j = 0; j < nm; ++j) {
-                        const float4 yj = ybuf[j];
-                        const float a = se_kernel_value(xi, fi, yj, ld4(moving + (size_t)j * REC + 4), gates);
-                        if (a > 0.f) {
-                            const float yv[3] = {yj.x, yj.y, yj.z};
-                            float cr[3]; cross3(xi, yv, cr);
-                            sw[0] += a * cr[0]; sw[1] += a * cr[1]; sw[2] += a * cr[2];
-                            sv[0] += a * (yv[0] - xi[0]); sv[1] += a * (yv[1] - xi[1]); sv[2] += a * (yv[2] - xi[2]);
-                            ++nz;
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }
-                    acc8[6] += (double)nz;
-                    acc8[7] += (double)(cnt0[i] + (nwaves >= 8 ? cnt1[i] : 0));
-                }
-            }
-            __syncthreads();
-            if (!dense_mode) ticks[9] += __builtin_amdgcn_s_memrealtime() - t_c2;
+            phase_candidates(Dp, g, G, tile, y_lds, k);
+            cand_total += sh->cand;
             CVO_PHASE(1);
-            block_reduce<8>(acc8, sh, tid, nwaves);
-            if (G > 1) {
-                if (tid < 64) { if (!group_exchange<8>(sh, xch, G, g, 2u * (unsigned)k + 1u, lane)) sh->status = 6; }
-                __syncthreads();
-            }
             if (sh->status != 0) break;
-            float omega[3], v[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { omega[q] = (float)sh->vals[q]; v[q] = (float)sh->vals[3 + q]; }   // cvo.cpp:234-235
-            const int nnz = (int)sh->vals[6];
-            const int ncand = (int)sh->vals[7];
-            cand_total += ncand;
-            CVO_PHASE(2);
-
-            // ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
-            const LsConsts ls = make_ls(omega, v, ell);
-            double acc4[4] = {0, 0, 0, 0};
-            if (!dense_mode) {
-                for (int w = 0; w < nwaves; ++w) {                  // every wave's survivor segment, all lanes striding it
-                    const int cnt_w = sh->wcnt[w];
-                    const size_t sb = fbase + (size_t)min(total, w * CW);
-                    for (int q = tid; q < cnt_w; q += nthreads) {
-                        const float4 s0 = surv0[sb + q], s1 = surv1[sb + q];
-                        const float xi[3] = {s0.x, s0.y, s0.z};
-                        ls_terms(xi, s1, s0.w, ls, acc4[0], acc4[1], acc4[2], acc4[3]);
-                    }
-                }
-            } else {
-                for (int li = tid; li < nrows; li += nthreads) {
-                    const int i = g + G * li;
-                    const float4 lo = ld4(fixed + (size_t)i * REC), hi = ld4(fixed + (size_t)i * REC + 4);
-                    const float xi[3] = {lo.x, lo.y, lo.z};
-                    const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
-                    double Bi = 0, Ci = 0, Di = 0, Ei = 0;
-                    for (int j = 0; j < nm; ++j) {
-                        const float4 yj = ybuf[j];
-                        const float A_ij = se_kernel_value(xi, fi, yj, ld4(moving + (size_t)j * REC + 4), gates);
-                        if (A_ij > 0.f) ls_terms(xi, yj, A_ij, ls, Bi, Ci, Di, Ei);
-                    }
-                    acc4[0] += Bi; acc4[1] += Ci; acc4[2] += Di; acc4[3] += Ei;
-                }
-            }
-            __syncthreads();
+            phase_linesearch(Dp, g, G, tile, k);
             CVO_PHASE(3);
-            block_reduce<4>(acc4, sh, tid, nwaves);
-            if (G > 1) {
-                if (tid < 64) { if (!group_exchange<4>(sh, xch, G, g, 2u * (unsigned)k + 2u, lane)) sh->status = 6; }
-                __syncthreads();
-            }
             if (sh->status != 0) break;
-            CVO_PHASE(4);
-
-            // ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
-            if (tid == 0) {
-                const double B = sh->vals[0], C = sh->vals[1], Dd = sh->vals[2], E = sh->vals[3];
-                const float c3 = (float)(4.0 * float(E)), c2 = (float)(3.0 * float(Dd)), c1 = (float)(2.0 * float(C)), c0 = float(B);   // cvo.cpp:318
-                const float step = cubic_step(c3, c2, c1, c0, P.min_step);
-                float dist = -1.f;
-                int stop = 0;
-                if (norm3f(omega) < P.eps && norm3f(v) < P.eps) {                               // cvo.cpp:782
-                    stop = 1;
-                } else {
-                    float dR[9], dT[3], R[9], T[3], RdT[3], Rn[9];
-                    for (int i = 0; i < 9; ++i) R[i] = sh->R[i];
-                    for (int i = 0; i < 3; ++i) T[i] = sh->T[i];
-                    exp_sek3(omega, v, step, dR, dT);                                           // cvo.cpp:793
-                    mat3_vec(R, dT, RdT);
-                    for (int q = 0; q < 3; ++q) sh->T[q] = RdT[q] + T[q];                        // cvo.cpp:800
-                    mat3_mul(R, dR, Rn);
-                    for (int i = 0; i < 9; ++i) sh->R[i] = Rn[i];                                // cvo.cpp:801
-                    dist = dist_se3(dR, dT);
-                    if (dist < P.eps_2) stop = 1;                                               // cvo.cpp:804
-                }
-                if (stop) sh->iter_at_break = k;
-                else {
-                    float l = ell;                                                              // cvo.cpp:810-812
-                    l = (k > 2) ? (float)0.10 : l;
-                    l = (k > 9) ? (float)0.06 : l;
-                    l = (k > 19) ? (float)0.03 : l;
-                    sh->ell = l;
-                }
-                sh->stop = stop; sh->nnz = nnz; sh->cand = ncand; sh->step = step;
-                for (int i = 0; i < 12; ++i) sh->M[i] = M[i];
-                if (g == 0 && D.trace && k < D.trace_cap) {
-                    TraceRow& tr = D.trace[k];
-                    for (int q = 0; q < 3; ++q) { tr.omega[q] = omega[q]; tr.v[q] = v[q]; }
-                    tr.nnz = nnz; tr.candidates = ncand; tr.B = B; tr.C = C; tr.D = Dd; tr.E = E;
-                    tr.step = step; tr.ell = ell; tr.dist = dist; tr.pad_ = 0;
-                    *D.trace_len = k + 1;
-                }
-            }
-            __syncthreads();
+            phase_epilogue(Dp, g, tile, k);
             CVO_PHASE(5);
             if (sh->stop) { ++k; break; }
         }
@@ -772,7 +935,7 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
         // ---- after the loop (cvo.cpp:815-817): write the pair's state back
         __syncthreads();
         if (tid == 0 && g == 0) {
-            PairState* st = D.state;
+            PairState* st = Dp->state;
             float R[9], T[3], M[12];
             for (int i = 0; i < 9; ++i) { R[i] = sh->R[i]; st->R[i] = R[i]; }
             for (int i = 0; i < 3; ++i) { T[i] = sh->T[i]; st->T[i] = T[i]; }
@@ -793,10 +956,10 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
     }
 }
 
-template __global__ void cvo_align_kernel<1>(const PairDesc*, int, int, int, DevParams);
-template __global__ void cvo_align_kernel<2>(const PairDesc*, int, int, int, DevParams);
-template __global__ void cvo_align_kernel<3>(const PairDesc*, int, int, int, DevParams);
-template __global__ void cvo_align_kernel<4>(const PairDesc*, int, int, int, DevParams);
+template __global__ void cvo_align_kernel<1>(const PairDesc*, int, int, int, int, DevParams);
+template __global__ void cvo_align_kernel<2>(const PairDesc*, int, int, int, int, DevParams);
+template __global__ void cvo_align_kernel<3>(const PairDesc*, int, int, int, int, DevParams);
+template __global__ void cvo_align_kernel<4>(const PairDesc*, int, int, int, int, DevParams);
 
 // 64-byte result record per pair for the cross-GPU gather: 12 floats of transform,
 // then iter, A_nonzero, iterations_run, status as floats (exact below 2^24).
@@ -814,15 +977,17 @@ hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream
 
 int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
 
-size_t align_shared_bytes(int tile) {
+// LDS: Shared | row offsets | cull tile (3*tile floats) | per-wave transpose patches | resident y cloud (16 B * nm_pad, optional)
+size_t align_shared_bytes(int tile, int y_points) {
     return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)(MAX_ROWS_PER_WG + 64) * sizeof(int) + (size_t)3 * tile * sizeof(float) +
-           (size_t)MAX_WAVES * STG_WORDS_PER_WAVE * sizeof(uint32_t);
+           (size_t)MAX_WAVES * STG_WORDS_PER_WAVE * sizeof(uint32_t) + (size_t)y_points * sizeof(float4);
 }
 int align_tile_granule() { return 32 * STG_GROUPS * 2; }
 
-hipError_t launch_align(int rpt, int grid, int block, int tile, hipStream_t stream, const PairDesc* descs, int n_pairs, int G, const DevParams& P) {
-    const size_t shmem = align_shared_bytes(tile);
-    void (*fn)(const PairDesc*, int, int, int, DevParams) = nullptr;
+hipError_t launch_align(int rpt, int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+                        const DevParams& P) {
+    const size_t shmem = align_shared_bytes(tile, y_points);
+    void (*fn)(const PairDesc*, int, int, int, int, DevParams) = nullptr;
     switch (rpt) {
         case 1: fn = cvo_align_kernel<1>; break;
         case 2: fn = cvo_align_kernel<2>; break;
@@ -831,7 +996,7 @@ hipError_t launch_align(int rpt, int grid, int block, int tile, hipStream_t stre
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, P);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_points > 0 ? 1 : 0, P);
     return hipGetLastError();
 }
 
