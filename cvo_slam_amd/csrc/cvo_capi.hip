@@ -24,7 +24,7 @@ namespace cvohip {
 size_t align_shared_bytes(int tile, int y_points);
 int align_tile_granule();
 int align_blocks_per_cu();
-hipError_t launch_align(int rpt, int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 int score_grid(int na);
@@ -107,7 +107,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
-    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_bits, d_cnt, d_flat_ij, d_jT, d_ckT, d_dcT, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
+    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_jT, d_ckT, d_dcT, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
     PinBuf h_descs, h_states, h_stage, h_partials;
     int wg_request = 0;          // 0 = auto
     int tile_request = 0;        // 0 = auto
@@ -133,7 +133,7 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_bits, &d_cnt, &d_flat_ij, &d_jT, &d_ckT, &d_dcT, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_jT, &d_ckT, &d_dcT, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -195,8 +195,6 @@ struct Engine {
         const int rows_per = (nf_max + G - 1) / G;
         int block = rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64));
         if (block_request > 0) block = std::max(64, std::min(512, round_up(block_request, 64)));
-        const int row_unit = block >= 512 ? 256 : block;                 // rows one register slot covers: the waves form 4 row groups x 2 column parts
-        int rpt = std::max(1, std::min(4, (rows_per + row_unit - 1) / row_unit));
 
         int rc;
         if ((rc = d_descs.ensure(sizeof(PairDesc) * n))) return rc;
@@ -205,13 +203,8 @@ struct Engine {
         if ((rc = h_states.ensure(sizeof(PairState) * n))) return rc;
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
         const size_t plane = (size_t)(nf_pad + G) * capf;
-        const int rows_pad = round_up(std::max(rows_per, 1), 64);
-        const int nwords_pad = round_up((nm_max + 31) / 32 + tgran / 32, 4);   // a tile's padded tail may spill past ceil(nm/32)
-        const size_t bits_words = (size_t)G * rows_pad * nwords_pad;
+        const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
         if ((rc = d_ybuild.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
-        if ((rc = d_bits.ensure(sizeof(uint32_t) * (size_t)n * bits_words))) return rc;
-        if ((rc = d_cnt.ensure(sizeof(int) * (size_t)n * 2 * nf_pad))) return rc;
-        if ((rc = d_flat_ij.ensure(sizeof(uint32_t) * (size_t)n * plane))) return rc;
         int capn = 64; while (capn < nm_max / 8 && capn < 4096) capn *= 2;   // longest transposed row: 512 at 3k points, 2048 at 10k
         if (const char* e = std::getenv("CVO_HIP_ROW_CAP")) capn = std::max(1, std::atoi(e));
         const size_t tplane = (size_t)G * capn * rows_pad;
@@ -237,10 +230,6 @@ struct Engine {
             D.nf_pad = nf_pad; D.rows_pad = rows_pad; D.capf = capf; D.nm_pad = nm_pad;
             D.ybuf = static_cast<float4*>(d_ybuf.p) + (size_t)i * G * nm_pad;
             D.ybuild = static_cast<float4*>(d_ybuild.p) + (size_t)i * G * nm_pad;
-            D.bits = static_cast<uint32_t*>(d_bits.p) + (size_t)i * bits_words;
-            D.nwords_pad = nwords_pad;
-            D.cnt = static_cast<int*>(d_cnt.p) + (size_t)i * 2 * nf_pad;
-            D.flat_ij = static_cast<uint32_t*>(d_flat_ij.p) + (size_t)i * plane;
             D.capn = capn;
             D.jT = static_cast<uint16_t*>(d_jT.p) + (size_t)i * tplane;
             D.ckT = static_cast<float*>(d_ckT.p) + (size_t)i * tplane;
@@ -263,7 +252,7 @@ struct Engine {
         // keep the transformed moving cloud resident in LDS (16 B per point) when it fits beside the rest
         int y_points = 0;
         if (align_shared_bytes(tile, nm_pad) <= (size_t)156 * 1024 && !std::getenv("CVO_HIP_NO_YLDS")) y_points = nm_pad;
-        hipError_t e = launch_align(rpt, grid, block, tile, y_points, s, static_cast<const PairDesc*>(d_descs.p), n, G, P);
+        hipError_t e = launch_align(grid, block, tile, y_points, s, static_cast<const PairDesc*>(d_descs.p), n, G, P);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));
         HIP_TRY(hipMemcpyAsync(h_states.p, d_states.p, sizeof(PairState) * n, hipMemcpyDeviceToHost, s));

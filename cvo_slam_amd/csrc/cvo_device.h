@@ -60,17 +60,13 @@ struct PairDesc {
     const float* moving;     // [nm][REC]
     int nf, nm;
     int nf_pad, nm_pad;      // multiples of 64
-    int rows_pad;            // rows_per rounded up to 64: row stride of the hit bitmap
+    int rows_pad;            // rows_per rounded up to 128: row stride of the transposed lists
     int capf;                // flat capacity per row, on average (a workgroup owning r rows may hold r*capf candidates)
     float4* ybuf;            // [G][nm_pad]     transformed moving points {y0,y1,y2,g0}
     float4* ybuild;          // [G][nm_pad]     the positions the candidate lists were built at
-    uint32_t* bits;          // [G][rows_pad][nwords_pad]  row-major hit bitmap of the last cull (bit 31 = first column of a word)
-    int nwords_pad;          // words per bitmap row: ceil(nm/32) rounded up to the flush granule
-    int* cnt;                // [2][nf_pad]     hits per row found by each of the two column parts of the cull
-    // flat arrays: plane = (nf_pad + G) * capf entries; workgroup g owns [g*rows_per*capf, (g+1)*rows_per*capf)
-    uint32_t* flat_ij;       // compacted candidates (local row << 16 | column); a row's are contiguous, columns ascending
+    // survivor planes: (nf_pad + G) * capf entries; workgroup g owns [g*rows_per*capf, (g+1)*rows_per*capf)
     int capn;                // longest row the transposed lists hold (longer => dense fallback)
-    uint16_t* jT;            // [G][capn][rows_pad]  transposed lists: column of entry n of local row li
+    uint16_t* jT;            // [G][capn][rows_pad]  transposed lists: column of entry n of local row li, columns ascending
     float* ckT;              // same shape: colour factor ck of the pair (filled by the first pass over a new list)
     float* dcT;              // same shape: colour distance d2c (+inf = failed the colour gate)
     float4* surv0;           // survivors compacted per wave chunk, in candidate order: {x_i, a}

@@ -2,32 +2,31 @@
 //
 // cvo_align_kernel: the whole of cvo::align() (thirdparty/cvo/src/cvo.cpp:763-821)
 // for a batch of independent frame pairs in ONE persistent launch.  G workgroups
-// cooperate on a pair (each owns a contiguous block of fixed-cloud rows) and stay
+// cooperate on a pair (rows of the fixed cloud are dealt round-robin to them) and stay
 // resident for all of its iterations; R, T, ell never leave the device.
 //
-// One iteration (cvo.cpp:768-813):
-//   T   transform_pcd (cvo.cpp:336-341): y_j = M p_j into ybuf (HBM/L2 resident)
-//   S   [only when the candidate lists are stale]  dense O(N*M) cull: the moving
-//       cloud streams through LDS tiles (SoA, ds_read_b128 broadcasts, 4 columns per
-//       read), rows live in registers (RPT per lane), 3 sub + 1 mul + 2 fma per
-//       pair and one v_min3-folded compare per 4*RPT pairs; hits are appended to the
-//       row's staging list in ascending column order (= the CSR order of
-//       Eigen::setFromTriplets, cvo.cpp:182), then compacted into flat arrays.
-//       The lists are built with radius (1+skin)*r and stay valid until the rigid
-//       motion since the build can have moved any point by skin*r (checked every
-//       iteration from the two transforms and max|p|), or ell changes.
-//   C1  one lane per candidate: the reference's own pair arithmetic (cvo.cpp:166-175:
-//       un-fused f32 d2, colour gate, double exp, a > sp_thres) -> a, a*(x cross y), a*(y-x)
-//   C2  one lane per row: f32 sums in column order (cvo.cpp:213-223), f64 across
-//       rows (cvo.cpp:226-230) by wave shuffles + LDS, exchanged between the pair's
-//       workgroups as tagged 8-byte granules
+// One iteration (cvo.cpp:768-813), each phase a non-inlined device function:
+//   T   transform_pcd (cvo.cpp:336-341): y_j = M p_j into ybuf and an LDS-resident copy; exact
+//       displacement of every point since the candidate lists were built
+//   S   [only when the lists are stale]  dense cull straight into per-row candidate lists:
+//       the moving cloud sits in an LDS tile (SoA, ds_read_b128 broadcasts), a lane carries
+//       two rows, 3 sub + 3 fma + 1 v_alignbit per pair test; 32-column groups whose bounding
+//       box is out of reach of the wave's rows are skipped; hits are appended in ascending
+//       column order (= the CSR order of Eigen::setFromTriplets, cvo.cpp:182) to the
+//       transposed list jT[n][row].  Lists are built with radius (1+skin)*r and stay valid
+//       until some point has moved skin*r, or ell changes.
+//   C   one lane per row walks its list: the reference's own pair arithmetic (cvo.cpp:166-175:
+//       un-fused f32 d2, colour gate, double exp, a > sp_thres), f32 row sums in column order
+//       (cvo.cpp:213-223), f64 across rows (cvo.cpp:226-230) by wave shuffles + LDS, exchanged
+//       between the pair's workgroups as tagged 8-byte granules; survivors {x_i,a},{y_j} are
+//       compacted per wave
 //   L   one lane per survivor: beta..epsil and the B..E terms (cvo.cpp:282-306), f64
 //   E   one lane: cubic, stop tests, Exp_SEK3, pose update, ell schedule
 //       (cvo.cpp:317-333, 782-812)
 // The cull uses fused arithmetic and a widened radius (a superset of the reference's
-// neighbourhood); membership in A is decided in C1 by the reference's own
-// expression, so the sparse set, every kernel value and every per-row sum follow
-// the oracle's float sequence regardless of when the lists were built.
+// neighbourhood); membership in A is decided in C by the reference's own expression, so the
+// sparse set, every kernel value and every per-row sum follow the oracle's float sequence
+// regardless of when the lists were built.
 //
 // MFMA is deliberately not used: S is a distance test + compare, C1/L are
 // exp-heavy survivor work; neither is a contraction.
@@ -192,6 +191,7 @@ struct Gates {
     float s2, csig2;
     double inv_den_l, inv_den_c;
     float q_lim, q_il, q_ic;  // conservative f32 pre-test of a > sp before the double exps
+    bool poly_ok;             // q_lim <= 0.25: exponents of pairs that pass the pre-test need no range reduction
 };
 
 // exp(x) in double for the only arguments the survivor path produces: the pre-test
@@ -200,8 +200,7 @@ struct Gates {
 // ~1 ulp like libm's exp; anything outside [-0.25, 0] takes the library routine.  The
 // value is rounded to f32 right after (cvo.cpp:172-173), where a 1-ulp double
 // difference is invisible except on ~1e-8 of inputs.
-__device__ __forceinline__ double exp_small(double x) {
-    if (!(x >= -0.25 && x <= 0.0)) return exp(x);
+__device__ __forceinline__ double exp_poly13(double x) {
     double p = 1.0 / 6227020800.0;                                  // 1/13!
     p = __builtin_fma(p, x, 1.0 / 479001600.0);
     p = __builtin_fma(p, x, 1.0 / 39916800.0);
@@ -217,6 +216,10 @@ __device__ __forceinline__ double exp_small(double x) {
     p = __builtin_fma(p, x, 1.0);
     p = __builtin_fma(p, x, 1.0);
     return p;
+}
+__device__ __forceinline__ double exp_small(double x) {
+    if (!(x >= -0.25 && x <= 0.0)) return exp(x);
+    return exp_poly13(x);
 }
 
 __device__ __forceinline__ float feat_d2(const float* fa, const float* fb) {   // fixed-size 5 reduction (t0+t1)+(t2+(t3+t4))
@@ -256,6 +259,19 @@ __device__ __forceinline__ float se_kernel_value_pre(const float* xi, const floa
     return a > G.sp ? a : 0.f;
 }
 
+// Branch-free form for the candidate loop (several independent entries in flight per lane); requires
+// Gates::poly_ok, i.e. every exponent that passes the pre-test lies in [-0.25, 0].  A rejected pair's
+// arithmetic runs on a clamped argument and is thrown away.
+__device__ __forceinline__ float se_kernel_value_flat(const float* xi, const float4 yj, float ck, float d2c, bool active, const Gates& G) {
+    const float e0 = xi[0] - yj.x, e1 = xi[1] - yj.y, e2 = xi[2] - yj.z;
+    float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;                  // nanoflann.hpp:403-406
+    const bool pass = active & (d2 < G.d2_thres) & !(d2 * G.q_il + d2c * G.q_ic > G.q_lim);
+    const double x = fmax((double)(-d2) * G.inv_den_l, -0.25);
+    const float k = (float)((double)G.s2 * exp_poly13(x));
+    const float a = ck * k;
+    return (pass & (a > G.sp)) ? a : 0.f;
+}
+
 __device__ __forceinline__ Gates make_gates(float l, const DevParams& P) {
     Gates G;
     G.s2 = P.sigma * P.sigma;                                       // se_kernel(ell, sigma*sigma), cvo.cpp:189
@@ -270,6 +286,7 @@ __device__ __forceinline__ Gates make_gates(float l, const DevParams& P) {
     G.q_il = (float)G.inv_den_l;
     G.q_ic = (float)G.inv_den_c;
     G.q_lim = logf(G.s2 * G.csig2 / P.sp_thres) * 1.001f + 1e-3f;   // a>sp  <=>  d2/den_l + d2c/den_c < ln(s2*csig2/sp)
+    G.poly_ok = G.q_lim <= 0.25f;
     return G;
 }
 
@@ -314,74 +331,47 @@ __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float
 }
 
 // ---------------------------------------------------------------- S: dense cull
-// Branch-free, 7 VALU per pair test: 3 sub, 3 fma (the last one folds "- thr" in, so the sign
-// bit of t = d2 - thr is the hit) and one v_alignbit that shifts the sign into the row's
-// 32-column word, w = (w << 1) | sign(t): the first column of a group ends up in bit 31.
+// 7 VALU per pair test: 3 sub, 3 fma (the last one folds "- thr" in, so the sign bit of
+// t = d2 - thr is the hit) and one v_alignbit that shifts the sign into the row's 32-column
+// word, w = (w << 1) | sign(t): the first column of a group ends up in bit 31.
 // (Packed v_pk_*_f32 forms were measured: they issue at half the rate, no gain.)
-// A wave owns 64*R rows (R per lane) and one contiguous part of the tile's columns; columns
-// come from LDS 4 at a time (ds_read_b128, the same address in every lane: broadcast), the
-// next two quads are fetched while the current two are tested.  Every STG_GROUPS groups the
-// wave transposes its words through a private LDS patch and writes them to the ROW-major
-// bitmap bits[row][word] as 16-byte row segments, so the extraction pass reads a row's words
-// with consecutive lanes and writes its candidate list coalesced.
-constexpr int STG_GROUPS = 4;
-constexpr int STG_STRIDE = 5;                                       // words per row in the patch (4 + 1 pad: conflict-free writes)
-constexpr int STG_WORDS_PER_WAVE = 4 * 64 * STG_STRIDE;             // up to 4 rows per lane
+// Columns come from the LDS tile 4 at a time (ds_read_b128, the same address in every lane:
+// broadcast); a lane carries SWEEP_R rows (consecutive 64-row blocks) so one read feeds
+// SWEEP_R tests.
+constexpr int SWEEP_R = 2;
 
-template <int R, int RPT>
-__device__ __forceinline__ void sweep_part(const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ lz,
-                                           int ngroups /* multiple of STG_GROUPS */, int word_base, const float (&x)[RPT][3],
-                                           const int (&row0)[RPT] /* local row of lane 0, per r */, int nrows, int (&cnt)[RPT],
-                                           gu32* __restrict__ bits, int nwords_pad, volatile uint32_t* stg, float thr, int lane) {
-    const float4* qx = reinterpret_cast<const float4*>(lx);
-    const float4* qy = reinterpret_cast<const float4*>(ly);
-    const float4* qz = reinterpret_cast<const float4*>(lz);
-    const float nthr = -thr;
-    const int nq2 = ngroups * 4;                                    // pairs of quads
-    float4 X0 = qx[0], Y0 = qy[0], Z0 = qz[0], X1 = qx[1], Y1 = qy[1], Z1 = qz[1];
-    uint32_t w[R];
+__device__ __forceinline__ void sweep_group(const float* lx, const float* ly, const float* lz, int c0 /* wave-uniform */,
+                                            const float (&x)[SWEEP_R][3], float nthr, uint32_t (&w)[SWEEP_R]) {
+    const float4* qx = reinterpret_cast<const float4*>(lx + c0);
+    const float4* qy = reinterpret_cast<const float4*>(ly + c0);
+    const float4* qz = reinterpret_cast<const float4*>(lz + c0);
 #pragma unroll
-    for (int r = 0; r < R; ++r) w[r] = 0u;
-#pragma unroll 1
-    for (int p = 0; p < nq2; ++p) {
-        const int pn = (p + 1 < nq2) ? p + 1 : p;
-        const float4 nX0 = qx[2 * pn], nY0 = qy[2 * pn], nZ0 = qz[2 * pn], nX1 = qx[2 * pn + 1], nY1 = qy[2 * pn + 1], nZ1 = qz[2 * pn + 1];
-        const float cx[8] = {X0.x, X0.y, X0.z, X0.w, X1.x, X1.y, X1.z, X1.w};
-        const float cy[8] = {Y0.x, Y0.y, Y0.z, Y0.w, Y1.x, Y1.y, Y1.z, Y1.w};
-        const float cz[8] = {Z0.x, Z0.y, Z0.z, Z0.w, Z1.x, Z1.y, Z1.z, Z1.w};
+    for (int r = 0; r < SWEEP_R; ++r) w[r] = 0u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+    for (int q = 0; q < 8; ++q) {
+        const float4 X = qx[q], Y = qy[q], Z = qz[q];
+        const float cx[4] = {X.x, X.y, X.z, X.w}, cy[4] = {Y.x, Y.y, Y.z, Y.w}, cz[4] = {Z.x, Z.y, Z.z, Z.w};
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int r = 0; r < SWEEP_R; ++r) {
                 const float dx = x[r][0] - cx[u], dy = x[r][1] - cy[u], dz = x[r][2] - cz[u];
                 const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nthr)));
                 w[r] = __builtin_amdgcn_alignbit(w[r], __float_as_uint(t), 31);
             }
         }
-        if ((p & 3) == 3) {                                         // 32 columns done: park the group's words
-            const int grp = p >> 2;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                stg[(r * 64 + lane) * STG_STRIDE + (grp & (STG_GROUPS - 1))] = w[r];
-                cnt[r] += __popc(w[r]);
-                w[r] = 0u;
-            }
-            if ((grp & (STG_GROUPS - 1)) == STG_GROUPS - 1) {       // patch full: lanes (4 per row) write 16-byte row segments
-                const int word0 = word_base + grp - (STG_GROUPS - 1);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        const int rl = (lane >> 2) + 16 * k4, wd = lane & 3;
-                        const uint32_t v = stg[(r * 64 + rl) * STG_STRIDE + wd];
-                        const int li = row0[r] + rl;
-                        if (li < nrows) bits[(size_t)li * nwords_pad + word0 + wd] = v;
-                    }
-                }
-            }
-        }
-        X0 = nX0; Y0 = nY0; Z0 = nZ0; X1 = nX1; Y1 = nY1; Z1 = nZ1;
     }
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
 }
 
 // ---------------------------------------------------------------- the kernel, phase by phase
@@ -399,16 +389,18 @@ template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
 }
 
 struct Lds {
-    Shared* sh; int* rowoff; float* lx; float* ly; float* lz; volatile uint32_t* stg_all; float4* ylds;
+    Shared* sh; int* rowlen; float* gbox; float* lx; float* ly; float* lz; float4* ylds;
 };
+// Shared | candidate-list length per local row | bounding boxes of the tile's 32-column groups (6 planes) |
+// cull tile, SoA | resident transformed moving cloud (optional)
 __device__ __forceinline__ Lds lds_layout(int tile) {
     Lds L;
     L.sh = reinterpret_cast<Shared*>(cvo_smem);
-    L.rowoff = reinterpret_cast<int*>(cvo_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
-    L.lx = reinterpret_cast<float*>(L.rowoff + (MAX_ROWS_PER_WG + 64));
+    L.rowlen = reinterpret_cast<int*>(cvo_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
+    L.gbox = reinterpret_cast<float*>(L.rowlen + (MAX_ROWS_PER_WG + 64));
+    L.lx = L.gbox + 6 * (tile >> 5);
     L.ly = L.lx + tile; L.lz = L.ly + tile;
-    L.stg_all = reinterpret_cast<volatile uint32_t*>(L.lz + tile);
-    L.ylds = reinterpret_cast<float4*>(const_cast<uint32_t*>(L.stg_all) + MAX_WAVES * STG_WORDS_PER_WAVE);
+    L.ylds = reinterpret_cast<float4*>(L.lz + tile);
     return L;
 }
 
@@ -416,26 +408,22 @@ __device__ __forceinline__ Lds lds_layout(int tile) {
 // near surfaces have many more neighbours per row than far ones, bands of rows would be unbalanced
 struct Ctx {
     const gfloat* fixed; const gfloat* moving;
-    int nf, nm, nrows, rows_per, rows_pad, ngroups_all, nwords_pad, capn, nm_pad, flat_cap, g, G;
+    int nf, nm, nrows, rows_per, rows_pad, capn, nm_pad, flat_cap, g, G;
     GF4 ybuf, ybuild, surv0, surv1;
-    gu32* bits; gint* cnt0; gint* cnt1; gu32* flat_ij; gu16* jT; gfloat* ckT; gfloat* dcT; gu64* xch;
+    gu16* jT; gfloat* ckT; gfloat* dcT; gu64* xch;
     size_t fbase;
 };
 __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     const PairDesc& D = *Dp;
     Ctx c;
     c.g = g; c.G = G;
-    c.nf = D.nf; c.nm = D.nm; c.nm_pad = D.nm_pad; c.rows_pad = D.rows_pad; c.nwords_pad = D.nwords_pad; c.capn = D.capn;
+    c.nf = D.nf; c.nm = D.nm; c.nm_pad = D.nm_pad; c.rows_pad = D.rows_pad; c.capn = D.capn;
     c.rows_per = (c.nf + G - 1) / G;
     c.nrows = (g < c.nf) ? (c.nf - g + G - 1) / G : 0;
-    c.ngroups_all = (c.nm + 31) >> 5;
     c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
     c.ybuf = GF4{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
     c.ybuild = GF4{(gv4f*)D.ybuild + (size_t)g * D.nm_pad};
     c.surv0 = GF4{(gv4f*)D.surv0}; c.surv1 = GF4{(gv4f*)D.surv1};
-    c.bits = (gu32*)D.bits + (size_t)g * D.rows_pad * D.nwords_pad;
-    c.cnt0 = (gint*)D.cnt; c.cnt1 = c.cnt0 + D.nf_pad;
-    c.flat_ij = (gu32*)D.flat_ij;
     c.jT = (gu16*)D.jT + (size_t)g * D.capn * D.rows_pad;
     c.ckT = (gfloat*)D.ckT + (size_t)g * D.capn * D.rows_pad;
     c.dcT = (gfloat*)D.dcT + (size_t)g * D.capn * D.rows_pad;
@@ -487,157 +475,125 @@ __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, in
     __syncthreads();
 }
 
-// ---- S: dense cull into the row-major hit bitmap + per-row hit counts
-template <int RPT>
+// ---- S: dense cull straight into the transposed candidate lists.
+// A wave owns pairs of consecutive 64-row blocks (a lane = one row of each) and walks ALL columns for them, so a row's
+// hits are found in ascending column order (= the CSR order of Eigen::setFromTriplets, cvo.cpp:182) and can be appended to
+// the row's list jT[n][row] on the spot: no bitmap, no scan, no second pass.  Only 32-column groups whose bounding box
+// comes within the cull radius of the wave's rows' bounding box are tested at all (one lane per group decides, a ballot
+// turns the decisions into a scalar mask the wave then iterates).
 __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh;
-    const Ctx c = make_ctx(Dp, g, G);
-    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
-    const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
-    const float Rb = r_c * (1.0f + sh->P.skin);
-    const float thr_cull = Rb * Rb * 1.00001f;
-    // waves form a RGN x CPN grid: RGN groups of 64*RPT rows, CPN column parts of every tile, so
-    // that all waves carry the same number of pair tests (two per SIMD, none left alone)
-    const int CPN = (nwaves >= 8) ? 2 : 1, RGN = nwaves / CPN;
-    const int rg = wave % RGN, cp = wave / RGN;
-    volatile uint32_t* stg = L.stg_all + wave * STG_WORDS_PER_WAVE;
-    gint* cnt_part = cp ? c.cnt1 : c.cnt0;
-    for (int rb = 0; rb < c.nrows; rb += RPT * RGN * 64) {
-        float x[RPT][3]; int row0[RPT]; int cnt[RPT];
-        int nv = 0;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            row0[r] = rb + r * (RGN * 64) + rg * 64;
-            const int li = row0[r] + lane;
-            cnt[r] = 0;
-            if (li < c.nrows) {
-                const float4 lo = ld4(c.fixed + (size_t)(g + G * li) * REC);
-                x[r][0] = lo.x; x[r][1] = lo.y; x[r][2] = lo.z;
-            } else {
-                x[r][0] = x[r][1] = x[r][2] = FAR_ROW;
-            }
-            if (row0[r] < c.nrows) nv = r + 1;                      // rows are a prefix per wave: skip the all-padding ones
-        }
-        for (int t0 = 0; t0 < c.nm; t0 += tile) {
-            const int tn = min(tile, c.nm - t0);
-            const int gran = 32 * STG_GROUPS * CPN;                 // every column part is a whole number of flush granules
-            const int tnp = (tn + gran - 1) / gran * gran;
-            __syncthreads();                                        // previous tile fully consumed
-            for (int jj = tid; jj < tnp; jj += nthreads) {
-                float4 y = make_float4(FAR_COL, FAR_COL, FAR_COL, 0.f);
-                if (jj < tn) { y = c.ybuf[t0 + jj]; if (rb == 0) c.ybuild.set(t0 + jj, y); }
-                L.lx[jj] = y.x; L.ly[jj] = y.y; L.lz[jj] = y.z;
-            }
-            __syncthreads();
-            const int ngp = (tnp >> 5) / CPN;                       // groups in this wave's column part
-            const int c0 = cp * ngp * 32;                           // its first column inside the tile
-            const int wb = (t0 >> 5) + cp * ngp;                    // its first bitmap word
-            if (RPT >= 4 && nv == 4) sweep_part<(RPT >= 4 ? 4 : 1), RPT>(L.lx + c0, L.ly + c0, L.lz + c0, ngp, wb, x, row0, c.nrows, cnt, c.bits, c.nwords_pad, stg, thr_cull, lane);
-            else if (RPT >= 3 && nv == 3) sweep_part<(RPT >= 3 ? 3 : 1), RPT>(L.lx + c0, L.ly + c0, L.lz + c0, ngp, wb, x, row0, c.nrows, cnt, c.bits, c.nwords_pad, stg, thr_cull, lane);
-            else if (RPT >= 2 && nv == 2) sweep_part<(RPT >= 2 ? 2 : 1), RPT>(L.lx + c0, L.ly + c0, L.lz + c0, ngp, wb, x, row0, c.nrows, cnt, c.bits, c.nwords_pad, stg, thr_cull, lane);
-            else if (nv >= 1) sweep_part<1, RPT>(L.lx + c0, L.ly + c0, L.lz + c0, ngp, wb, x, row0, c.nrows, cnt, c.bits, c.nwords_pad, stg, thr_cull, lane);
-        }
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) { const int li = row0[r] + lane; if (li < c.nrows) cnt_part[g + G * li] = cnt[r]; }
-    }
-    if (tid == 0) sh->Rb = Rb;
-    __syncthreads();                                                // counts, bitmap visible to the whole workgroup
-}
-
-// ---- X: row offsets (exclusive scan of the counts), the set bits become row-major lists, which are transposed
-// into jT[n][row] for the candidate phase
-__device__ __noinline__ void phase_lists(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh; int* rowoff = L.rowoff;
+    const Lds L = lds_layout(tile); Shared* sh = L.sh; int* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
-    const int CPN = (nwaves >= 8) ? 2 : 1;
-    const int rps = (nrows + nthreads - 1) / nthreads;
-    const int l0 = min(nrows, tid * rps), l1 = min(nrows, l0 + rps);
-    int mine = 0;
-    for (int li = l0; li < l1; ++li) mine += c.cnt0[g + G * li] + (CPN > 1 ? c.cnt1[g + G * li] : 0);
-    int total = 0;
-    int run = block_exclusive_scan(mine, sh, tid, nwaves, total);
-    for (int li = l0; li < l1; ++li) { rowoff[li] = run; run += c.cnt0[g + G * li] + (CPN > 1 ? c.cnt1[g + G * li] : 0); }
-    if (tid == 0) rowoff[nrows] = total;
-    const int dense = (total > c.flat_cap) ? 1 : 0;                 // lists too small: dense per-row fallback until the next rebuild
-    __syncthreads();
-    if (!dense) {
-        // a wave takes four rows per trip (their bitmap words are loaded together); lanes = consecutive
-        // words of a row, an in-wave prefix sum of the popcounts places every lane's hits, so the
-        // packed (row << 16 | column) entries of a row leave the wave as one contiguous run
-        const int nwords = c.ngroups_all;
-        for (int li0 = wave * 4; li0 < nrows; li0 += nwaves * 4) {
-            size_t o[4];
+    const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
+    const float Rb = r_c * (1.0f + sh->P.skin);
+    const float thr_cull = Rb * Rb * 1.00001f;
+    const float thr_box = thr_cull * 1.001f;                        // box gaps are compared with a margin: a skipped group holds no hit
+    const float nthr = -thr_cull;
+    const int gplane = tile >> 5;                                   // stride of the six bounding-box planes
+    const int nblk2 = (nrows + 64 * SWEEP_R - 1) / (64 * SWEEP_R);  // row-block pairs of this workgroup
+    const float INF = __builtin_inff();
+    for (int t0 = 0; t0 < c.nm; t0 += tile) {
+        const int tn = min(tile, c.nm - t0);
+        const int tnp = (tn + 31) & ~31;
+        __syncthreads();                                            // previous tile fully consumed
+        for (int jj = tid; jj < tnp; jj += nthreads) {              // a wave's half = one 32-column group
+            float4 y = make_float4(FAR_COL, FAR_COL, FAR_COL, 0.f);
+            float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+            if (jj < tn) {
+                y = c.ybuf[t0 + jj]; c.ybuild.set(t0 + jj, y);
+                lo[0] = hi[0] = y.x; lo[1] = hi[1] = y.y; lo[2] = hi[2] = y.z;
+            }
+            L.lx[jj] = y.x; L.ly[jj] = y.y; L.lz[jj] = y.z;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) o[u] = c.fbase + rowoff[min(li0 + u, nrows)];
-            for (int wb0 = 0; wb0 < nwords; wb0 += 64) {
-                uint32_t wv[4];
+            for (int off = 16; off > 0; off >>= 1) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    wv[u] = (li0 + u < nrows && wb0 + lane < nwords) ? c.bits[(size_t)(li0 + u) * c.nwords_pad + wb0 + lane] : 0u;
+                for (int q = 0; q < 3; ++q) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], off, 64)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], off, 64)); }
+            }
+            if ((lane & 31) == 0) {
+                const int gi = jj >> 5;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    uint32_t w = wv[u];
-                    const int cw = __popc(w);
-                    int inc = cw;
+                for (int q = 0; q < 3; ++q) { L.gbox[q * gplane + gi] = lo[q]; L.gbox[(3 + q) * gplane + gi] = hi[q]; }
+            }
+        }
+        __syncthreads();
+        const int ngr = tnp >> 5;
+        for (int b2 = wave; b2 < nblk2; b2 += nwaves) {
+            float x[SWEEP_R][3]; int li[SWEEP_R]; int cnt[SWEEP_R];
+            float blo[3] = {INF, INF, INF}, bhi[3] = {-INF, -INF, -INF};
 #pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
-                    const int tot = __shfl(inc, 63, 64);
-                    size_t pos = o[u] + (size_t)(inc - cw);
-                    const uint32_t tag = ((uint32_t)(li0 + u) << 16) | (uint32_t)((wb0 + lane) * 32);
-                    while (w) {                                     // bit 31 = first column of the group: ascending columns
-                        const int kbit = __clz(w);
-                        c.flat_ij[pos++] = tag + (uint32_t)kbit;
-                        w &= ~(0x80000000u >> kbit);
+            for (int r = 0; r < SWEEP_R; ++r) {
+                li[r] = (b2 * SWEEP_R + r) * 64 + lane;
+                if (li[r] < nrows) {
+                    const float4 lo4 = ld4(c.fixed + (size_t)(g + G * li[r]) * REC);
+                    x[r][0] = lo4.x; x[r][1] = lo4.y; x[r][2] = lo4.z;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { blo[q] = fminf(blo[q], x[r][q]); bhi[q] = fmaxf(bhi[q], x[r][q]); }
+                } else {
+                    x[r][0] = x[r][1] = x[r][2] = FAR_ROW;
+                }
+                cnt[r] = (t0 == 0) ? 0 : rowlen[li[r]];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { blo[q] = wave_min(blo[q]); bhi[q] = wave_max(bhi[q]); }
+            for (int gb = 0; gb < ngr; gb += 64) {
+                bool near = false;
+                if (gb + lane < ngr) {
+                    float gap2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const float glo = L.gbox[q * gplane + gb + lane], ghi = L.gbox[(3 + q) * gplane + gb + lane];
+                        const float d = fmaxf(0.f, fmaxf(glo - bhi[q], blo[q] - ghi));
+                        gap2 = __builtin_fmaf(d, d, gap2);
                     }
-                    o[u] += tot;
+                    near = gap2 <= thr_box;                         // false for NaN (inf - inf of an all-padding group): skipped
+                }
+                unsigned long long mask = __ballot(near);
+                while (mask) {
+                    const int gi = gb + __builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    uint32_t w[SWEEP_R];
+                    sweep_group(L.lx, L.ly, L.lz, gi * 32, x, nthr, w);
+                    const uint32_t col0 = (uint32_t)(t0 + gi * 32);
+#pragma unroll
+                    for (int r = 0; r < SWEEP_R; ++r) {
+                        uint32_t ww = w[r];
+                        while (ww) {                                // bit 31 = first column of the group: ascending columns
+                            const int kbit = __clz(ww);
+                            if (cnt[r] < c.capn) c.jT[(size_t)cnt[r] * c.rows_pad + li[r]] = (uint16_t)(col0 + (uint32_t)kbit);
+                            ++cnt[r];
+                            ww &= ~(0x80000000u >> kbit);
+                        }
+                    }
                 }
             }
+#pragma unroll
+            for (int r = 0; r < SWEEP_R; ++r) rowlen[li[r]] = cnt[r];   // rowlen has room for the padding rows of the last block pair
         }
     }
-    __syncthreads();                                                // flat_ij complete
-    // transpose through a per-wave LDS patch (64 rows x 16 entries): reads are 64-byte row segments, writes are
-    // 128-byte runs over 64 consecutive rows.  A wave owns the 64-row blocks wave, wave+nwaves, ... -- the rows it
-    // walks in the candidate phase.
+    __syncthreads();
+    // every wave's share of the lists as walked by the candidate phase (64-row blocks wave, wave + nwaves, ...)
     int my_tot = 0, my_lmax = 0;
-    if (!dense) {
-        volatile uint32_t* patch = L.stg_all + wave * STG_WORDS_PER_WAVE;      // 64 x 17 words
-        for (int lb = wave * 64; lb < nrows; lb += nwaves * 64) {
-            const int li = lb + lane;
-            const int len = (li < nrows) ? rowoff[li + 1] - rowoff[li] : 0;
-            int lmaxb = len, ltot = len;
+    for (int lb = wave * 64; lb < nrows; lb += nwaves * 64) {
+        const int len = (lb + lane < nrows) ? rowlen[lb + lane] : 0;
+        int lmaxb = len, ltot = len;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { lmaxb = max(lmaxb, __shfl_xor(lmaxb, off, 64)); ltot += __shfl_xor(ltot, off, 64); }
-            my_tot += ltot; my_lmax = max(my_lmax, lmaxb);
-            for (int n0 = 0; n0 < min(lmaxb, c.capn); n0 += 16) {
-#pragma unroll
-                for (int k16 = 0; k16 < 16; ++k16) {
-                    const int r = (lane >> 4) + 4 * k16, e = lane & 15;
-                    const int lr = lb + r;
-                    uint32_t v = 0u;
-                    if (lr < nrows) { const int o = rowoff[lr]; if (n0 + e < rowoff[lr + 1] - o) v = c.flat_ij[c.fbase + o + n0 + e]; }
-                    patch[r * 17 + e] = v;
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t v = patch[lane * 17 + e];
-                    if (n0 + e < len && n0 + e < c.capn) c.jT[(size_t)(n0 + e) * c.rows_pad + li] = (uint16_t)(v & 0xFFFFu);
-                }
-            }
-        }
+        for (int off = 32; off > 0; off >>= 1) { lmaxb = max(lmaxb, __shfl_xor(lmaxb, off, 64)); ltot += __shfl_xor(ltot, off, 64); }
+        my_tot += ltot; my_lmax = max(my_lmax, lmaxb);
     }
     if (lane == 0) { sh->wtot[wave] = my_tot; sh->wsum[wave] = my_lmax; }
     __syncthreads();
     if (tid == 0) {
         int lmax_all = 0, run_w = 0;
         for (int w = 0; w < nwaves; ++w) { lmax_all = max(lmax_all, sh->wsum[w]); sh->wbase[w] = run_w; run_w += sh->wtot[w]; }
-        const int dense2 = dense | (lmax_all > c.capn ? 1 : 0);     // a row longer than the transposed lists hold
-        sh->ell_build = sh->ell; sh->list_valid = 1;
-        sh->dense_mode = dense2; sh->total = total; sh->lmax = lmax_all;
-        sh->rebuilds += 1; sh->dense_fallbacks += dense2 ? 1 : 0;
+        // candidates beyond what the survivor planes hold, or a row longer than the transposed lists: dense per-row
+        // fallback until the next rebuild
+        const int dense = ((run_w > c.flat_cap) || (lmax_all > c.capn)) ? 1 : 0;
+        sh->Rb = Rb; sh->ell_build = sh->ell; sh->list_valid = 1;
+        sh->dense_mode = dense; sh->total = run_w; sh->lmax = lmax_all;
+        sh->rebuilds += 1; sh->dense_fallbacks += dense;
     }
     __syncthreads();
 }
@@ -645,7 +601,7 @@ __device__ __noinline__ void phase_lists(const PairDesc* Dp_in, int g_in, int G_
 // ---- C: exact kernel values + compute_flow row sums (cvo.cpp:202-231), reduced over the workgroup and the pair's workgroups
 __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh; const int* rowoff = L.rowoff;
+    const Lds L = lds_layout(tile); Shared* sh = L.sh; const int* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
@@ -665,7 +621,7 @@ __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, i
         for (int lb = wave * 64; lb < nrows; lb += nwaves * 64) {
             const int li = lb + lane;
             const bool rowok = li < nrows;
-            const int len = rowok ? rowoff[li + 1] - rowoff[li] : 0;
+            const int len = rowok ? rowlen[li] : 0;
             int lw = len;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
@@ -697,34 +653,42 @@ __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, i
                 // the PF entries are independent until their results are added to the row sums: evaluate them side by
                 // side (four exp / gate chains in flight per lane), then fold them in column order
                 float av[PF]; float4 yv4[PF];
+                if (!fresh_list && gates.poly_ok) {
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int n = n0 + u;
-                    const int j = jq[u]; float ck = ckq[u], d2c = dcq[u];
-                    av[u] = 0.f; yv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (n < len) {
-                        const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
-                        yv4[u] = yj;
-                        if (fresh_list) {
-                            // colour gate and factor (cvo.cpp:169-173) depend on the two points only: done by the first pass
-                            // over a new list and kept.  A pair that fails the gate gets d2c = +inf, ck = 0: the pre-test in
-                            // se_kernel_value_pre then rejects it for good.
-                            const float4 gh = ld4(c.moving + (size_t)j * REC + 4);
-                            const float fb[5] = {yj.w, gh.x, gh.y, gh.z, gh.w};
-                            d2c = feat_d2(fi, fb);
-                            if (d2c < gates.d2c_thres && !(d2c * gates.q_ic > gates.q_lim))
-                                ck = (float)((double)gates.csig2 * exp_small((double)(-d2c) * gates.inv_den_c));
-                            else { ck = 0.f; d2c = __builtin_inff(); }
-                            const size_t cur = (size_t)n * c.rows_pad + li;
-                            c.ckT[cur] = ck; c.dcT[cur] = d2c;
+                    for (int u = 0; u < PF; ++u) {
+                        yv4[u] = y_lds ? L.ylds[jq[u]] : c.ybuf[jq[u]];   // entries past the row's end carry j = 0
+                        av[u] = se_kernel_value_flat(xi, yv4[u], ckq[u], dcq[u], n0 + u < len, gates);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        const int n = n0 + u;
+                        const int j = jq[u]; float ck = ckq[u], d2c = dcq[u];
+                        av[u] = 0.f; yv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (n < len) {
+                            const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
+                            yv4[u] = yj;
+                            if (fresh_list) {
+                                // colour gate and factor (cvo.cpp:169-173) depend on the two points only: done by the first pass
+                                // over a new list and kept.  A pair that fails the gate gets d2c = +inf, ck = 0: the pre-test in
+                                // se_kernel_value_pre then rejects it for good.
+                                const float4 gh = ld4(c.moving + (size_t)j * REC + 4);
+                                const float fb[5] = {yj.w, gh.x, gh.y, gh.z, gh.w};
+                                d2c = feat_d2(fi, fb);
+                                if (d2c < gates.d2c_thres && !(d2c * gates.q_ic > gates.q_lim))
+                                    ck = (float)((double)gates.csig2 * exp_small((double)(-d2c) * gates.inv_den_c));
+                                else { ck = 0.f; d2c = __builtin_inff(); }
+                                const size_t cur = (size_t)n * c.rows_pad + li;
+                                c.ckT[cur] = ck; c.dcT[cur] = d2c;
+                            }
+                            av[u] = se_kernel_value_pre(xi, yj, ck, d2c, gates);
                         }
-                        av[u] = se_kernel_value_pre(xi, yj, ck, d2c, gates);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const float a = av[u];
-                    if (a > 0.f) {
+                    {   // a == 0 for a non-member: it adds exact zeros, the sums keep their bits
                         const float yv[3] = {yv4[u].x, yv4[u].y, yv4[u].z};
                         float cr[3]; cross3(xi, yv, cr);            // cvo.cpp:216
                         sw[0] += a * cr[0]; sw[1] += a * cr[1]; sw[2] += a * cr[2];
@@ -767,7 +731,7 @@ __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, i
 #pragma unroll
             for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }
             acc8[6] += (double)nz;
-            acc8[7] += (double)(c.cnt0[i] + (nwaves >= 8 ? c.cnt1[i] : 0));
+            acc8[7] += (double)rowlen[li];
         }
     }
     __syncthreads();
@@ -877,7 +841,6 @@ __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int
     __syncthreads();
 }
 
-template <int RPT>
 __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, DevParams P) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
@@ -904,6 +867,9 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
         long long cand_total = 0;
         unsigned long long ticks[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+#ifdef CVO_KTRACE
+        unsigned long long kt_prev[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
         const unsigned long long clk_t0 = t_prev, clk_c0 = __builtin_amdgcn_s_memtime();
 #define CVO_PHASE(idx) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); ticks[idx] += t_now - t_prev; t_prev = t_now; } while (0)
         const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
@@ -913,11 +879,8 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
             phase_transform(Dp, g, G, tile, y_lds);
             if (sh->rebuild) {
                 const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
-                phase_cull<RPT>(Dp, g, G, tile);
-                const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
-                phase_lists(Dp, g, G, tile);
-                const unsigned long long t_c = __builtin_amdgcn_s_memrealtime();
-                ticks[6] += t_b - t_a; ticks[8] += t_c - t_b;
+                phase_cull(Dp, g, G, tile);
+                ticks[6] += __builtin_amdgcn_s_memrealtime() - t_a;
             }
             CVO_PHASE(0);
             phase_candidates(Dp, g, G, tile, y_lds, k);
@@ -929,6 +892,13 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
             if (sh->status != 0) break;
             phase_epilogue(Dp, g, tile, k);
             CVO_PHASE(5);
+#ifdef CVO_KTRACE   // experiment builds only: the trace row's B..E carry this iteration's phase times (100 MHz ticks) instead
+            if (tid == 0 && g == 0 && Dp->trace && k < Dp->trace_cap) {
+                TraceRow& tr = Dp->trace[k];
+                tr.B = (double)(ticks[0] - kt_prev[0]); tr.C = (double)(ticks[1] - kt_prev[1]); tr.D = (double)(ticks[3] - kt_prev[3]); tr.E = (double)(ticks[5] - kt_prev[5]);
+                for (int q = 0; q < 10; ++q) kt_prev[q] = ticks[q];
+            }
+#endif
             if (sh->stop) { ++k; break; }
         }
 
@@ -956,11 +926,6 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
     }
 }
 
-template __global__ void cvo_align_kernel<1>(const PairDesc*, int, int, int, int, DevParams);
-template __global__ void cvo_align_kernel<2>(const PairDesc*, int, int, int, int, DevParams);
-template __global__ void cvo_align_kernel<3>(const PairDesc*, int, int, int, int, DevParams);
-template __global__ void cvo_align_kernel<4>(const PairDesc*, int, int, int, int, DevParams);
-
 // 64-byte result record per pair for the cross-GPU gather: 12 floats of transform,
 // then iter, A_nonzero, iterations_run, status as floats (exact below 2^24).
 __global__ void cvo_pack_results_kernel(const PairState* __restrict__ st, float* __restrict__ out, int n) {
@@ -977,26 +942,19 @@ hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream
 
 int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
 
-// LDS: Shared | row offsets | cull tile (3*tile floats) | per-wave transpose patches | resident y cloud (16 B * nm_pad, optional)
+// LDS: Shared | list lengths | group boxes | cull tile (3*tile floats) | resident y cloud (16 B * nm_pad, optional)
 size_t align_shared_bytes(int tile, int y_points) {
-    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)(MAX_ROWS_PER_WG + 64) * sizeof(int) + (size_t)3 * tile * sizeof(float) +
-           (size_t)MAX_WAVES * STG_WORDS_PER_WAVE * sizeof(uint32_t) + (size_t)y_points * sizeof(float4);
+    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)(MAX_ROWS_PER_WG + 64) * sizeof(int) + (size_t)6 * (tile >> 5) * sizeof(float) +
+           (size_t)3 * tile * sizeof(float) + (size_t)y_points * sizeof(float4);
 }
-int align_tile_granule() { return 32 * STG_GROUPS * 2; }
+int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 
-hipError_t launch_align(int rpt, int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         const DevParams& P) {
     const size_t shmem = align_shared_bytes(tile, y_points);
-    void (*fn)(const PairDesc*, int, int, int, int, DevParams) = nullptr;
-    switch (rpt) {
-        case 1: fn = cvo_align_kernel<1>; break;
-        case 2: fn = cvo_align_kernel<2>; break;
-        case 3: fn = cvo_align_kernel<3>; break;
-        default: fn = cvo_align_kernel<4>; break;
-    }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cvo_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_points > 0 ? 1 : 0, P);
+    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_points > 0 ? 1 : 0, P);
     return hipGetLastError();
 }
 

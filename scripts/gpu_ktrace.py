@@ -1,0 +1,21 @@
+"""Experiment (needs a build with EXTRA=-DCVO_KTRACE): per-iteration phase times of one pair."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+import cvo_slam_amd as ca
+idx = int(os.environ.get("PAIR", "0"))
+(_, fx, ff, mx, mf), = bench.generate_pairs(idx, 1)
+h = ca.Cvo()
+for rep in range(2):
+    h = ca.Cvo()
+    h.set_pcd(fx, ff); h.set_pcd(mx, mf)
+    out = h.align(trace_cap=128)
+rows = out
+print("k ell cand nnz | cull cand ls epi (us)")
+tot = np.zeros(4)
+for k, r in enumerate(rows):
+    t = r["BCDE"] / 100.0; tot += t
+    print(k, round(float(r["ell"]), 2), r["candidates"], r["nnz"], "|", *(round(float(x), 1) for x in t))
+print("totals us", tot.round(0), "sum", tot.sum().round(0))
