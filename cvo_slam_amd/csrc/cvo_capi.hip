@@ -25,7 +25,7 @@ size_t align_shared_bytes(int tile, int y_points);
 int align_tile_granule();
 int align_blocks_per_cu();
 hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
-                        const DevParams& P);
+                        unsigned launch_tag, const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 int score_grid(int na);
 int score_nout();
@@ -108,11 +108,15 @@ struct Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
     DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_jT, d_ckT, d_dcT, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
-    PinBuf h_descs, h_states, h_stage, h_partials;
+    PinBuf h_descs, h_states, h_states_in, h_stage, h_partials;   // h_states: final states, written by the kernel itself (mapped pinned memory)
+    std::vector<unsigned char> descs_uploaded;                     // what d_descs holds: unchanged descriptors are not sent again
+    unsigned launch_seq = 0;
+    size_t xch_zeroed_bytes = 0;
     int wg_request = 0;          // 0 = auto
     int tile_request = 0;        // 0 = auto
     int capf_request = 0;        // flat capacity per row (0 = auto)
     int block_request = 0;       // threads per workgroup (0 = auto)
+    int per_cu = 1;              // workgroups resident per CU: 1 x 512 threads, or 2 x 256 threads (half the LDS each)
     float last_ms = 0.f;
     bool launched = false;
 
@@ -125,6 +129,7 @@ struct Engine {
         P = to_dev(prm);
         if (const char* e = std::getenv("CVO_HIP_FLAT_CAP")) capf_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_BLOCK")) block_request = std::atoi(e);
+        if (const char* e = std::getenv("CVO_HIP_WGS_PER_CU")) per_cu = std::max(1, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_SKIN")) P.skin = (float)std::atof(e);
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
@@ -134,7 +139,7 @@ struct Engine {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_jT, &d_ckT, &d_dcT, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
-        for (PinBuf* b : {&h_descs, &h_states, &h_stage, &h_partials}) b->release();
+        for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -168,7 +173,7 @@ struct Engine {
 
     int pick_workgroups(int n_pairs, int nf_max) const {
         int G = wg_request;
-        if (G <= 0) { G = 1; while (G * 2 * n_pairs <= num_cus * align_blocks_per_cu() && G < 32) G *= 2; }
+        if (G <= 0) { G = 1; while (G * 2 * n_pairs <= num_cus * per_cu && G < 32) G *= 2; }
         const int g_min = (nf_max + MAX_ROWS_PER_WG - 1) / MAX_ROWS_PER_WG;     // a workgroup owns at most MAX_ROWS_PER_WG rows
         G = std::max(std::max(1, g_min), std::min(G, num_cus));
         return G;
@@ -185,15 +190,23 @@ struct Engine {
         int nf_max = 0, nm_max = 0;
         for (const PairIn& p : pairs) { nf_max = std::max(nf_max, p.fixed ? p.fixed->n : 0); nm_max = std::max(nm_max, p.moving ? p.moving->n : 0); }
         const int G = pick_workgroups(n, nf_max);
-        const int slots = std::max(1, std::min(n, num_cus * align_blocks_per_cu() / G));   // every workgroup of the grid must be resident
+        const int slots = std::max(1, std::min(n, num_cus * per_cu / G));   // every workgroup of the grid must be resident
         const int grid = slots * G;
         const int nf_pad = round_up(std::max(nf_max, 1), 64), nm_pad = round_up(std::max(nm_max, 1), 64);
         int capf = capf_request;
         if (capf <= 0) capf = std::max(96, nm_max / 12);                                 // flat lists, average per row
         const int tgran = align_tile_granule();
+        // LDS budget of one workgroup; the resident moving cloud (16 B/point) has priority over a long cull tile
+        const size_t lds_cap = (size_t)(160 / per_cu - 4) * 1024;
         int tile = tile_request > 0 ? round_up(tile_request, tgran) : std::min(round_up(std::max(nm_max, tgran), tgran), 4096);
+        if (tile_request <= 0) {
+            while (tile > 512 && align_shared_bytes(tile, nm_pad) > lds_cap) tile -= tgran;
+            if (align_shared_bytes(tile, nm_pad) > lds_cap) tile = std::min(round_up(std::max(nm_max, tgran), tgran), 2048);   // cloud stays in HBM/L2
+            while (tile > tgran && align_shared_bytes(tile, 0) > lds_cap) tile -= tgran;
+        }
         const int rows_per = (nf_max + G - 1) / G;
         int block = rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64));
+        if (per_cu > 1) block = std::min(block, 256);
         if (block_request > 0) block = std::max(64, std::min(512, round_up(block_request, 64)));
 
         int rc;
@@ -201,6 +214,8 @@ struct Engine {
         if ((rc = h_descs.ensure(sizeof(PairDesc) * n))) return rc;
         if ((rc = d_states.ensure(sizeof(PairState) * n))) return rc;
         if ((rc = h_states.ensure(sizeof(PairState) * n))) return rc;
+        if ((rc = h_states_in.ensure(sizeof(PairState) * n))) return rc;
+        if (2 * (long long)P.max_iter + 2 >= 65536) return fail(CVO_ERR_INVALID, "max_iter must be below 32767");
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
         const size_t plane = (size_t)(nf_pad + G) * capf;
         const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
@@ -220,7 +235,9 @@ struct Engine {
             if ((rc = d_tracelen.ensure(sizeof(int) * 4))) return rc;
             HIP_TRY(hipMemsetAsync(d_tracelen.p, 0, sizeof(int) * 4, s));
         }
-        PairDesc* hd = static_cast<PairDesc*>(h_descs.p);
+        std::vector<PairDesc> hdv(n);
+        std::memset(hdv.data(), 0, sizeof(PairDesc) * n);            // padding bytes take part in the comparison below
+        PairDesc* hd = hdv.data();
         for (int i = 0; i < n; ++i) {
             PairDesc& D = hd[i];
             D.fixed = pairs[i].fixed ? pairs[i].fixed->rec() : nullptr;
@@ -238,24 +255,38 @@ struct Engine {
             D.surv1 = static_cast<float4*>(d_surv1.p) + (size_t)i * plane;
             D.xch = static_cast<unsigned long long*>(d_xch.p) + (size_t)i * 2 * G * XCH_WORDS;
             D.state = static_cast<PairState*>(d_states.p) + i;
+            D.state_in = upload_states ? static_cast<const PairState*>(h_states_in.p) + i : D.state;
+            D.state_host = static_cast<PairState*>(h_states.p) + i;
             D.trace = (want_trace && i == 0) ? static_cast<TraceRow*>(d_trace.p) : nullptr;
             D.trace_cap = want_trace ? trace_cap : 0;
             D.trace_len = want_trace ? static_cast<int*>(d_tracelen.p) : nullptr;
         }
-        HIP_TRY(hipMemcpyAsync(d_descs.p, hd, sizeof(PairDesc) * n, hipMemcpyHostToDevice, s));
-        if (upload_states) {
-            std::memcpy(h_states.p, states_in, sizeof(PairState) * n);
-            HIP_TRY(hipMemcpyAsync(d_states.p, h_states.p, sizeof(PairState) * n, hipMemcpyHostToDevice, s));
+        // Steady state = no copy-engine work at all: copies queued on different streams share the DMA engines and a copy behind
+        // another stream's running kernel would serialise the launches.  Descriptors go up only when they changed, start states
+        // are read by the kernel from pinned host memory, final states are written by it to pinned host memory, and the
+        // exchange area is cleared only when it is new (tags carry the launch number).
+        if (descs_uploaded.size() != sizeof(PairDesc) * n || std::memcmp(descs_uploaded.data(), hd, sizeof(PairDesc) * n) != 0) {
+            HIP_TRY(hipStreamSynchronize(s));                         // an earlier launch on this stream may still read d_descs / h_descs
+            std::memcpy(h_descs.p, hd, sizeof(PairDesc) * n);
+            HIP_TRY(hipMemcpyAsync(d_descs.p, h_descs.p, sizeof(PairDesc) * n, hipMemcpyHostToDevice, s));
+            descs_uploaded.assign(reinterpret_cast<const unsigned char*>(hd), reinterpret_cast<const unsigned char*>(hd) + sizeof(PairDesc) * n);
         }
-        if (G > 1) HIP_TRY(hipMemsetAsync(d_xch.p, 0, xch_bytes, s));
+        if (upload_states) {
+            if (launched) HIP_TRY(hipStreamSynchronize(last_stream));  // a queued launch of this engine may not have read its start states yet
+            std::memcpy(h_states_in.p, states_in, sizeof(PairState) * n);
+        }
+        launch_seq = (launch_seq + 1) & 0xFFFFu;
+        if (G > 1 && (xch_zeroed_bytes != d_xch.bytes || launch_seq == 0)) {
+            HIP_TRY(hipMemsetAsync(d_xch.p, 0, d_xch.bytes, s));
+            xch_zeroed_bytes = d_xch.bytes;
+        }
         HIP_TRY(hipEventRecord(ev0, s));
         // keep the transformed moving cloud resident in LDS (16 B per point) when it fits beside the rest
         int y_points = 0;
-        if (align_shared_bytes(tile, nm_pad) <= (size_t)156 * 1024 && !std::getenv("CVO_HIP_NO_YLDS")) y_points = nm_pad;
-        hipError_t e = launch_align(grid, block, tile, y_points, s, static_cast<const PairDesc*>(d_descs.p), n, G, P);
+        if (align_shared_bytes(tile, nm_pad) <= lds_cap && !std::getenv("CVO_HIP_NO_YLDS")) y_points = nm_pad;
+        hipError_t e = launch_align(grid, block, tile, y_points, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, P);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));
-        HIP_TRY(hipMemcpyAsync(h_states.p, d_states.p, sizeof(PairState) * n, hipMemcpyDeviceToHost, s));
         launched = true;
         last_stream = s;
         return CVO_OK;

@@ -72,7 +72,9 @@ struct PairDesc {
     float4* surv0;           // survivors compacted per wave chunk, in candidate order: {x_i, a}
     float4* surv1;           //                                                         {y_j, 0}
     unsigned long long* xch; // [2][G][XCH_WORDS]
-    PairState* state;
+    const PairState* state_in;   // start state: the device copy (carried from the last launch) or a pinned host buffer the caller filled
+    PairState* state;            // device copy of the final state
+    PairState* state_host;       // pinned host mirror the kernel writes the final state to (no copy engine between launches)
     TraceRow* trace;         // optional
     int trace_cap;
     int* trace_len;

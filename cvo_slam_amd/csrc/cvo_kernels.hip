@@ -71,6 +71,8 @@ struct __attribute__((aligned(16))) Shared {
     int rebuilds;
     int dense_fallbacks;
     int rebuild;           // this iteration rebuilds the candidate lists
+    unsigned launch_tag;   // high 16 bits of every exchange tag: this launch's sequence number (granules of earlier launches never match)
+    unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
     float omega[3];        // this iteration's twist (f32, cvo.cpp:234-235)
     float v[3];
     float dist;
@@ -435,7 +437,7 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
 
 // ---- T: transform_pcd (cvo.cpp:336-341) into ybuf (+ the LDS-resident copy); how far has any point moved since
 // the candidate lists were built (exact displacement of the very positions the tests use); rebuild decision.
-__device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
     const Lds L = lds_layout(tile); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
@@ -481,7 +483,7 @@ __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, in
 // the row's list jT[n][row] on the spot: no bitmap, no scan, no second pass.  Only 32-column groups whose bounding box
 // comes within the cull radius of the wave's rows' bounding box are tested at all (one lane per group decides, a ballot
 // turns the decisions into a scalar mask the wave then iterates).
-__device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
+static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
     const Lds L = lds_layout(tile); Shared* sh = L.sh; int* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
@@ -599,17 +601,19 @@ __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_i
 }
 
 // ---- C: exact kernel values + compute_flow row sums (cvo.cpp:202-231), reduced over the workgroup and the pair's workgroups
-__device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
+static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tile); Shared* sh = L.sh; const int* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
+    const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
     const Gates gates = make_gates(sh->ell, sh->P);
     const bool dense_mode = sh->dense_mode != 0, fresh_list = sh->rebuild != 0;
     const int total = sh->total;
     const float inv_c = 1 / sh->P.c, inv_d = 1 / sh->P.d;
     double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // omega[3], v[3], nnz, candidates
+    const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
     if (!dense_mode) {
         // one lane per ROW, walking the row's candidate list (transposed: the lanes of a wave read entry n of 64
         // consecutive rows as one coalesced run).  The point gather y_j comes from the LDS-resident cloud, x_i and the
@@ -734,21 +738,25 @@ __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, i
             acc8[7] += (double)rowlen[li];
         }
     }
+    const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     block_reduce<8>(acc8, sh, tid, nwaves);
+    const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
     if (G > 1) {
-        if (tid < 64) { if (!group_exchange<8>(sh, c.xch, G, g, 2u * (unsigned)k + 1u, lane)) sh->status = 6; }
+        if (tid < 64) { if (!group_exchange<8>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 1u), lane)) sh->status = 6; }
         __syncthreads();
     }
     if (tid == 0) {
         for (int q = 0; q < 3; ++q) { sh->omega[q] = (float)sh->vals[q]; sh->v[q] = (float)sh->vals[3 + q]; }   // cvo.cpp:234-235
         sh->nnz = (int)sh->vals[6]; sh->cand = (int)sh->vals[7];
+        const unsigned long long ts4 = __builtin_amdgcn_s_memrealtime();
+        sh->sub[0] += ts1 - ts0; sh->sub[1] += ts2 - ts1; sh->sub[2] += ts3 - ts2; sh->sub[3] += ts4 - ts3;
     }
     __syncthreads();
 }
 
 // ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
-__device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int k_in) {
+static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), k = uni(k_in);
     const Lds L = lds_layout(tile); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
@@ -759,14 +767,23 @@ __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, i
     const LsConsts ls = make_ls(omega, v, sh->ell);
     double acc4[4] = {0, 0, 0, 0};
     if (!sh->dense_mode) {
-        for (int w = 0; w < nwaves; ++w) {                          // every wave's survivor segment, all lanes striding it
-            const int cnt_w = sh->wcnt[w];
-            const size_t sb = c.fbase + (size_t)sh->wbase[w];
-            for (int q = tid; q < cnt_w; q += nthreads) {
-                const float4 s0 = c.surv0[sb + q], s1 = c.surv1[sb + q];
-                const float xi[3] = {s0.x, s0.y, s0.z};
-                ls_terms(xi, s1, s0.w, ls, acc4[0], acc4[1], acc4[2], acc4[3]);
-            }
+        // the waves' survivor segments, walked as one index space (one round of load latency, not one per segment)
+        int cum[MAX_WAVES + 1], off[MAX_WAVES];
+        cum[0] = 0;
+#pragma unroll
+        for (int w = 0; w < MAX_WAVES; ++w) {
+            cum[w + 1] = cum[w] + (w < nwaves ? sh->wcnt[w] : 0);
+            off[w] = (w < nwaves ? sh->wbase[w] : 0) - cum[w];
+        }
+        const int nsurv = cum[MAX_WAVES];
+        for (int q = tid; q < nsurv; q += nthreads) {
+            int o = off[0];
+#pragma unroll
+            for (int w = 1; w < MAX_WAVES; ++w) o = (q >= cum[w]) ? off[w] : o;
+            const size_t at = c.fbase + (size_t)(q + o);
+            const float4 s0 = c.surv0[at], s1 = c.surv1[at];
+            const float xi[3] = {s0.x, s0.y, s0.z};
+            ls_terms(xi, s1, s0.w, ls, acc4[0], acc4[1], acc4[2], acc4[3]);
         }
     } else {
         const Gates gates = make_gates(sh->ell, sh->P);
@@ -787,13 +804,13 @@ __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, i
     __syncthreads();
     block_reduce<4>(acc4, sh, tid, nwaves);
     if (G > 1) {
-        if (tid < 64) { if (!group_exchange<4>(sh, c.xch, G, g, 2u * (unsigned)k + 2u, lane)) sh->status = 6; }
+        if (tid < 64) { if (!group_exchange<4>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 2u), lane)) sh->status = 6; }
         __syncthreads();
     }
 }
 
 // ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
-__device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int tile_in, int k_in) {
+static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int tile_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), tile = uni(tile_in), k = uni(k_in);
     Shared* sh = lds_layout(tile).sh;
     if (threadIdx.x == 0) {
@@ -841,24 +858,25 @@ __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int
     __syncthreads();
 }
 
-__global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, DevParams P) {
+__global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, unsigned launch_tag, DevParams P) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
     const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
-    if (tid == 0) sh->P = P;
+    if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; }
 
     for (int p = slot; p < n_pairs; p += slots) {
         const PairDesc* Dp = descs + p;
         const int nf = Dp->nf, nm = Dp->nm;
         const int rows_per = (nf + G - 1) / G;
-        if (tid == 0) {
-            const PairState* st = Dp->state;
-            for (int i = 0; i < 9; ++i) sh->R[i] = st->R[i];
-            for (int i = 0; i < 3; ++i) sh->T[i] = st->T[i];
-            for (int i = 0; i < 12; ++i) sh->M[i] = st->transform[i];
-            sh->ell = st->ell;
+        if (tid < 25) {                                               // R[9], T[3], ell, transform[12]: the head of PairState, one lane per word
+            const float v = ((const gfloat*)Dp->state_in)[tid];
+            if (tid < 9) sh->R[tid] = v; else if (tid < 12) sh->T[tid - 9] = v; else if (tid == 12) sh->ell = v; else sh->M[tid - 13] = v;
+        }
+        if (tid == 32) {
+            const PairState* st = Dp->state_in;
             sh->stop = 0; sh->status = 0; sh->iter_at_break = st->iter; sh->nnz = 0; sh->cand = 0;
+            for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
             sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
@@ -905,22 +923,25 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
         // ---- after the loop (cvo.cpp:815-817): write the pair's state back
         __syncthreads();
         if (tid == 0 && g == 0) {
-            PairState* st = Dp->state;
+            PairState fin;
             float R[9], T[3], M[12];
-            for (int i = 0; i < 9; ++i) { R[i] = sh->R[i]; st->R[i] = R[i]; }
-            for (int i = 0; i < 3; ++i) { T[i] = sh->T[i]; st->T[i] = T[i]; }
+            for (int i = 0; i < 9; ++i) { R[i] = sh->R[i]; fin.R[i] = R[i]; }
+            for (int i = 0; i < 3; ++i) { T[i] = sh->T[i]; fin.T[i] = T[i]; }
             make_transform(R, T, M);                                                            // final update_tf, cvo.cpp:817
-            for (int i = 0; i < 12; ++i) { st->prev_transform[i] = sh->M[i]; st->transform[i] = M[i]; }
-            st->ell = sh->ell;
-            st->iter = sh->iter_at_break;                                                       // unchanged (stale) if no break: Q4
-            st->A_nonzero = sh->nnz;
-            st->iterations_run = k;
-            st->status = sh->status;
-            st->rebuilds = sh->rebuilds;
-            st->dense_fallbacks = sh->dense_fallbacks;
-            st->candidates_total = cand_total;
-            for (int i = 0; i < 10; ++i) st->phase_ticks[i] = ticks[i];
-            st->clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; st->clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0;
+            for (int i = 0; i < 12; ++i) { fin.prev_transform[i] = sh->M[i]; fin.transform[i] = M[i]; }
+            fin.ell = sh->ell;
+            fin.iter = sh->iter_at_break;                                                       // unchanged (stale) if no break: Q4
+            fin.A_nonzero = sh->nnz;
+            fin.iterations_run = k;
+            fin.status = sh->status;
+            fin.rebuilds = sh->rebuilds;
+            fin.dense_fallbacks = sh->dense_fallbacks;
+            fin.candidates_total = cand_total;
+            ticks[7] = sh->sub[0]; ticks[9] = sh->sub[1]; ticks[2] = sh->sub[2]; ticks[4] = sh->sub[3];
+            for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = ticks[i];
+            fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0;
+            *Dp->state = fin;                                          // device copy: the next launch may start from it, the result packer reads it
+            *Dp->state_host = fin;                                     // pinned host mirror: visible to the host when the kernel has completed
         }
         __syncthreads();
     }
@@ -950,11 +971,11 @@ size_t align_shared_bytes(int tile, int y_points) {
 int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 
 hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
-                        const DevParams& P) {
+                        unsigned launch_tag, const DevParams& P) {
     const size_t shmem = align_shared_bytes(tile, y_points);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cvo_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_points > 0 ? 1 : 0, P);
+    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_points > 0 ? 1 : 0, launch_tag, P);
     return hipGetLastError();
 }
 
