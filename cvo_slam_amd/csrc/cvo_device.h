@@ -66,9 +66,8 @@ struct PairDesc {
     float4* ybuild;          // [G][nm_pad]     the positions the candidate lists were built at
     // survivor planes: (nf_pad + G) * capf entries; workgroup g owns [g*rows_per*capf, (g+1)*rows_per*capf)
     int capn;                // longest row the transposed lists hold (longer => dense fallback)
-    uint16_t* jT;            // [G][capn][rows_pad]  transposed lists: column of entry n of local row li, columns ascending
-    float* ckT;              // same shape: colour factor ck of the pair (filled by the first pass over a new list)
-    float* dcT;              // same shape: colour distance d2c (+inf = failed the colour gate)
+    uint16_t* jT;            // [G][capn][rows_pad]  the cull's transposed lists: column of entry n of local row li, columns ascending
+    uint2* ent;              // same shape, by slot (rows sorted by list length): {colour factor ck as bits (NaN = failed the gate), column}
     float4* surv0;           // survivors compacted per wave chunk, in candidate order: {x_i, a}
     float4* surv1;           //                                                         {y_j, 0}
     unsigned long long* xch; // [2][G][XCH_WORDS]

@@ -59,6 +59,9 @@ struct __attribute__((aligned(16))) Shared {
     int wcnt[MAX_WAVES];   // survivors each wave compacted in the candidate phase
     int wtot[MAX_WAVES];   // candidates each wave owns (sum of its rows' list lengths)
     int wbase[MAX_WAVES];  // start of the wave's survivor segment (exclusive prefix of wtot)
+    int wnb[MAX_WAVES];    // 64-slot blocks each wave walks in the candidate phase ...
+    unsigned char wblk[MAX_WAVES][MAX_ROWS_PER_WG / 64];   // ... and which ones (longest first, loads balanced)
+    int blktot[MAX_ROWS_PER_WG / 64];   // candidates per block
     int lmax;              // longest candidate list of this workgroup's rows
     int list_valid;
     int dense_mode;        // candidates did not fit the lists: per-row dense fallback until the next rebuild
@@ -93,6 +96,8 @@ struct GF4 {
     __device__ __forceinline__ void set(size_t i, const float4 v) const { v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; p[i] = t; }
 };
 typedef CVO_GLOBAL uint16_t gu16;
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef CVO_GLOBAL v2u gv2u;
 typedef CVO_GLOBAL uint32_t gu32;
 typedef CVO_GLOBAL int gint;
 typedef CVO_GLOBAL unsigned long long gu64;
@@ -193,7 +198,7 @@ struct Gates {
     float s2, csig2;
     double inv_den_l, inv_den_c;
     float q_lim, q_il, q_ic;  // conservative f32 pre-test of a > sp before the double exps
-    bool poly_ok;             // q_lim <= 0.25: exponents of pairs that pass the pre-test need no range reduction
+    bool poly_ok;             // d2_thres/(2 l^2) <= 0.25: exponents of pairs inside the radius need no range reduction
 };
 
 // exp(x) in double for the only arguments the survivor path produces: the pre-test
@@ -249,25 +254,23 @@ __device__ __forceinline__ float se_kernel_value(const float* xi, const float* f
     return a > G.sp ? a : 0.f;
 }
 
-// The same decision for a listed candidate whose colour part (d2c < d2c_thres passed, ck) was
-// settled when the list was first used: only the geometric half of cvo.cpp:166-175 is left.
-__device__ __forceinline__ float se_kernel_value_pre(const float* xi, const float4 yj, float ck, float d2c, const Gates& G) {
+// A listed candidate carries its colour factor ck (cvo.cpp:169-173 depend on the two points only; NaN = failed the colour
+// gate), so only the geometric half of cvo.cpp:166-175 is left per iteration.
+__device__ __forceinline__ float se_kernel_value_ck(const float* xi, const float4 yj, float ck, const Gates& G) {
     const float e0 = xi[0] - yj.x, e1 = xi[1] - yj.y, e2 = xi[2] - yj.z;
     float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;                  // nanoflann.hpp:403-406
     if (!(d2 < G.d2_thres)) return 0.f;
-    if (d2 * G.q_il + d2c * G.q_ic > G.q_lim) return 0.f;
     const float k = (float)((double)G.s2 * exp_small((double)(-d2) * G.inv_den_l));
     const float a = ck * k;
-    return a > G.sp ? a : 0.f;
+    return a > G.sp ? a : 0.f;                                                 // false for NaN
 }
-
-// Branch-free form for the candidate loop (several independent entries in flight per lane); requires
-// Gates::poly_ok, i.e. every exponent that passes the pre-test lies in [-0.25, 0].  A rejected pair's
-// arithmetic runs on a clamped argument and is thrown away.
-__device__ __forceinline__ float se_kernel_value_flat(const float* xi, const float4 yj, float ck, float d2c, bool active, const Gates& G) {
+// Branch-free form for the steady-state loop (several independent entries in flight per lane); requires Gates::poly_ok,
+// i.e. every exponent of a pair inside the radius lies in [-0.25, 0].  A rejected pair's arithmetic runs on a clamped
+// argument and is thrown away.
+__device__ __forceinline__ float se_kernel_value_flat(const float* xi, const float4 yj, float ck, bool active, const Gates& G) {
     const float e0 = xi[0] - yj.x, e1 = xi[1] - yj.y, e2 = xi[2] - yj.z;
     float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;                  // nanoflann.hpp:403-406
-    const bool pass = active & (d2 < G.d2_thres) & !(d2 * G.q_il + d2c * G.q_ic > G.q_lim);
+    const bool pass = active & (d2 < G.d2_thres);
     const double x = fmax((double)(-d2) * G.inv_den_l, -0.25);
     const float k = (float)((double)G.s2 * exp_poly13(x));
     const float a = ck * k;
@@ -288,7 +291,7 @@ __device__ __forceinline__ Gates make_gates(float l, const DevParams& P) {
     G.q_il = (float)G.inv_den_l;
     G.q_ic = (float)G.inv_den_c;
     G.q_lim = logf(G.s2 * G.csig2 / P.sp_thres) * 1.001f + 1e-3f;   // a>sp  <=>  d2/den_l + d2c/den_c < ln(s2*csig2/sp)
-    G.poly_ok = G.q_lim <= 0.25f;
+    G.poly_ok = (double)G.d2_thres * G.inv_den_l <= 0.2499;
     return G;
 }
 
@@ -390,16 +393,24 @@ template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
+constexpr int PF = 4;                 // list entries a lane evaluates side by side
+constexpr int NCLS = 128;             // list-length classes (ceil(len / PF), the last one open-ended) the rows are sorted by
+constexpr int ROWS_LDS = MAX_ROWS_PER_WG + 128;
+
 struct Lds {
-    Shared* sh; int* rowlen; float* gbox; float* lx; float* ly; float* lz; float4* ylds;
+    Shared* sh; uint16_t* lenS; uint16_t* row_of; uint16_t* rowlen; int* hist; int* base; float* gbox; float* lx; float* ly; float* lz; float4* ylds;
 };
-// Shared | candidate-list length per local row | bounding boxes of the tile's 32-column groups (6 planes) |
+// Shared | list length per slot | row of a slot | list length per local row | sort histograms | group boxes (6 planes) |
 // cull tile, SoA | resident transformed moving cloud (optional)
 __device__ __forceinline__ Lds lds_layout(int tile) {
     Lds L;
     L.sh = reinterpret_cast<Shared*>(cvo_smem);
-    L.rowlen = reinterpret_cast<int*>(cvo_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
-    L.gbox = reinterpret_cast<float*>(L.rowlen + (MAX_ROWS_PER_WG + 64));
+    L.lenS = reinterpret_cast<uint16_t*>(cvo_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
+    L.row_of = L.lenS + ROWS_LDS;
+    L.rowlen = L.row_of + ROWS_LDS;
+    L.hist = reinterpret_cast<int*>(L.rowlen + ROWS_LDS);
+    L.base = L.hist + MAX_WAVES * NCLS;
+    L.gbox = reinterpret_cast<float*>(L.base + MAX_WAVES * NCLS);
     L.lx = L.gbox + 6 * (tile >> 5);
     L.ly = L.lx + tile; L.lz = L.ly + tile;
     L.ylds = reinterpret_cast<float4*>(L.lz + tile);
@@ -412,7 +423,7 @@ struct Ctx {
     const gfloat* fixed; const gfloat* moving;
     int nf, nm, nrows, rows_per, rows_pad, capn, nm_pad, flat_cap, g, G;
     GF4 ybuf, ybuild, surv0, surv1;
-    gu16* jT; gfloat* ckT; gfloat* dcT; gu64* xch;
+    gu16* jT; gv2u* ent; gu64* xch;
     size_t fbase;
 };
 __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
@@ -427,8 +438,7 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     c.ybuild = GF4{(gv4f*)D.ybuild + (size_t)g * D.nm_pad};
     c.surv0 = GF4{(gv4f*)D.surv0}; c.surv1 = GF4{(gv4f*)D.surv1};
     c.jT = (gu16*)D.jT + (size_t)g * D.capn * D.rows_pad;
-    c.ckT = (gfloat*)D.ckT + (size_t)g * D.capn * D.rows_pad;
-    c.dcT = (gfloat*)D.dcT + (size_t)g * D.capn * D.rows_pad;
+    c.ent = (gv2u*)D.ent + (size_t)g * D.capn * D.rows_pad;
     c.xch = (gu64*)D.xch;
     c.fbase = (size_t)g * c.rows_per * D.capf;
     c.flat_cap = c.rows_per * D.capf;
@@ -485,7 +495,7 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
 // turns the decisions into a scalar mask the wave then iterates).
 static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh; int* rowlen = L.rowlen;
+    const Lds L = lds_layout(tile); Shared* sh = L.sh; uint16_t* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
@@ -572,147 +582,230 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                 }
             }
 #pragma unroll
-            for (int r = 0; r < SWEEP_R; ++r) rowlen[li[r]] = cnt[r];   // rowlen has room for the padding rows of the last block pair
+            for (int r = 0; r < SWEEP_R; ++r) rowlen[li[r]] = (uint16_t)cnt[r];   // rowlen has room for the padding rows of the last block pair
+        }
+    }
+    if (tid == 0) { sh->Rb = Rb; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1; }
+    __syncthreads();
+}
+
+// ---- X: rows sorted by list length.  The candidate phase walks one row per lane, so a wave pays for the longest list of
+// its 64 rows: rows are ordered by length class (descending, stable in row order: a counting sort whose every count is
+// deterministic) into "slots", 64 consecutive slots form a block of near-equal lists, and blocks are dealt to the waves
+// longest-first onto the least loaded wave.  Only the order in which rows are visited changes: each row's own sum still runs
+// in column order.
+__device__ __forceinline__ int len_class(int len) { return min(NCLS - 1, (len + PF - 1) / PF); }
+
+static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
+    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
+    const int nrows = c.nrows;
+    const int nblk = (nrows + 63) >> 6;
+    volatile int* hist = L.hist; volatile int* base = L.base;
+    for (int i = tid; i < MAX_WAVES * NCLS; i += nthreads) hist[i] = 0;
+    for (int sl = nrows + tid; sl < nblk * 64; sl += nthreads) { L.lenS[sl] = 0; L.row_of[sl] = 0; }   // padding slots: empty lists of row 0
+    __syncthreads();
+    // wave w sorts the contiguous rows [r0, r1)
+    const int per = (((nrows + nwaves - 1) / nwaves) + 63) & ~63;
+    const int r0 = min(nrows, wave * per), r1 = min(nrows, r0 + per);
+    for (int li = r0 + lane; li < r1; li += 64) atomicAdd(const_cast<int*>(&hist[wave * NCLS + len_class(L.rowlen[li])]), 1);
+    __syncthreads();
+    if (tid < NCLS) { int t = 0; for (int w = 0; w < nwaves; ++w) t += hist[w * NCLS + tid]; base[tid] = t; }   // rows per class
+    __syncthreads();
+    int start_c = 0;
+    if (tid < NCLS) { for (int cc = tid + 1; cc < NCLS; ++cc) start_c += base[cc]; }                         // longer classes first
+    __syncthreads();
+    if (tid < NCLS) { int run = start_c; for (int w = 0; w < nwaves; ++w) { base[w * NCLS + tid] = run; run += hist[w * NCLS + tid]; } }
+    __syncthreads();
+    for (int li0 = r0; li0 < r1; li0 += 64) {
+        const int li = li0 + lane;
+        const bool valid = li < r1;
+        const int len = valid ? (int)L.rowlen[li] : 0;
+        const int cls = valid ? len_class(len) : -1;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {                                              // one trip per distinct class among the 64 rows
+            const int src = __builtin_ctzll(todo);
+            const int c0 = __shfl(cls, src, 64);
+            const unsigned long long m = __ballot(cls == c0);
+            if (cls == c0) {
+                const int slot = base[wave * NCLS + c0] + __popcll(m & ((1ull << lane) - 1ull));
+                L.lenS[slot] = (uint16_t)len; L.row_of[slot] = (uint16_t)li;
+            }
+            if (lane == src) base[wave * NCLS + c0] += __popcll(m);
+            todo &= ~m;
         }
     }
     __syncthreads();
-    // every wave's share of the lists as walked by the candidate phase (64-row blocks wave, wave + nwaves, ...)
-    int my_tot = 0, my_lmax = 0;
-    for (int lb = wave * 64; lb < nrows; lb += nwaves * 64) {
-        const int len = (lb + lane < nrows) ? rowlen[lb + lane] : 0;
+    int my_lmax = 0;
+    for (int b = wave; b < nblk; b += nwaves) {
+        const int len = L.lenS[b * 64 + lane];
         int lmaxb = len, ltot = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lmaxb = max(lmaxb, __shfl_xor(lmaxb, off, 64)); ltot += __shfl_xor(ltot, off, 64); }
-        my_tot += ltot; my_lmax = max(my_lmax, lmaxb);
+        if (lane == 0) { sh->blktot[b] = ltot; L.hist[b] = lmaxb; }
+        my_lmax = max(my_lmax, lmaxb);
     }
-    if (lane == 0) { sh->wtot[wave] = my_tot; sh->wsum[wave] = my_lmax; }
+    if (lane == 0) sh->wsum[wave] = my_lmax;
     __syncthreads();
     if (tid == 0) {
-        int lmax_all = 0, run_w = 0;
-        for (int w = 0; w < nwaves; ++w) { lmax_all = max(lmax_all, sh->wsum[w]); sh->wbase[w] = run_w; run_w += sh->wtot[w]; }
-        // candidates beyond what the survivor planes hold, or a row longer than the transposed lists: dense per-row
-        // fallback until the next rebuild
+        int load[MAX_WAVES], lmax_all = 0;
+        for (int w = 0; w < MAX_WAVES; ++w) { load[w] = 0; sh->wnb[w] = 0; sh->wtot[w] = 0; if (w < nwaves) lmax_all = max(lmax_all, sh->wsum[w]); }
+        for (int b = 0; b < nblk; ++b) {                            // blocks come longest first: greedy onto the least loaded wave
+            int best = 0;
+            for (int w = 1; w < nwaves; ++w) if (load[w] < load[best]) best = w;
+            sh->wblk[best][sh->wnb[best]++] = (unsigned char)b;
+            load[best] += (L.hist[b] + PF - 1) / PF + 3;           // steps of the block + its fixed cost
+            sh->wtot[best] += sh->blktot[b];
+        }
+        int run_w = 0;
+        for (int w = 0; w < nwaves; ++w) { sh->wbase[w] = run_w; run_w += sh->wtot[w]; }
+        // candidates beyond what the survivor planes hold, or a row longer than the lists: dense per-row fallback until the
+        // next rebuild
         const int dense = ((run_w > c.flat_cap) || (lmax_all > c.capn)) ? 1 : 0;
-        sh->Rb = Rb; sh->ell_build = sh->ell; sh->list_valid = 1;
         sh->dense_mode = dense; sh->total = run_w; sh->lmax = lmax_all;
-        sh->rebuilds += 1; sh->dense_fallbacks += dense;
+        sh->dense_fallbacks += dense;
     }
     __syncthreads();
 }
 
-// ---- C: exact kernel values + compute_flow row sums (cvo.cpp:202-231), reduced over the workgroup and the pair's workgroups
+// ---- C: exact kernel values + compute_flow row sums (cvo.cpp:202-231), reduced over the workgroup and the pair's workgroups.
+// One lane per ROW (slot), walking the row's candidate list; the lanes of a wave read entry n of 64 consecutive slots as
+// one coalesced run.  The point gather y_j comes from the LDS-resident cloud, x_i and the row sums live in registers, so
+// a candidate costs no scattered global access and the f32 sums add up in column order (cvo.cpp:213-223) without a
+// second pass.  Survivors {x_i,a},{y_j} are compacted per wave (ballot + prefix popcount) for the line-search phase.
+struct RowSums { float sw[3], sv[3]; };
+
+__device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, float a, RowSums& rs, const Ctx& c, size_t sbase, int& wcount, int lane) {
+    {   // a == 0 for a non-member: it adds exact zeros, the sums keep their bits
+        const float yv[3] = {y4.x, y4.y, y4.z};
+        float cr[3]; cross3(xi, yv, cr);                            // cvo.cpp:216
+        rs.sw[0] += a * cr[0]; rs.sw[1] += a * cr[1]; rs.sw[2] += a * cr[2];
+        rs.sv[0] += a * (yv[0] - xi[0]); rs.sv[1] += a * (yv[1] - xi[1]); rs.sv[2] += a * (yv[2] - xi[2]);   // cvo.cpp:217
+    }
+    const unsigned long long mask = __ballot(a > 0.f);
+    if (a > 0.f) {
+        const size_t pos = sbase + wcount + __popcll(mask & ((1ull << lane) - 1ull));
+        c.surv0.set(pos, make_float4(xi[0], xi[1], xi[2], a)); c.surv1.set(pos, make_float4(y4.x, y4.y, y4.z, 0.f));
+    }
+    wcount += __popcll(mask);
+}
+
+// every iteration but the first after a rebuild: entries {ck, j} stream in, PF per lane per step, the next step's in flight
+template <bool YLDS, bool FLAT>
+__device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, float inv_c, float inv_d,
+                                            double (&acc8)[8]) {
+    const size_t sbase = c.fbase + sh->wbase[wave];
+    int wcount = 0;
+    const int nb = sh->wnb[wave];
+    for (int bi = 0; bi < nb; ++bi) {
+        const int slot = (int)sh->wblk[wave][bi] * 64 + lane;
+        const int len = L.lenS[slot];
+        int lw = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
+        const float4 lo = ld4(c.fixed + (size_t)(c.g + c.G * (int)L.row_of[slot]) * REC);
+        const float xi[3] = {lo.x, lo.y, lo.z};
+        RowSums rs = {{0, 0, 0}, {0, 0, 0}};
+        const gv2u* ep = c.ent + slot;
+        v2u eq[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) eq[u] = ep[(size_t)u * c.rows_pad];
+        for (int n0 = 0; n0 < lw; n0 += PF) {
+            const int nn = min(n0 + PF, c.capn - PF);               // the prefetch stays inside the lists
+            v2u en[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) en[u] = ep[(size_t)(nn + u) * c.rows_pad];
+            float av[PF]; float4 yv4[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {                          // independent until folded: PF exp chains in flight per lane
+                const bool act = n0 + u < len;
+                const int j = act ? (int)eq[u].y : 0;               // slots past the row's end hold stale entries
+                yv4[u] = YLDS ? L.ylds[j] : c.ybuf[j];
+                const float ck = __uint_as_float(eq[u].x);
+                if (FLAT) av[u] = se_kernel_value_flat(xi, yv4[u], ck, act, gates);
+                else av[u] = act ? se_kernel_value_ck(xi, yv4[u], ck, gates) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], rs, c, sbase, wcount, lane);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) eq[u] = en[u];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * rs.sw[q]); acc8[3 + q] += (double)(inv_d * rs.sv[q]); }   // cvo.cpp:222-223
+    }
+    if (lane == 0) { sh->wcnt[wave] = wcount; acc8[6] = (double)wcount; }
+}
+
+// the first iteration on new lists: columns come from the cull's raw lists (by row), the colour gate and factor
+// (cvo.cpp:169-173) are evaluated once and kept with the column in the slot-ordered entries
+template <bool YLDS>
+__device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, float inv_c, float inv_d,
+                                           double (&acc8)[8]) {
+    const size_t sbase = c.fbase + sh->wbase[wave];
+    int wcount = 0;
+    const int nb = sh->wnb[wave];
+    for (int bi = 0; bi < nb; ++bi) {
+        const int slot = (int)sh->wblk[wave][bi] * 64 + lane;
+        const int len = L.lenS[slot];
+        const int li = L.row_of[slot];
+        int lw = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
+        const gfloat* xr = c.fixed + (size_t)(c.g + c.G * li) * REC;
+        const float4 lo = ld4(xr), hi = ld4(xr + 4);
+        const float xi[3] = {lo.x, lo.y, lo.z};
+        const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
+        RowSums rs = {{0, 0, 0}, {0, 0, 0}};
+        int jn = len > 0 ? (int)c.jT[li] : 0;
+        for (int n = 0; n < lw; ++n) {
+            const bool act = n < len;
+            const int j = jn;
+            jn = (n + 1 < len) ? (int)c.jT[(size_t)(n + 1) * c.rows_pad + li] : 0;
+            float a = 0.f; float4 yj = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act) {
+                yj = YLDS ? L.ylds[j] : c.ybuf[j];
+                const float4 gh = ld4(c.moving + (size_t)j * REC + 4);
+                const float fb[5] = {yj.w, gh.x, gh.y, gh.z, gh.w};
+                const float d2c = feat_d2(fi, fb);
+                const float ck = (d2c < gates.d2c_thres) ? (float)((double)gates.csig2 * exp_small((double)(-d2c) * gates.inv_den_c)) : __builtin_nanf("");
+                v2u e; e.x = __float_as_uint(ck); e.y = (unsigned)j;
+                c.ent[(size_t)n * c.rows_pad + slot] = e;
+                a = se_kernel_value_ck(xi, yj, ck, gates);
+            }
+            fold_entry(xi, yj, a, rs, c, sbase, wcount, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * rs.sw[q]); acc8[3 + q] += (double)(inv_d * rs.sv[q]); }   // cvo.cpp:222-223
+    }
+    if (lane == 0) { sh->wcnt[wave] = wcount; acc8[6] = (double)wcount; }
+}
+
 static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh; const int* rowlen = L.rowlen;
+    const Lds L = lds_layout(tile); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
     const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
     const Gates gates = make_gates(sh->ell, sh->P);
     const bool dense_mode = sh->dense_mode != 0, fresh_list = sh->rebuild != 0;
-    const int total = sh->total;
     const float inv_c = 1 / sh->P.c, inv_d = 1 / sh->P.d;
     double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // omega[3], v[3], nnz, candidates
     const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
     if (!dense_mode) {
-        // one lane per ROW, walking the row's candidate list (transposed: the lanes of a wave read entry n of 64
-        // consecutive rows as one coalesced run).  The point gather y_j comes from the LDS-resident cloud, x_i and the
-        // row sums live in registers, so a candidate costs no scattered global access and the f32 sums add up in column
-        // order (cvo.cpp:213-223) without a second pass.  Survivors {x_i,a},{y_j} are compacted per wave (ballot +
-        // prefix popcount) for the line-search phase.
-        const size_t sbase = c.fbase + sh->wbase[wave];
-        int wcount = 0;
-        for (int lb = wave * 64; lb < nrows; lb += nwaves * 64) {
-            const int li = lb + lane;
-            const bool rowok = li < nrows;
-            const int len = rowok ? rowlen[li] : 0;
-            int lw = len;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
-            float xi[3] = {0.f, 0.f, 0.f}, fi[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-            if (rowok) {
-                const gfloat* xr = c.fixed + (size_t)(g + G * li) * REC;
-                const float4 lo = ld4(xr);
-                xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; fi[0] = lo.w;
-                if (fresh_list) { const float4 hi = ld4(xr + 4); fi[1] = hi.x; fi[2] = hi.y; fi[3] = hi.z; fi[4] = hi.w; }
-            }
-            float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
-            // the lists stream from HBM / Infinity Cache: entries n+PF .. n+2PF-1 are in flight while n .. n+PF-1 are evaluated
-            constexpr int PF = 4;
-            int jq[PF]; float ckq[PF], dcq[PF];
-            auto fetch = [&](int n0, int (&jo)[PF], float (&cko)[PF], float (&dco)[PF]) {
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const bool in = n0 + u < len;
-                    const size_t at = (size_t)(n0 + u) * c.rows_pad + li;
-                    jo[u] = in ? (int)c.jT[at] : 0;
-                    cko[u] = (in && !fresh_list) ? c.ckT[at] : 0.f;
-                    dco[u] = (in && !fresh_list) ? c.dcT[at] : 0.f;
-                }
-            };
-            fetch(0, jq, ckq, dcq);
-            for (int n0 = 0; n0 < lw; n0 += PF) {
-                int jn[PF]; float ckn[PF], dcn[PF];
-                fetch(n0 + PF, jn, ckn, dcn);
-                // the PF entries are independent until their results are added to the row sums: evaluate them side by
-                // side (four exp / gate chains in flight per lane), then fold them in column order
-                float av[PF]; float4 yv4[PF];
-                if (!fresh_list && gates.poly_ok) {
-#pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        yv4[u] = y_lds ? L.ylds[jq[u]] : c.ybuf[jq[u]];   // entries past the row's end carry j = 0
-                        av[u] = se_kernel_value_flat(xi, yv4[u], ckq[u], dcq[u], n0 + u < len, gates);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        const int n = n0 + u;
-                        const int j = jq[u]; float ck = ckq[u], d2c = dcq[u];
-                        av[u] = 0.f; yv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (n < len) {
-                            const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
-                            yv4[u] = yj;
-                            if (fresh_list) {
-                                // colour gate and factor (cvo.cpp:169-173) depend on the two points only: done by the first pass
-                                // over a new list and kept.  A pair that fails the gate gets d2c = +inf, ck = 0: the pre-test in
-                                // se_kernel_value_pre then rejects it for good.
-                                const float4 gh = ld4(c.moving + (size_t)j * REC + 4);
-                                const float fb[5] = {yj.w, gh.x, gh.y, gh.z, gh.w};
-                                d2c = feat_d2(fi, fb);
-                                if (d2c < gates.d2c_thres && !(d2c * gates.q_ic > gates.q_lim))
-                                    ck = (float)((double)gates.csig2 * exp_small((double)(-d2c) * gates.inv_den_c));
-                                else { ck = 0.f; d2c = __builtin_inff(); }
-                                const size_t cur = (size_t)n * c.rows_pad + li;
-                                c.ckT[cur] = ck; c.dcT[cur] = d2c;
-                            }
-                            av[u] = se_kernel_value_pre(xi, yj, ck, d2c, gates);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const float a = av[u];
-                    {   // a == 0 for a non-member: it adds exact zeros, the sums keep their bits
-                        const float yv[3] = {yv4[u].x, yv4[u].y, yv4[u].z};
-                        float cr[3]; cross3(xi, yv, cr);            // cvo.cpp:216
-                        sw[0] += a * cr[0]; sw[1] += a * cr[1]; sw[2] += a * cr[2];
-                        sv[0] += a * (yv[0] - xi[0]); sv[1] += a * (yv[1] - xi[1]); sv[2] += a * (yv[2] - xi[2]);   // cvo.cpp:217
-                    }
-                    const unsigned long long mask = __ballot(a > 0.f);
-                    if (a > 0.f) {
-                        const size_t pos = sbase + wcount + __popcll(mask & ((1ull << lane) - 1ull));
-                        c.surv0.set(pos, make_float4(xi[0], xi[1], xi[2], a)); c.surv1.set(pos, make_float4(yv4[u].x, yv4[u].y, yv4[u].z, 0.f));
-                    }
-                    wcount += __popcll(mask);
-                }
-#pragma unroll
-                for (int u = 0; u < PF; ++u) { jq[u] = jn[u]; ckq[u] = ckn[u]; dcq[u] = dcn[u]; }
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }   // cvo.cpp:222-223
+        if (fresh_list) {
+            if (y_lds) cand_fresh<true>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
+            else cand_fresh<false>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
+        } else if (gates.poly_ok) {
+            if (y_lds) cand_steady<true, true>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
+            else cand_steady<false, true>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
+        } else {
+            if (y_lds) cand_steady<true, false>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
+            else cand_steady<false, false>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
         }
-        if (lane == 0) { sh->wcnt[wave] = wcount; acc8[6] = (double)wcount; }
-        if (tid == 0) acc8[7] = (double)total;
+        if (tid == 0) acc8[7] = (double)sh->total;
     } else {
         for (int li = tid; li < nrows; li += nthreads) {            // dense fallback: every column of the row
             const int i = g + G * li;
@@ -735,7 +828,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 #pragma unroll
             for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }
             acc8[6] += (double)nz;
-            acc8[7] += (double)rowlen[li];
+            acc8[7] += (double)L.rowlen[li];
         }
     }
     const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
@@ -898,7 +991,9 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
             if (sh->rebuild) {
                 const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
                 phase_cull(Dp, g, G, tile);
-                ticks[6] += __builtin_amdgcn_s_memrealtime() - t_a;
+                const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
+                phase_sort(Dp, g, G, tile);
+                ticks[6] += t_b - t_a; ticks[8] += __builtin_amdgcn_s_memrealtime() - t_b;
             }
             CVO_PHASE(0);
             phase_candidates(Dp, g, G, tile, y_lds, k);
@@ -963,10 +1058,10 @@ hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream
 
 int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
 
-// LDS: Shared | list lengths | group boxes | cull tile (3*tile floats) | resident y cloud (16 B * nm_pad, optional)
+// LDS: Shared | slot/row tables | sort histograms | group boxes | cull tile (3*tile floats) | resident y cloud (16 B * nm_pad, optional)
 size_t align_shared_bytes(int tile, int y_points) {
-    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)(MAX_ROWS_PER_WG + 64) * sizeof(int) + (size_t)6 * (tile >> 5) * sizeof(float) +
-           (size_t)3 * tile * sizeof(float) + (size_t)y_points * sizeof(float4);
+    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)3 * ROWS_LDS * sizeof(uint16_t) + (size_t)2 * MAX_WAVES * NCLS * sizeof(int) +
+           (size_t)6 * (tile >> 5) * sizeof(float) + (size_t)3 * tile * sizeof(float) + (size_t)y_points * sizeof(float4);
 }
 int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 

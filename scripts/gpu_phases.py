@@ -17,10 +17,10 @@ for wgs in [int(x) for x in os.environ.get("WGS", "1,2,4").split(",")]:
     info = B.last_launch(); ph = B.last_phase_seconds()
     its = info["iterations_total"]
     cand_sub = {"prologue": ph.pop("rb_scan"), "rows": ph.pop("c2_rowsums"), "wg_reduce": ph.pop("reduce1"), "exchange": ph.pop("reduce2")}
-    rb_sweep = ph.pop("rb_sweep"); ph.pop("rb_extract")
+    rb_sweep = ph.pop("rb_sweep"); rb_sort = ph.pop("rb_extract")
     tot = sum(ph.values())
     print(f"wgs={wgs} kernel {info['kernel_ms']:.2f} ms, iterations {its} (max {max(r['iterations_run'] for r in res)}), cand/iter {info['candidates_total']/its:.0f}")
     rb = sum(r["rebuilds"] for r in res); df = sum(r["dense_fallbacks"] for r in res)
-    print(f"   rebuilds {rb} ({rb/len(res):.1f}/pair), dense fallbacks {df}; cull per rebuild {1e6*rb_sweep/max(rb,1):.0f} us")
+    print(f"   rebuilds {rb} ({rb/len(res):.1f}/pair), dense fallbacks {df}; cull per rebuild {1e6*rb_sweep/max(rb,1):.0f} us, sort {1e6*rb_sort/max(rb,1):.1f} us")
     print("   per-iteration us (wg0):", {k: round(1e6 * v / its, 1) for k, v in ph.items()}, "sum", round(1e6 * tot / its, 1))
     print("   inside candidates (thread 0):", {k: round(1e6 * v / its, 1) for k, v in cand_sub.items()})
