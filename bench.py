@@ -4,7 +4,10 @@
 A "step" aligns one batch of 64 independent synthetic 640x480 RGB-D frame pairs
 (~3000 points per cloud, TUM fr1 intrinsics) per GPU through the C ABI's batched
 path: one persistent launch of cvo_align_kernel, clouds already resident in HBM,
-R=I, T=0, ell=0.15 at the start of every step (fresh-object semantics).  At N GPUs
+R=I, T=0, ell=0.15 at the start of every step (fresh-object semantics).  Eight
+steps are in flight on separate HIP streams (BASELINE config 3: "HIP streams"),
+one workgroup per pair: a launch covers 64 of the 256 CUs, its pairs have
+data-dependent iteration counts, the other launches fill what it leaves idle.  At N GPUs
 every rank owns its own 64 pairs (weak scaling: BASELINE config 3 at N=1, config 4
 = 512 pairs at N=8); the only collective is an RCCL all-gather of the 64-byte
 result records.  Rank 0 prints one JSON line.
@@ -24,6 +27,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per step in flight (the HIP runtime maps streams onto 4 queues by default; launches that share a
+# queue run one after the other).  Read by the runtime when it initialises, i.e. after this line.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PAIRS_PER_GPU = 64
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -100,11 +106,11 @@ def cpu_baseline(pairs, threads, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="frame pairs per GPU per step")
-    ap.add_argument("--workgroups", type=int, default=0, help="workgroups per pair (0 = auto)")
-    ap.add_argument("--streams", type=int, default=2, help="steps in flight (batch objects on separate HIP streams)")
+    ap.add_argument("--workgroups", type=int, default=1, help="workgroups per pair (0 = auto: lowest latency of one batch alone; 1 = highest throughput)")
+    ap.add_argument("--streams", type=int, default=8, help="steps in flight (batch objects on separate HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -178,6 +184,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(depth):                         # setup: every batch object's first launch uploads its descriptors
+        step(i)
+    drain()
     for i in range(args.warmup):
         step(i)
     drain()
@@ -214,6 +223,8 @@ def main():
         achieved_gbs = bytes_launch / (k_ms * 1e-3) / 1e9
         achieved_tf = flops_launch / (k_ms * 1e-3) / 1e12
         value = world * n * args.steps / elapsed
+        step_ms_rank = 1e3 * elapsed / args.steps          # one launch retires every step_ms_rank on this GPU
+        overlap = k_ms / step_ms_rank                      # launches running side by side, on average
         traffic = None                                  # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_run.sh)
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -234,9 +245,14 @@ def main():
                        "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": "RCCL all_gather of 64-byte result records" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "cvo_align_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "path is VALU-issue bound, not HBM bound (SURVEY 8d): see valu"},
-            "valu": {"achieved": achieved_tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / FP32_VALU_PEAK_TF,
-                     "algorithmic_flops_per_launch": flops_launch, "pair_tests_per_s": flops_launch / 8.0 / (k_ms * 1e-3)},
+                         "launches_side_by_side": overlap, "achieved_all_launches": achieved_gbs * overlap,
+                         "frac_all_launches": achieved_gbs * overlap / HBM_PEAK_GBS,
+                         "note": "achieved = algorithmic bytes of ONE launch / its own HIP-event duration; a launch holds 64 of 256 CUs and "
+                                 "launches_side_by_side of them run at once, achieved_all_launches is the whole GPU's rate.  The path is "
+                                 "latency/VALU bound, not HBM bound (SURVEY 8d): see valu and DESIGN.md"},
+            "valu": {"achieved": achieved_tf * overlap, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf * overlap / FP32_VALU_PEAK_TF,
+                     "algorithmic_flops_per_launch": flops_launch, "pair_tests_per_s": flops_launch / 8.0 / (k_ms * 1e-3) * overlap,
+                     "note": "algorithmic pair tests (dense N*M per iteration, two sweeps) of all launches in flight; the kernel skips most of them"},
         }
         if not args.no_cpu_baseline and world == 1:
             cores = host_threads()

@@ -59,9 +59,7 @@ struct __attribute__((aligned(16))) Shared {
     int wcnt[MAX_WAVES];   // survivors each wave compacted in the candidate phase
     int wtot[MAX_WAVES];   // candidates each wave owns (sum of its rows' list lengths)
     int wbase[MAX_WAVES];  // start of the wave's survivor segment (exclusive prefix of wtot)
-    int wnb[MAX_WAVES];    // 64-slot blocks each wave walks in the candidate phase ...
-    unsigned char wblk[MAX_WAVES][MAX_ROWS_PER_WG / 64];   // ... and which ones (longest first, loads balanced)
-    int blktot[MAX_ROWS_PER_WG / 64];   // candidates per block
+    int wnb[MAX_WAVES];    // 64-slot blocks each wave walks in the candidate phase (serpentine deal, see phase_sort)
     int lmax;              // longest candidate list of this workgroup's rows
     int list_valid;
     int dense_mode;        // candidates did not fit the lists: per-row dense fallback until the next rebuild
@@ -591,10 +589,12 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
 
 // ---- X: rows sorted by list length.  The candidate phase walks one row per lane, so a wave pays for the longest list of
 // its 64 rows: rows are ordered by length class (descending, stable in row order: a counting sort whose every count is
-// deterministic) into "slots", 64 consecutive slots form a block of near-equal lists, and blocks are dealt to the waves
-// longest-first onto the least loaded wave.  Only the order in which rows are visited changes: each row's own sum still runs
-// in column order.
+// deterministic) into "slots", 64 consecutive slots form a block of near-equal lists, and the blocks (longest first) are
+// dealt to the waves in serpentine order (0..7, 7..0, 0..7, ...), which keeps the waves' loads within one block of each other.
+// Only the order in which rows are visited changes: each row's own sum still runs in column order.
 __device__ __forceinline__ int len_class(int len) { return min(NCLS - 1, (len + PF - 1) / PF); }
+// i-th block of a wave in the serpentine deal
+__device__ __forceinline__ int wave_block(int i, int wave, int nwaves) { return i * nwaves + ((i & 1) ? nwaves - 1 - wave : wave); }
 
 static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
@@ -603,64 +603,71 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
     const int nblk = (nrows + 63) >> 6;
-    volatile int* hist = L.hist; volatile int* base = L.base;
+    int* hist = L.hist; int* base = L.base;
     for (int i = tid; i < MAX_WAVES * NCLS; i += nthreads) hist[i] = 0;
     for (int sl = nrows + tid; sl < nblk * 64; sl += nthreads) { L.lenS[sl] = 0; L.row_of[sl] = 0; }   // padding slots: empty lists of row 0
     __syncthreads();
     // wave w sorts the contiguous rows [r0, r1)
     const int per = (((nrows + nwaves - 1) / nwaves) + 63) & ~63;
     const int r0 = min(nrows, wave * per), r1 = min(nrows, r0 + per);
-    for (int li = r0 + lane; li < r1; li += 64) atomicAdd(const_cast<int*>(&hist[wave * NCLS + len_class(L.rowlen[li])]), 1);
+    for (int li = r0 + lane; li < r1; li += 64) atomicAdd(&hist[wave * NCLS + len_class(L.rowlen[li])], 1);
     __syncthreads();
-    if (tid < NCLS) { int t = 0; for (int w = 0; w < nwaves; ++w) t += hist[w * NCLS + tid]; base[tid] = t; }   // rows per class
-    __syncthreads();
-    int start_c = 0;
-    if (tid < NCLS) { for (int cc = tid + 1; cc < NCLS; ++cc) start_c += base[cc]; }                         // longer classes first
-    __syncthreads();
-    if (tid < NCLS) { int run = start_c; for (int w = 0; w < nwaves; ++w) { base[w * NCLS + tid] = run; run += hist[w * NCLS + tid]; } }
+    if (tid < 64) {
+        // lane l owns classes 2l and 2l+1: rows per class over all waves, then an exclusive SUFFIX sum (longer classes first)
+        int t0 = 0, t1 = 0;
+        for (int w = 0; w < nwaves; ++w) { t0 += hist[w * NCLS + 2 * lane]; t1 += hist[w * NCLS + 2 * lane + 1]; }
+        int inc = t0 + t1;                                          // inclusive suffix over lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_down(inc, off, 64); if (lane + off < 64) inc += t; }
+        const int after = inc - (t0 + t1);                          // rows in classes of higher lanes
+        int run0 = after + t1, run1 = after;
+        for (int w = 0; w < nwaves; ++w) {
+            const int h0 = hist[w * NCLS + 2 * lane], h1 = hist[w * NCLS + 2 * lane + 1];
+            base[w * NCLS + 2 * lane] = run0; base[w * NCLS + 2 * lane + 1] = run1;
+            run0 += h0; run1 += h1;
+        }
+    }
     __syncthreads();
     for (int li0 = r0; li0 < r1; li0 += 64) {
         const int li = li0 + lane;
         const bool valid = li < r1;
         const int len = valid ? (int)L.rowlen[li] : 0;
         const int cls = valid ? len_class(len) : -1;
+        // rank among the rows of the same class in this step and the class's size, by ballots alone; LDS is touched once after
+        int rank = 0, csize = 0; bool leader = false;
         unsigned long long todo = __ballot(valid);
         while (todo) {                                              // one trip per distinct class among the 64 rows
             const int src = __builtin_ctzll(todo);
-            const int c0 = __shfl(cls, src, 64);
+            const int c0 = __builtin_amdgcn_readlane(cls, src);
             const unsigned long long m = __ballot(cls == c0);
-            if (cls == c0) {
-                const int slot = base[wave * NCLS + c0] + __popcll(m & ((1ull << lane) - 1ull));
-                L.lenS[slot] = (uint16_t)len; L.row_of[slot] = (uint16_t)li;
-            }
-            if (lane == src) base[wave * NCLS + c0] += __popcll(m);
+            if (cls == c0) { rank = __popcll(m & ((1ull << lane) - 1ull)); csize = __popcll(m); leader = lane == src; }
             todo &= ~m;
         }
+        if (valid) {
+            const int slot = base[wave * NCLS + cls] + rank;
+            L.lenS[slot] = (uint16_t)len; L.row_of[slot] = (uint16_t)li;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (leader) base[wave * NCLS + cls] += csize;               // one lane per class: no two lanes touch the same counter
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    int my_lmax = 0;
-    for (int b = wave; b < nblk; b += nwaves) {
+    // every wave sums up the blocks the serpentine deal gives it
+    int my_lmax = 0, my_tot = 0, my_nb = 0;
+    for (int i = 0;; ++i) {
+        const int b = wave_block(i, wave, nwaves);
+        if (b >= nblk) break;
         const int len = L.lenS[b * 64 + lane];
         int lmaxb = len, ltot = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lmaxb = max(lmaxb, __shfl_xor(lmaxb, off, 64)); ltot += __shfl_xor(ltot, off, 64); }
-        if (lane == 0) { sh->blktot[b] = ltot; L.hist[b] = lmaxb; }
-        my_lmax = max(my_lmax, lmaxb);
+        my_lmax = max(my_lmax, lmaxb); my_tot += ltot; ++my_nb;
     }
-    if (lane == 0) sh->wsum[wave] = my_lmax;
+    if (lane == 0) { sh->wsum[wave] = my_lmax; sh->wtot[wave] = my_tot; sh->wnb[wave] = my_nb; }
     __syncthreads();
     if (tid == 0) {
-        int load[MAX_WAVES], lmax_all = 0;
-        for (int w = 0; w < MAX_WAVES; ++w) { load[w] = 0; sh->wnb[w] = 0; sh->wtot[w] = 0; if (w < nwaves) lmax_all = max(lmax_all, sh->wsum[w]); }
-        for (int b = 0; b < nblk; ++b) {                            // blocks come longest first: greedy onto the least loaded wave
-            int best = 0;
-            for (int w = 1; w < nwaves; ++w) if (load[w] < load[best]) best = w;
-            sh->wblk[best][sh->wnb[best]++] = (unsigned char)b;
-            load[best] += (L.hist[b] + PF - 1) / PF + 3;           // steps of the block + its fixed cost
-            sh->wtot[best] += sh->blktot[b];
-        }
-        int run_w = 0;
-        for (int w = 0; w < nwaves; ++w) { sh->wbase[w] = run_w; run_w += sh->wtot[w]; }
+        int lmax_all = 0, run_w = 0;
+        for (int w = 0; w < nwaves; ++w) { lmax_all = max(lmax_all, sh->wsum[w]); sh->wbase[w] = run_w; run_w += sh->wtot[w]; }
         // candidates beyond what the survivor planes hold, or a row longer than the lists: dense per-row fallback until the
         // next rebuild
         const int dense = ((run_w > c.flat_cap) || (lmax_all > c.capn)) ? 1 : 0;
@@ -694,13 +701,13 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
 
 // every iteration but the first after a rebuild: entries {ck, j} stream in, PF per lane per step, the next step's in flight
 template <bool YLDS, bool FLAT>
-__device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, float inv_c, float inv_d,
+__device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                             double (&acc8)[8]) {
     const size_t sbase = c.fbase + sh->wbase[wave];
     int wcount = 0;
     const int nb = sh->wnb[wave];
     for (int bi = 0; bi < nb; ++bi) {
-        const int slot = (int)sh->wblk[wave][bi] * 64 + lane;
+        const int slot = wave_block(bi, wave, nwaves) * 64 + lane;
         const int len = L.lenS[slot];
         int lw = len;
 #pragma unroll
@@ -741,13 +748,13 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
 // the first iteration on new lists: columns come from the cull's raw lists (by row), the colour gate and factor
 // (cvo.cpp:169-173) are evaluated once and kept with the column in the slot-ordered entries
 template <bool YLDS>
-__device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, float inv_c, float inv_d,
+__device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                            double (&acc8)[8]) {
     const size_t sbase = c.fbase + sh->wbase[wave];
     int wcount = 0;
     const int nb = sh->wnb[wave];
     for (int bi = 0; bi < nb; ++bi) {
-        const int slot = (int)sh->wblk[wave][bi] * 64 + lane;
+        const int slot = wave_block(bi, wave, nwaves) * 64 + lane;
         const int len = L.lenS[slot];
         const int li = L.row_of[slot];
         int lw = len;
@@ -796,14 +803,14 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
     const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
     if (!dense_mode) {
         if (fresh_list) {
-            if (y_lds) cand_fresh<true>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
-            else cand_fresh<false>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
+            if (y_lds) cand_fresh<true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+            else cand_fresh<false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
         } else if (gates.poly_ok) {
-            if (y_lds) cand_steady<true, true>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
-            else cand_steady<false, true>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
+            if (y_lds) cand_steady<true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+            else cand_steady<false, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
         } else {
-            if (y_lds) cand_steady<true, false>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
-            else cand_steady<false, false>(c, L, sh, gates, lane, wave, inv_c, inv_d, acc8);
+            if (y_lds) cand_steady<true, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+            else cand_steady<false, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
         }
         if (tid == 0) acc8[7] = (double)sh->total;
     } else {
