@@ -107,7 +107,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
-    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_jT, d_ent, d_surv0, d_surv1, d_xch, d_trace, d_tracelen, d_partials;
+    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_jT, d_ent, d_surv, d_xch, d_trace, d_tracelen, d_partials;
     PinBuf h_descs, h_states, h_states_in, h_stage, h_partials;   // h_states: final states, written by the kernel itself (mapped pinned memory)
     std::vector<unsigned char> descs_uploaded;                     // what d_descs holds: unchanged descriptors are not sent again
     unsigned launch_seq = 0;
@@ -138,7 +138,7 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_jT, &d_ent, &d_surv0, &d_surv1, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_jT, &d_ent, &d_surv, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -226,8 +226,7 @@ struct Engine {
         const size_t tplane = (size_t)G * capn * rows_pad;
         if ((rc = d_jT.ensure(sizeof(uint16_t) * (size_t)n * tplane))) return rc;
         if ((rc = d_ent.ensure(sizeof(uint2) * (size_t)n * tplane))) return rc;
-        if ((rc = d_surv0.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
-        if ((rc = d_surv1.ensure(sizeof(float4) * (size_t)n * plane))) return rc;
+        if ((rc = d_surv.ensure(sizeof(uint2) * (size_t)n * plane))) return rc;
         const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n * 2 * G * XCH_WORDS;
         if ((rc = d_xch.ensure(xch_bytes))) return rc;
         if (want_trace) {
@@ -250,8 +249,7 @@ struct Engine {
             D.capn = capn;
             D.jT = static_cast<uint16_t*>(d_jT.p) + (size_t)i * tplane;
             D.ent = static_cast<uint2*>(d_ent.p) + (size_t)i * tplane;
-            D.surv0 = static_cast<float4*>(d_surv0.p) + (size_t)i * plane;
-            D.surv1 = static_cast<float4*>(d_surv1.p) + (size_t)i * plane;
+            D.surv = static_cast<uint2*>(d_surv.p) + (size_t)i * plane;
             D.xch = static_cast<unsigned long long*>(d_xch.p) + (size_t)i * 2 * G * XCH_WORDS;
             D.state = static_cast<PairState*>(d_states.p) + i;
             D.state_in = upload_states ? static_cast<const PairState*>(h_states_in.p) + i : D.state;

@@ -68,8 +68,7 @@ struct PairDesc {
     int capn;                // longest row the transposed lists hold (longer => dense fallback)
     uint16_t* jT;            // [G][capn][rows_pad]  the cull's transposed lists: column of entry n of local row li, columns ascending
     uint2* ent;              // same shape, by slot (rows sorted by list length): {colour factor ck as bits (NaN = failed the gate), column}
-    float4* surv0;           // survivors compacted per wave chunk, in candidate order: {x_i, a}
-    float4* surv1;           //                                                         {y_j, 0}
+    uint2* surv;             // nonzeros of A compacted per wave, in the order they were found: {a as bits, slot << 16 | column}
     unsigned long long* xch; // [2][G][XCH_WORDS]
     const PairState* state_in;   // start state: the device copy (carried from the last launch) or a pinned host buffer the caller filled
     PairState* state;            // device copy of the final state

@@ -70,8 +70,10 @@ struct __attribute__((aligned(16))) Shared {
     int nnz;
     int cand;
     int rebuilds;
+    int refines;           // list rebuilds done by filtering the old lists (ell drops)
     int dense_fallbacks;
     int rebuild;           // this iteration rebuilds the candidate lists
+    int x_lds;             // the fixed points, by slot, sit in the (otherwise idle) cull tile: lx/ly/lz[slot]
     unsigned launch_tag;   // high 16 bits of every exchange tag: this launch's sequence number (granules of earlier launches never match)
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
     float omega[3];        // this iteration's twist (f32, cvo.cpp:234-235)
@@ -420,7 +422,7 @@ __device__ __forceinline__ Lds lds_layout(int tile) {
 struct Ctx {
     const gfloat* fixed; const gfloat* moving;
     int nf, nm, nrows, rows_per, rows_pad, capn, nm_pad, flat_cap, g, G;
-    GF4 ybuf, ybuild, surv0, surv1;
+    GF4 ybuf, ybuild; gv2u* surv;
     gu16* jT; gv2u* ent; gu64* xch;
     size_t fbase;
 };
@@ -434,13 +436,19 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
     c.ybuf = GF4{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
     c.ybuild = GF4{(gv4f*)D.ybuild + (size_t)g * D.nm_pad};
-    c.surv0 = GF4{(gv4f*)D.surv0}; c.surv1 = GF4{(gv4f*)D.surv1};
+    c.surv = (gv2u*)D.surv;
     c.jT = (gu16*)D.jT + (size_t)g * D.capn * D.rows_pad;
     c.ent = (gv2u*)D.ent + (size_t)g * D.capn * D.rows_pad;
     c.xch = (gu64*)D.xch;
     c.fbase = (size_t)g * c.rows_per * D.capf;
     c.flat_cap = c.rows_per * D.capf;
     return c;
+}
+
+// fixed point of a slot: from the LDS copy made after the sort, or gathered from the cloud
+__device__ __forceinline__ void load_x(const Ctx& c, const Lds& L, bool x_lds, int slot, float (&xi)[3]) {
+    if (x_lds) { xi[0] = L.lx[slot]; xi[1] = L.ly[slot]; xi[2] = L.lz[slot]; }
+    else { const float4 lo = ld4(c.fixed + (size_t)(c.g + c.G * (int)L.row_of[slot]) * REC); xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; }
 }
 
 // ---- T: transform_pcd (cvo.cpp:336-341) into ybuf (+ the LDS-resident copy); how far has any point moved since
@@ -479,7 +487,12 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
         const float r_c = sqrtf(gate_d2_align(ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
         // the lists hold every pair within Rb of the build positions; a pair within r_c now was within
         // r_c + (its point's displacement) then.  Every workgroup of the pair computes the same bits here.
-        sh->rebuild = (!have_list || (sh->ell_build != ell) || (r_c + sqrtf(dmax2) * 1.0001f + 1.0e-5f) * 1.00001f > sh->Rb) ? 1 : 0;
+        const float reach = (sqrtf(dmax2) * 1.0001f + 1.0e-5f);      // how much closer a pair can be now than when the lists were built
+        int rb = (!have_list || (sh->ell_build != ell) || (r_c + reach) * 1.00001f > sh->Rb) ? 1 : 0;
+        // ell has dropped (cvo.cpp:810-812) and the old, wider lists still hold every pair within the NEW list radius of the
+        // current positions: filter them in place instead of a dense cull (2 = refine).  Not in dense mode (no lists to filter).
+        if (rb && have_list && !sh->dense_mode && sh->ell_build != ell && (r_c * (1.0f + sh->P.skin) + reach) * 1.00001f <= sh->Rb) rb = 2;
+        sh->rebuild = rb;
         for (int i = 0; i < 12; ++i) sh->M[i] = M[i];
     }
     __syncthreads();
@@ -674,6 +687,15 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
         sh->dense_mode = dense; sh->total = run_w; sh->lmax = lmax_all;
         sh->dense_fallbacks += dense;
     }
+    // the cull tile is idle until the next cull: it keeps the fixed points in slot order for the candidate and line-search phases
+    const int xl = (nblk * 64 <= tile) ? 1 : 0;
+    if (xl) {
+        for (int sl = tid; sl < nblk * 64; sl += nthreads) {
+            const float4 lo = ld4(c.fixed + (size_t)(g + G * (int)L.row_of[sl]) * REC);
+            L.lx[sl] = lo.x; L.ly[sl] = lo.y; L.lz[sl] = lo.z;
+        }
+    }
+    if (tid == 0) sh->x_lds = xl;
     __syncthreads();
 }
 
@@ -684,7 +706,8 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
 // second pass.  Survivors {x_i,a},{y_j} are compacted per wave (ballot + prefix popcount) for the line-search phase.
 struct RowSums { float sw[3], sv[3]; };
 
-__device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, float a, RowSums& rs, const Ctx& c, size_t sbase, int& wcount, int lane) {
+__device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, float a, unsigned tag /* slot << 16 | column */, RowSums& rs, const Ctx& c,
+                                           size_t sbase, int& wcount, int lane) {
     {   // a == 0 for a non-member: it adds exact zeros, the sums keep their bits
         const float yv[3] = {y4.x, y4.y, y4.z};
         float cr[3]; cross3(xi, yv, cr);                            // cvo.cpp:216
@@ -693,8 +716,9 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
     }
     const unsigned long long mask = __ballot(a > 0.f);
     if (a > 0.f) {
-        const size_t pos = sbase + wcount + __popcll(mask & ((1ull << lane) - 1ull));
-        c.surv0.set(pos, make_float4(xi[0], xi[1], xi[2], a)); c.surv1.set(pos, make_float4(y4.x, y4.y, y4.z, 0.f));
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        v2u rec; rec.x = __float_as_uint(a); rec.y = tag;             // 8 bytes per nonzero: the line search finds x_i, y_j in LDS
+        c.surv[sbase + (size_t)(wcount + (int)below)] = rec;
     }
     wcount += __popcll(mask);
 }
@@ -704,6 +728,7 @@ template <bool YLDS, bool FLAT>
 __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                             double (&acc8)[8]) {
     const size_t sbase = c.fbase + sh->wbase[wave];
+    const bool x_lds = sh->x_lds != 0;
     int wcount = 0;
     const int nb = sh->wnb[wave];
     for (int bi = 0; bi < nb; ++bi) {
@@ -712,18 +737,19 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         int lw = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
-        const float4 lo = ld4(c.fixed + (size_t)(c.g + c.G * (int)L.row_of[slot]) * REC);
-        const float xi[3] = {lo.x, lo.y, lo.z};
+        float xi[3]; load_x(c, L, x_lds, slot, xi);
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
         const gv2u* ep = c.ent + slot;
+        const size_t estep = (size_t)PF * c.rows_pad;
+        const unsigned stag = (unsigned)slot << 16;
         v2u eq[PF];
 #pragma unroll
         for (int u = 0; u < PF; ++u) eq[u] = ep[(size_t)u * c.rows_pad];
         for (int n0 = 0; n0 < lw; n0 += PF) {
-            const int nn = min(n0 + PF, c.capn - PF);               // the prefetch stays inside the lists
+            if (n0 + 2 * PF <= c.capn) ep += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
             v2u en[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) en[u] = ep[(size_t)(nn + u) * c.rows_pad];
+            for (int u = 0; u < PF; ++u) en[u] = ep[(size_t)u * c.rows_pad];
             float av[PF]; float4 yv4[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {                          // independent until folded: PF exp chains in flight per lane
@@ -734,8 +760,9 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
                 if (FLAT) av[u] = se_kernel_value_flat(xi, yv4[u], ck, act, gates);
                 else av[u] = act ? se_kernel_value_ck(xi, yv4[u], ck, gates) : 0.f;
             }
+            if (FLAT) asm volatile("; all four kernel values before the first fold" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
 #pragma unroll
-            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], rs, c, sbase, wcount, lane);
+            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, c, sbase, wcount, lane);
 #pragma unroll
             for (int u = 0; u < PF; ++u) eq[u] = en[u];
         }
@@ -781,12 +808,77 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
                 c.ent[(size_t)n * c.rows_pad + slot] = e;
                 a = se_kernel_value_ck(xi, yj, ck, gates);
             }
-            fold_entry(xi, yj, a, rs, c, sbase, wcount, lane);
+            fold_entry(xi, yj, a, ((unsigned)slot << 16) | (unsigned)j, rs, c, sbase, wcount, lane);
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * rs.sw[q]); acc8[3 + q] += (double)(inv_d * rs.sv[q]); }   // cvo.cpp:222-223
     }
     if (lane == 0) { sh->wcnt[wave] = wcount; acc8[6] = (double)wcount; }
+}
+
+// ---- R: ell has dropped: the lists shrink to the new radius in place.  The test is the cull's (same fused arithmetic on the
+// current positions), so the result is the list a dense cull would build now, with the colour factors it already carries.
+template <bool YLDS>
+__device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* sh, float nthr, int lane, int wave, int nwaves) {
+    int kept = 0;
+    const int nb = sh->wnb[wave];
+    for (int bi = 0; bi < nb; ++bi) {
+        const int slot = wave_block(bi, wave, nwaves) * 64 + lane;
+        const int len = L.lenS[slot];
+        int lw = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
+        float xi[3]; load_x(c, L, sh->x_lds != 0, slot, xi);
+        gv2u* wp = c.ent + slot;                                    // where the next kept entry goes: never ahead of the reads
+        const gv2u* ep = wp;
+        const size_t estep = (size_t)PF * c.rows_pad;
+        int cnt = 0;
+        v2u eq[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) eq[u] = ep[(size_t)u * c.rows_pad];
+        for (int n0 = 0; n0 < lw; n0 += PF) {
+            if (n0 + 2 * PF <= c.capn) ep += estep;                 // next step's entries: loaded before this step stores anything
+            v2u en[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) en[u] = ep[(size_t)u * c.rows_pad];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const bool act = n0 + u < len;
+                const int j = act ? (int)eq[u].y : 0;
+                const float4 y = YLDS ? L.ylds[j] : c.ybuf[j];
+                const float dx = xi[0] - y.x, dy = xi[1] - y.y, dz = xi[2] - y.z;
+                const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nthr)));
+                if (act && t < 0.f) { *wp = eq[u]; wp += c.rows_pad; ++cnt; }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) eq[u] = en[u];
+        }
+        L.lenS[slot] = (uint16_t)cnt;
+        kept += cnt;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    return kept;
+}
+
+static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
+    const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
+    const float Rb = r_c * (1.0f + sh->P.skin);
+    const float nthr = -(Rb * Rb * 1.00001f);                       // = the cull's threshold for this ell
+    for (int j = tid; j < c.nm; j += nthreads) c.ybuild.set(j, c.ybuf[j]);   // displacements count from here again
+    const int kept = y_lds ? refine_lists<true>(c, L, sh, nthr, lane, wave, nwaves) : refine_lists<false>(c, L, sh, nthr, lane, wave, nwaves);
+    if (lane == 0) sh->wsum[wave] = kept;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < nwaves; ++w) tot += sh->wsum[w];
+        sh->total = tot; sh->Rb = Rb; sh->ell_build = sh->ell; sh->refines += 1;
+    }
+    __syncthreads();
 }
 
 static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
@@ -797,7 +889,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
     const int nrows = c.nrows;
     const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
     const Gates gates = make_gates(sh->ell, sh->P);
-    const bool dense_mode = sh->dense_mode != 0, fresh_list = sh->rebuild != 0;
+    const bool dense_mode = sh->dense_mode != 0, fresh_list = sh->rebuild == 1;
     const float inv_c = 1 / sh->P.c, inv_d = 1 / sh->P.d;
     double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // omega[3], v[3], nnz, candidates
     const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
@@ -856,8 +948,8 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 }
 
 // ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
-static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int k_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), k = uni(k_in);
+static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tile); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6;
@@ -876,14 +968,16 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
             off[w] = (w < nwaves ? sh->wbase[w] : 0) - cum[w];
         }
         const int nsurv = cum[MAX_WAVES];
+        const bool x_lds = sh->x_lds != 0;
         for (int q = tid; q < nsurv; q += nthreads) {
             int o = off[0];
 #pragma unroll
             for (int w = 1; w < MAX_WAVES; ++w) o = (q >= cum[w]) ? off[w] : o;
-            const size_t at = c.fbase + (size_t)(q + o);
-            const float4 s0 = c.surv0[at], s1 = c.surv1[at];
-            const float xi[3] = {s0.x, s0.y, s0.z};
-            ls_terms(xi, s1, s0.w, ls, acc4[0], acc4[1], acc4[2], acc4[3]);
+            const v2u rec = c.surv[c.fbase + (size_t)(q + o)];
+            const int slot = (int)(rec.y >> 16), j = (int)(rec.y & 0xFFFFu);
+            float xi[3]; load_x(c, L, x_lds, slot, xi);
+            const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
+            ls_terms(xi, yj, __uint_as_float(rec.x), ls, acc4[0], acc4[1], acc4[2], acc4[3]);
         }
     } else {
         const Gates gates = make_gates(sh->ell, sh->P);
@@ -977,7 +1071,7 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
             const PairState* st = Dp->state_in;
             sh->stop = 0; sh->status = 0; sh->iter_at_break = st->iter; sh->nnz = 0; sh->cand = 0;
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
-            sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
+            sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
 
@@ -995,19 +1089,21 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
 
         for (; ok_pair && k < P.max_iter; ++k) {
             phase_transform(Dp, g, G, tile, y_lds);
-            if (sh->rebuild) {
+            if (sh->rebuild == 1) {
                 const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
                 phase_cull(Dp, g, G, tile);
                 const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
                 phase_sort(Dp, g, G, tile);
                 ticks[6] += t_b - t_a; ticks[8] += __builtin_amdgcn_s_memrealtime() - t_b;
+            } else if (sh->rebuild == 2) {
+                phase_refine(Dp, g, G, tile, y_lds);
             }
             CVO_PHASE(0);
             phase_candidates(Dp, g, G, tile, y_lds, k);
             cand_total += sh->cand;
             CVO_PHASE(1);
             if (sh->status != 0) break;
-            phase_linesearch(Dp, g, G, tile, k);
+            phase_linesearch(Dp, g, G, tile, y_lds, k);
             CVO_PHASE(3);
             if (sh->status != 0) break;
             phase_epilogue(Dp, g, tile, k);
