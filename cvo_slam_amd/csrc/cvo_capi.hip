@@ -73,7 +73,7 @@ struct PinBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
 };
 
-// a point cloud resident in HBM: n records of 8 floats {x,y,z,f0..f4}
+// a point cloud resident in HBM: two planes of n float4, {x,y,z,f0} then {f1..f4} (cvo_device.h)
 struct Cloud {
     DevBuf buf; int n = 0;
     float* rec() const { return static_cast<float*>(buf.p); }
@@ -107,7 +107,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
-    DevBuf d_descs, d_states, d_ybuf, d_ybuild, d_jT, d_ent, d_surv, d_xch, d_trace, d_tracelen, d_partials;
+    DevBuf d_descs, d_states, d_ybuf, d_jT, d_ent, d_surv, d_xch, d_trace, d_tracelen, d_partials;
     PinBuf h_descs, h_states, h_states_in, h_stage, h_partials;   // h_states: final states, written by the kernel itself (mapped pinned memory)
     std::vector<unsigned char> descs_uploaded;                     // what d_descs holds: unchanged descriptors are not sent again
     unsigned launch_seq = 0;
@@ -138,7 +138,7 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_ybuild, &d_jT, &d_ent, &d_surv, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -159,11 +159,11 @@ struct Engine {
         rc = h_stage.ensure(bytes); if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(stream));                       // staging buffer may still feed an earlier copy
         float* s = static_cast<float*>(h_stage.p);
-        for (int i = 0; i < n; ++i) {
-            s[(size_t)i * REC + 0] = xyz[(size_t)i * 3 + 0];
-            s[(size_t)i * REC + 1] = xyz[(size_t)i * 3 + 1];
-            s[(size_t)i * REC + 2] = xyz[(size_t)i * 3 + 2];
-            for (int ch = 0; ch < 5; ++ch) s[(size_t)i * REC + 3 + ch] = feat[(size_t)ch * n + i];
+        for (int i = 0; i < n; ++i) {                                // plane 0: {x, y, z, f0}; plane 1: {f1..f4}
+            float* lo = s + lo_off(i); float* hi = s + hi_off(n, i);
+            lo[0] = xyz[(size_t)i * 3 + 0]; lo[1] = xyz[(size_t)i * 3 + 1]; lo[2] = xyz[(size_t)i * 3 + 2];
+            lo[3] = feat[i];
+            for (int ch = 1; ch < 5; ++ch) hi[ch - 1] = feat[(size_t)ch * n + i];
         }
         HIP_TRY(hipMemcpyAsync(c.buf.p, s, bytes, hipMemcpyHostToDevice, stream));
         return CVO_OK;
@@ -219,7 +219,6 @@ struct Engine {
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
         const size_t plane = (size_t)(nf_pad + G) * capf;
         const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
-        if ((rc = d_ybuild.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
         int capn = 64; while (capn < nm_max / 8 && capn < 4096) capn *= 2;   // longest transposed row: 512 at 3k points, 2048 at 10k
         if (const char* e = std::getenv("CVO_HIP_ROW_CAP")) capn = std::max(1, std::atoi(e));
         capn = std::max(8, round_up(capn, 4));                               // the candidate phase reads entries four at a time, one step ahead
@@ -245,7 +244,6 @@ struct Engine {
             D.nm = pairs[i].moving ? pairs[i].moving->n : 0;
             D.nf_pad = nf_pad; D.rows_pad = rows_pad; D.capf = capf; D.nm_pad = nm_pad;
             D.ybuf = static_cast<float4*>(d_ybuf.p) + (size_t)i * G * nm_pad;
-            D.ybuild = static_cast<float4*>(d_ybuild.p) + (size_t)i * G * nm_pad;
             D.capn = capn;
             D.jT = static_cast<uint16_t*>(d_jT.p) + (size_t)i * tplane;
             D.ent = static_cast<uint2*>(d_ent.p) + (size_t)i * tplane;

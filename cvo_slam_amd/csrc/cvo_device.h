@@ -6,11 +6,13 @@
 
 namespace cvohip {
 
-// One point = 8 floats {x, y, z, f0, f1, f2, f3, f4}: the reference's position
-// (data_type.h:30) and 5-channel feature row (data_type.h:75) packed to 32 B so a
-// lane fetches a whole point with two 16-B loads and consecutive lanes stay
-// coalesced.
-constexpr int REC = 8;
+// A cloud of n points in HBM is two planes of n float4: {x, y, z, f0} -- the reference's position
+// (data_type.h:30) and the first channel of its 5-channel feature row (data_type.h:75), all that the
+// transform, the cull and the geometric half of the kernel value touch -- then {f1, f2, f3, f4}.
+// Consecutive lanes fetch consecutive 16-byte records of one plane.
+constexpr int REC = 8;                   // floats per point over both planes
+__host__ __device__ inline size_t lo_off(int i) { return (size_t)i * 4; }
+__host__ __device__ inline size_t hi_off(int n, int i) { return ((size_t)n + (size_t)i) * 4; }
 constexpr int MAX_ROWS_PER_WG = 4096;   // fixed-cloud rows one workgroup can own (LDS row-offset table)
 
 struct DevParams {           // cvo.cpp:35-51
@@ -56,14 +58,13 @@ struct TraceRow {        // == cvo_trace_row (include/cvo_hip.h)
 constexpr int XCH_WORDS = 16;
 
 struct PairDesc {
-    const float* fixed;      // [nf][REC]
-    const float* moving;     // [nm][REC]
+    const float* fixed;      // two planes of nf float4 (lo_off / hi_off)
+    const float* moving;     // two planes of nm float4
     int nf, nm;
     int nf_pad, nm_pad;      // multiples of 64
     int rows_pad;            // rows_per rounded up to 128: row stride of the transposed lists
     int capf;                // flat capacity per row, on average (a workgroup owning r rows may hold r*capf candidates)
-    float4* ybuf;            // [G][nm_pad]     transformed moving points {y0,y1,y2,g0}
-    float4* ybuild;          // [G][nm_pad]     the positions the candidate lists were built at
+    float4* ybuf;            // [G][nm_pad]     transformed moving points {y0,y1,y2,g0} (used when the cloud does not fit in LDS)
     // survivor planes: (nf_pad + G) * capf entries; workgroup g owns [g*rows_per*capf, (g+1)*rows_per*capf)
     int capn;                // longest row the transposed lists hold (longer => dense fallback)
     uint16_t* jT;            // [G][capn][rows_pad]  the cull's transposed lists: column of entry n of local row li, columns ascending
@@ -80,8 +81,8 @@ struct PairDesc {
 
 // score kernels (function_inner_product / se3_Hessian)
 struct ScoreDesc {
-    const float* a;          // [na][REC] queried cloud (positions optionally transformed by tran)
-    const float* b;          // [nb][REC] searched cloud
+    const float* a;          // two planes of na float4: queried cloud (positions optionally transformed by tran)
+    const float* b;          // two planes of nb float4: searched cloud
     int na, nb;
     float tran[12];
     int use_tran;

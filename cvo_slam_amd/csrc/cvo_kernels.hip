@@ -52,6 +52,7 @@ struct __attribute__((aligned(16))) Shared {
     float ell;
     float step;
     float M[12];
+    float Mb[12];          // the transform the candidate lists were built (or last filtered) under
     float Rb;              // radius they were built with
     float ell_build;
     float fred[MAX_WAVES];
@@ -422,7 +423,7 @@ __device__ __forceinline__ Lds lds_layout(int tile) {
 struct Ctx {
     const gfloat* fixed; const gfloat* moving;
     int nf, nm, nrows, rows_per, rows_pad, capn, nm_pad, flat_cap, g, G;
-    GF4 ybuf, ybuild; gv2u* surv;
+    GF4 ybuf; gv2u* surv;
     gu16* jT; gv2u* ent; gu64* xch;
     size_t fbase;
 };
@@ -435,7 +436,6 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     c.nrows = (g < c.nf) ? (c.nf - g + G - 1) / G : 0;
     c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
     c.ybuf = GF4{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
-    c.ybuild = GF4{(gv4f*)D.ybuild + (size_t)g * D.nm_pad};
     c.surv = (gv2u*)D.surv;
     c.jT = (gu16*)D.jT + (size_t)g * D.capn * D.rows_pad;
     c.ent = (gv2u*)D.ent + (size_t)g * D.capn * D.rows_pad;
@@ -448,7 +448,7 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
 // fixed point of a slot: from the LDS copy made after the sort, or gathered from the cloud
 __device__ __forceinline__ void load_x(const Ctx& c, const Lds& L, bool x_lds, int slot, float (&xi)[3]) {
     if (x_lds) { xi[0] = L.lx[slot]; xi[1] = L.ly[slot]; xi[2] = L.lz[slot]; }
-    else { const float4 lo = ld4(c.fixed + (size_t)(c.g + c.G * (int)L.row_of[slot]) * REC); xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; }
+    else { const float4 lo = ld4(c.fixed + lo_off(c.g + c.G * (int)L.row_of[slot])); xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; }
 }
 
 // ---- T: transform_pcd (cvo.cpp:336-341) into ybuf (+ the LDS-resident copy); how far has any point moved since
@@ -468,16 +468,20 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
         make_transform(R, T, M);                                    // update_tf, cvo.cpp:770
     }
     const bool have_list = sh->list_valid != 0;
+    float Mb[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Mb[i] = sh->Mb[i];
     float dmax2 = 0.f;
     for (int j = tid; j < c.nm; j += nthreads) {
-        const float4 lo = ld4(c.moving + (size_t)j * REC);
+        const float4 lo = ld4(c.moving + lo_off(j));
         float y0, y1, y2;
         apply_transform(M, lo.x, lo.y, lo.z, y0, y1, y2);
-        c.ybuf.set(j, make_float4(y0, y1, y2, lo.w));
-        if (y_lds) L.ylds[j] = make_float4(y0, y1, y2, lo.w);
-        if (have_list) {
-            const float4 yb = c.ybuild[j];
-            const float e0 = y0 - yb.x, e1 = y1 - yb.y, e2 = y2 - yb.z;
+        if (y_lds) L.ylds[j] = make_float4(y0, y1, y2, lo.w);       // the cloud stays in LDS for the whole iteration ...
+        else c.ybuf.set(j, make_float4(y0, y1, y2, lo.w));          // ... or, too large for that, in HBM/L2
+        if (have_list) {                                            // where the point was when the lists were built: the same arithmetic, then
+            float b0, b1, b2;
+            apply_transform(Mb, lo.x, lo.y, lo.z, b0, b1, b2);
+            const float e0 = y0 - b0, e1 = y1 - b1, e2 = y2 - b2;
             dmax2 = fmaxf(dmax2, __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)));
         }
     }
@@ -504,8 +508,8 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
 // the row's list jT[n][row] on the spot: no bitmap, no scan, no second pass.  Only 32-column groups whose bounding box
 // comes within the cull radius of the wave's rows' bounding box are tested at all (one lane per group decides, a ballot
 // turns the decisions into a scalar mask the wave then iterates).
-static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
+static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
     const Lds L = lds_layout(tile); Shared* sh = L.sh; uint16_t* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
@@ -526,7 +530,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             float4 y = make_float4(FAR_COL, FAR_COL, FAR_COL, 0.f);
             float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
             if (jj < tn) {
-                y = c.ybuf[t0 + jj]; c.ybuild.set(t0 + jj, y);
+                y = y_lds ? L.ylds[t0 + jj] : c.ybuf[t0 + jj];
                 lo[0] = hi[0] = y.x; lo[1] = hi[1] = y.y; lo[2] = hi[2] = y.z;
             }
             L.lx[jj] = y.x; L.ly[jj] = y.y; L.lz[jj] = y.z;
@@ -550,7 +554,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             for (int r = 0; r < SWEEP_R; ++r) {
                 li[r] = (b2 * SWEEP_R + r) * 64 + lane;
                 if (li[r] < nrows) {
-                    const float4 lo4 = ld4(c.fixed + (size_t)(g + G * li[r]) * REC);
+                    const float4 lo4 = ld4(c.fixed + lo_off(g + G * li[r]));
                     x[r][0] = lo4.x; x[r][1] = lo4.y; x[r][2] = lo4.z;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) { blo[q] = fminf(blo[q], x[r][q]); bhi[q] = fmaxf(bhi[q], x[r][q]); }
@@ -596,7 +600,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             for (int r = 0; r < SWEEP_R; ++r) rowlen[li[r]] = (uint16_t)cnt[r];   // rowlen has room for the padding rows of the last block pair
         }
     }
-    if (tid == 0) { sh->Rb = Rb; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1; }
+    if (tid == 0) { sh->Rb = Rb; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1; for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i]; }
     __syncthreads();
 }
 
@@ -691,7 +695,7 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
     const int xl = (nblk * 64 <= tile) ? 1 : 0;
     if (xl) {
         for (int sl = tid; sl < nblk * 64; sl += nthreads) {
-            const float4 lo = ld4(c.fixed + (size_t)(g + G * (int)L.row_of[sl]) * REC);
+            const float4 lo = ld4(c.fixed + lo_off(g + G * (int)L.row_of[sl]));
             L.lx[sl] = lo.x; L.ly[sl] = lo.y; L.lz[sl] = lo.z;
         }
     }
@@ -787,8 +791,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         int lw = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
-        const gfloat* xr = c.fixed + (size_t)(c.g + c.G * li) * REC;
-        const float4 lo = ld4(xr), hi = ld4(xr + 4);
+        const float4 lo = ld4(c.fixed + lo_off(c.g + c.G * li)), hi = ld4(c.fixed + hi_off(c.nf, c.g + c.G * li));
         const float xi[3] = {lo.x, lo.y, lo.z};
         const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
@@ -800,7 +803,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
             float a = 0.f; float4 yj = make_float4(0.f, 0.f, 0.f, 0.f);
             if (act) {
                 yj = YLDS ? L.ylds[j] : c.ybuf[j];
-                const float4 gh = ld4(c.moving + (size_t)j * REC + 4);
+                const float4 gh = ld4(c.moving + hi_off(c.nm, j));
                 const float fb[5] = {yj.w, gh.x, gh.y, gh.z, gh.w};
                 const float d2c = feat_d2(fi, fb);
                 const float ck = (d2c < gates.d2c_thres) ? (float)((double)gates.csig2 * exp_small((double)(-d2c) * gates.inv_den_c)) : __builtin_nanf("");
@@ -869,7 +872,6 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
     const float Rb = r_c * (1.0f + sh->P.skin);
     const float nthr = -(Rb * Rb * 1.00001f);                       // = the cull's threshold for this ell
-    for (int j = tid; j < c.nm; j += nthreads) c.ybuild.set(j, c.ybuf[j]);   // displacements count from here again
     const int kept = y_lds ? refine_lists<true>(c, L, sh, nthr, lane, wave, nwaves) : refine_lists<false>(c, L, sh, nthr, lane, wave, nwaves);
     if (lane == 0) sh->wsum[wave] = kept;
     __syncthreads();
@@ -877,6 +879,7 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
         int tot = 0;
         for (int w = 0; w < nwaves; ++w) tot += sh->wsum[w];
         sh->total = tot; sh->Rb = Rb; sh->ell_build = sh->ell; sh->refines += 1;
+        for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i];          // displacements count from here again
     }
     __syncthreads();
 }
@@ -908,14 +911,14 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
     } else {
         for (int li = tid; li < nrows; li += nthreads) {            // dense fallback: every column of the row
             const int i = g + G * li;
-            const float4 lo = ld4(c.fixed + (size_t)i * REC), hi = ld4(c.fixed + (size_t)i * REC + 4);
+            const float4 lo = ld4(c.fixed + lo_off(i)), hi = ld4(c.fixed + hi_off(c.nf, i));
             const float xi[3] = {lo.x, lo.y, lo.z};
             const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
             float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
             int nz = 0;
             for (int j = 0; j < c.nm; ++j) {
-                const float4 yj = c.ybuf[j];
-                const float a = se_kernel_value(xi, fi, yj, ld4(c.moving + (size_t)j * REC + 4), gates);
+                const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
+                const float a = se_kernel_value(xi, fi, yj, ld4(c.moving + hi_off(c.nm, j)), gates);
                 if (a > 0.f) {
                     const float yv[3] = {yj.x, yj.y, yj.z};
                     float cr[3]; cross3(xi, yv, cr);
@@ -983,13 +986,13 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
         const Gates gates = make_gates(sh->ell, sh->P);
         for (int li = tid; li < c.nrows; li += nthreads) {
             const int i = g + G * li;
-            const float4 lo = ld4(c.fixed + (size_t)i * REC), hi = ld4(c.fixed + (size_t)i * REC + 4);
+            const float4 lo = ld4(c.fixed + lo_off(i)), hi = ld4(c.fixed + hi_off(c.nf, i));
             const float xi[3] = {lo.x, lo.y, lo.z};
             const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
             double Bi = 0, Ci = 0, Di = 0, Ei = 0;
             for (int j = 0; j < c.nm; ++j) {
-                const float4 yj = c.ybuf[j];
-                const float A_ij = se_kernel_value(xi, fi, yj, ld4(c.moving + (size_t)j * REC + 4), gates);
+                const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
+                const float A_ij = se_kernel_value(xi, fi, yj, ld4(c.moving + hi_off(c.nm, j)), gates);
                 if (A_ij > 0.f) ls_terms(xi, yj, A_ij, ls, Bi, Ci, Di, Ei);
             }
             acc4[0] += Bi; acc4[1] += Ci; acc4[2] += Di; acc4[3] += Ei;
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
             phase_transform(Dp, g, G, tile, y_lds);
             if (sh->rebuild == 1) {
                 const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
-                phase_cull(Dp, g, G, tile);
+                phase_cull(Dp, g, G, tile, y_lds);
                 const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
                 phase_sort(Dp, g, G, tile);
                 ticks[6] += t_b - t_a; ticks[8] += __builtin_amdgcn_s_memrealtime() - t_b;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreDesc D, Dev
     float fa[5] = {0, 0, 0, 0, 0};
     const bool valid = i < D.na;
     if (valid) {
-        const float4 lo = ld4s(D.a + (size_t)i * REC), hi = ld4s(D.a + (size_t)i * REC + 4);
+        const float4 lo = ld4s(D.a + lo_off(i)), hi = ld4s(D.a + hi_off(D.na, i));
         if (D.use_tran) apply_transform(D.tran, lo.x, lo.y, lo.z, pa[0], pa[1], pa[2]);
         else { pa[0] = lo.x; pa[1] = lo.y; pa[2] = lo.z; }
         fa[0] = lo.w; fa[1] = hi.x; fa[2] = hi.y; fa[3] = hi.z; fa[4] = hi.w;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreDesc D, Dev
         __syncthreads();
         for (int jj = tid; jj < tn4; jj += SCORE_BLOCK) {
             float b0 = -3.0e18f, b1 = -3.0e18f, b2 = -3.0e18f;
-            if (jj < tn) { const float4 lo = ld4s(D.b + (size_t)(t0 + jj) * REC); b0 = lo.x; b1 = lo.y; b2 = lo.z; }
+            if (jj < tn) { const float4 lo = ld4s(D.b + lo_off(t0 + jj)); b0 = lo.x; b1 = lo.y; b2 = lo.z; }
             lx[jj] = b0; ly[jj] = b1; lz[jj] = b2;
         }
         __syncthreads();
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreDesc D, Dev
                 const float e0 = pa[0] - pb[0], e1 = pa[1] - pb[1], e2 = pa[2] - pb[2];
                 float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;            // nanoflann.hpp:403-406
                 if (!(d2 < d2_thres)) continue;                                      // cvo.cpp:423 / 654
-                const float4 blo = ld4s(D.b + (size_t)j * REC), bhi = ld4s(D.b + (size_t)j * REC + 4);
+                const float4 blo = ld4s(D.b + lo_off(j)), bhi = ld4s(D.b + hi_off(D.nb, j));
                 const float fb[5] = {blo.w, bhi.x, bhi.y, bhi.z, bhi.w};
                 float t[5];
 #pragma unroll
