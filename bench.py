@@ -230,9 +230,11 @@ def main():
         step_ms_rank = 1e3 * elapsed / args.steps          # one launch retires every step_ms_rank on this GPU
         overlap = k_ms / step_ms_rank                      # launches running side by side, on average
         traffic = None                                  # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_run.sh)
+        valu_instr = None                               # VALU wave-instructions one launch executes (same passes)
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = float(json.load(f)["hbm_bytes_per_launch"])
+                pmc = json.load(f)
+            traffic = float(pmc["hbm_bytes_per_launch"]); valu_instr = float(pmc.get("valu_wave_instructions_per_launch", 0)) or None
         except Exception:
             traffic = None
         out = {
@@ -254,9 +256,12 @@ def main():
                          "note": "achieved = algorithmic bytes of ONE launch / its own HIP-event duration; a launch holds 64 of 256 CUs and "
                                  "launches_side_by_side of them run at once, achieved_all_launches is the whole GPU's rate.  The path is "
                                  "latency/VALU bound, not HBM bound (SURVEY 8d): see valu and DESIGN.md"},
-            "valu": {"achieved": achieved_tf * overlap, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf * overlap / FP32_VALU_PEAK_TF,
-                     "algorithmic_flops_per_launch": flops_launch, "pair_tests_per_s": flops_launch / 8.0 / (k_ms * 1e-3) * overlap,
-                     "note": "algorithmic pair tests (dense N*M per iteration, two sweeps) of all launches in flight; the kernel skips most of them"},
+            "valu": {"dense_pair_tests_per_s": flops_launch / 8.0 / (step_ms_rank * 1e-3),
+                     "executed_wave_instructions_per_launch": valu_instr,
+                     "issue_slots_used": (valu_instr * 4.0 / (256 * 4 * 2.4e9 * step_ms_rank * 1e-3)) if valu_instr else None,
+                     "note": "issue_slots_used = VALU wave-instructions of one launch (SQ_INSTS_VALU, profiles/) x 4 cycles / (256 CUs x 4 SIMDs x 2.4 GHz x "
+                             "time per step): the share of the chip's plain-f32 issue slots the job keeps busy.  dense_pair_tests_per_s counts the "
+                             "N*M tests per iteration the reference's radius search stands for; the kernel skips most of them (lists + box cull)"},
         }
         if not args.no_cpu_baseline and world == 1:
             cores = host_threads()
