@@ -412,7 +412,7 @@ __device__ __forceinline__ Lds lds_layout(int tile) {
     L.hist = reinterpret_cast<int*>(L.rowlen + ROWS_LDS);
     L.base = L.hist + MAX_WAVES * NCLS;
     L.gbox = reinterpret_cast<float*>(L.base + MAX_WAVES * NCLS);
-    L.lx = L.gbox + 6 * (tile >> 5);
+    L.lx = L.gbox + 8 * (tile >> 5);
     L.ly = L.lx + tile; L.lz = L.ly + tile;
     L.ylds = reinterpret_cast<float4*>(L.lz + tile);
     return L;
@@ -519,7 +519,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     const float thr_cull = Rb * Rb * 1.00001f;
     const float thr_box = thr_cull * 1.001f;                        // box gaps are compared with a margin: a skipped group holds no hit
     const float nthr = -thr_cull;
-    const int gplane = tile >> 5;                                   // stride of the six bounding-box planes
+    const int gplane = tile >> 5;                                   // stride of the eight bounding-box planes: lo/hi of x, y, z and of y/z
     const int nblk2 = (nrows + 64 * SWEEP_R - 1) / (64 * SWEEP_R);  // row-block pairs of this workgroup
     const float INF = __builtin_inff();
     for (int t0 = 0; t0 < c.nm; t0 += tile) {
@@ -528,28 +528,31 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
         __syncthreads();                                            // previous tile fully consumed
         for (int jj = tid; jj < tnp; jj += nthreads) {              // a wave's half = one 32-column group
             float4 y = make_float4(FAR_COL, FAR_COL, FAR_COL, 0.f);
-            float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+            // box of the group in x, y, z and in the ray slope y/z: clouds come in image scan order, 32 consecutive points
+            // cover the whole width and depth range but only a few image rows
+            float lo[4] = {INF, INF, INF, INF}, hi[4] = {-INF, -INF, -INF, -INF};
             if (jj < tn) {
                 y = y_lds ? L.ylds[t0 + jj] : c.ybuf[t0 + jj];
                 lo[0] = hi[0] = y.x; lo[1] = hi[1] = y.y; lo[2] = hi[2] = y.z;
+                if (y.z > 1.0e-3f) { lo[3] = hi[3] = y.y / y.z; } else { lo[3] = -INF; hi[3] = INF; }   // behind / at the camera: no slope bound
             }
             L.lx[jj] = y.x; L.ly[jj] = y.y; L.lz[jj] = y.z;
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], off, 64)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], off, 64)); }
+                for (int q = 0; q < 4; ++q) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], off, 64)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], off, 64)); }
             }
             if ((lane & 31) == 0) {
                 const int gi = jj >> 5;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { L.gbox[q * gplane + gi] = lo[q]; L.gbox[(3 + q) * gplane + gi] = hi[q]; }
+                for (int q = 0; q < 4; ++q) { L.gbox[q * gplane + gi] = lo[q]; L.gbox[(4 + q) * gplane + gi] = hi[q]; }
             }
         }
         __syncthreads();
         const int ngr = tnp >> 5;
         for (int b2 = wave; b2 < nblk2; b2 += nwaves) {
             float x[SWEEP_R][3]; int li[SWEEP_R]; int cnt[SWEEP_R];
-            float blo[3] = {INF, INF, INF}, bhi[3] = {-INF, -INF, -INF};
+            float blo[4] = {INF, INF, INF, INF}, bhi[4] = {-INF, -INF, -INF, -INF};
 #pragma unroll
             for (int r = 0; r < SWEEP_R; ++r) {
                 li[r] = (b2 * SWEEP_R + r) * 64 + lane;
@@ -558,24 +561,32 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                     x[r][0] = lo4.x; x[r][1] = lo4.y; x[r][2] = lo4.z;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) { blo[q] = fminf(blo[q], x[r][q]); bhi[q] = fmaxf(bhi[q], x[r][q]); }
+                    if (lo4.z > 1.0e-3f) { const float t = lo4.y / lo4.z; blo[3] = fminf(blo[3], t); bhi[3] = fmaxf(bhi[3], t); }
+                    else { blo[3] = -INF; bhi[3] = INF; }
                 } else {
                     x[r][0] = x[r][1] = x[r][2] = FAR_ROW;
                 }
                 cnt[r] = (t0 == 0) ? 0 : rowlen[li[r]];
             }
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { blo[q] = wave_min(blo[q]); bhi[q] = wave_max(bhi[q]); }
+            for (int q = 0; q < 4; ++q) { blo[q] = wave_min(blo[q]); bhi[q] = wave_max(bhi[q]); }
+            // points p (a row), q (a column) within Rb of each other: |y_p/z_p - y_q/z_q| <= Rb (1 + |y_q/z_q|) / z_p
+            const float slope_reach = (blo[2] > 1.0e-3f) ? Rb * 1.01f / blo[2] : INF;
             for (int gb = 0; gb < ngr; gb += 64) {
                 bool near = false;
                 if (gb + lane < ngr) {
                     float gap2 = 0.f;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const float glo = L.gbox[q * gplane + gb + lane], ghi = L.gbox[(3 + q) * gplane + gb + lane];
+                        const float glo = L.gbox[q * gplane + gb + lane], ghi = L.gbox[(4 + q) * gplane + gb + lane];
                         const float d = fmaxf(0.f, fmaxf(glo - bhi[q], blo[q] - ghi));
                         gap2 = __builtin_fmaf(d, d, gap2);
                     }
-                    near = gap2 <= thr_box;                         // false for NaN (inf - inf of an all-padding group): skipped
+                    const float tlo = L.gbox[3 * gplane + gb + lane], thi = L.gbox[7 * gplane + gb + lane];
+                    const float tgap = fmaxf(0.f, fmaxf(tlo - bhi[3], blo[3] - thi));
+                    const float tabs = fmaxf(fabsf(tlo), fabsf(thi));
+                    // comparisons are false for NaN (inf - inf of an all-padding group): skipped
+                    near = (gap2 <= thr_box) && (tgap <= slope_reach * (1.0f + tabs) + 1.0e-6f);
                 }
                 unsigned long long mask = __ballot(near);
                 while (mask) {
@@ -1167,7 +1178,7 @@ int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
 // LDS: Shared | slot/row tables | sort histograms | group boxes | cull tile (3*tile floats) | resident y cloud (16 B * nm_pad, optional)
 size_t align_shared_bytes(int tile, int y_points) {
     return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)3 * ROWS_LDS * sizeof(uint16_t) + (size_t)2 * MAX_WAVES * NCLS * sizeof(int) +
-           (size_t)6 * (tile >> 5) * sizeof(float) + (size_t)3 * tile * sizeof(float) + (size_t)y_points * sizeof(float4);
+           (size_t)8 * (tile >> 5) * sizeof(float) + (size_t)3 * tile * sizeof(float) + (size_t)y_points * sizeof(float4);
 }
 int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 
