@@ -225,6 +225,15 @@ __device__ __forceinline__ double exp_poly13(double x) {
     p = __builtin_fma(p, x, 1.0);
     return p;
 }
+// exp(x) for x <= 0 of any size, branch-free: Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2, the same polynomial
+// (truncation 4e-18 at |r| = 0.35), scaled by 2^k with v_ldexp_f64.  ~1 ulp like libm's exp; the value is rounded to f32
+// right after (cvo.cpp:172-173).
+__device__ __forceinline__ double exp_neg(double x) {
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    return __builtin_ldexp(exp_poly13(r), (int)k);
+}
 __device__ __forceinline__ double exp_small(double x) {
     if (!(x >= -0.25 && x <= 0.0)) return exp(x);
     return exp_poly13(x);
@@ -788,8 +797,10 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
 }
 
 // the first iteration on new lists: columns come from the cull's raw lists (by row), the colour gate and factor
-// (cvo.cpp:169-173) are evaluated once and kept with the column in the slot-ordered entries
-template <bool YLDS>
+// (cvo.cpp:169-173) are evaluated once and kept with the column in the slot-ordered entries.  Three stages in flight per
+// lane: columns of step s+2 (gathered from the raw lists), second feature plane of the columns of step s+1, arithmetic
+// of step s.
+template <bool YLDS, bool FLAT>
 __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                            double (&acc8)[8]) {
     const size_t sbase = c.fbase + sh->wbase[wave];
@@ -806,23 +817,41 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         const float xi[3] = {lo.x, lo.y, lo.z};
         const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
-        int jn = len > 0 ? (int)c.jT[li] : 0;
-        for (int n = 0; n < lw; ++n) {
-            const bool act = n < len;
-            const int j = jn;
-            jn = (n + 1 < len) ? (int)c.jT[(size_t)(n + 1) * c.rows_pad + li] : 0;
-            float a = 0.f; float4 yj = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act) {
-                yj = YLDS ? L.ylds[j] : c.ybuf[j];
-                const float4 gh = ld4(c.moving + hi_off(c.nm, j));
-                const float fb[5] = {yj.w, gh.x, gh.y, gh.z, gh.w};
+        const gu16* jp = c.jT + li;                                 // entry n of this row: jp[n * rows_pad]
+        gv2u* ep = c.ent + slot;
+        const unsigned stag = (unsigned)slot << 16;
+        auto cols = [&](int n0, int (&jo)[PF]) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) jo[u] = (n0 + u < len) ? (int)jp[(size_t)(n0 + u) * c.rows_pad] : 0;
+        };
+        auto feats = [&](const int (&ji)[PF], float4 (&go)[PF]) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) go[u] = ld4(c.moving + hi_off(c.nm, ji[u]));
+        };
+        int j0[PF], j1[PF], j2[PF]; float4 g0[PF], g1[PF];
+        cols(0, j0); cols(PF, j1);
+        feats(j0, g0);
+        for (int n0 = 0; n0 < lw; n0 += PF) {
+            cols(n0 + 2 * PF, j2);
+            feats(j1, g1);
+            float av[PF]; float4 yv4[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const bool act = n0 + u < len;
+                const int j = j0[u];
+                yv4[u] = YLDS ? L.ylds[j] : c.ybuf[j];
+                const float fb[5] = {yv4[u].w, g0[u].x, g0[u].y, g0[u].z, g0[u].w};
                 const float d2c = feat_d2(fi, fb);
-                const float ck = (d2c < gates.d2c_thres) ? (float)((double)gates.csig2 * exp_small((double)(-d2c) * gates.inv_den_c)) : __builtin_nanf("");
-                v2u e; e.x = __float_as_uint(ck); e.y = (unsigned)j;
-                c.ent[(size_t)n * c.rows_pad + slot] = e;
-                a = se_kernel_value_ck(xi, yj, ck, gates);
+                const float ckv = (float)((double)gates.csig2 * exp_neg((double)(-d2c) * gates.inv_den_c));
+                const float ck = (d2c < gates.d2c_thres) ? ckv : __builtin_nanf("");
+                if (act) { v2u e; e.x = __float_as_uint(ck); e.y = (unsigned)j; ep[(size_t)(n0 + u) * c.rows_pad] = e; }
+                if (FLAT) av[u] = se_kernel_value_flat(xi, yv4[u], ck, act, gates);
+                else av[u] = act ? se_kernel_value_ck(xi, yv4[u], ck, gates) : 0.f;
             }
-            fold_entry(xi, yj, a, ((unsigned)slot << 16) | (unsigned)j, rs, c, sbase, wcount, lane);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (unsigned)j0[u], rs, c, sbase, wcount, lane);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { j0[u] = j1[u]; j1[u] = j2[u]; g0[u] = g1[u]; }
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * rs.sw[q]); acc8[3 + q] += (double)(inv_d * rs.sv[q]); }   // cvo.cpp:222-223
@@ -909,8 +938,13 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
     const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
     if (!dense_mode) {
         if (fresh_list) {
-            if (y_lds) cand_fresh<true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-            else cand_fresh<false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+            if (gates.poly_ok) {
+                if (y_lds) cand_fresh<true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+                else cand_fresh<false, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+            } else {
+                if (y_lds) cand_fresh<true, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+                else cand_fresh<false, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+            }
         } else if (gates.poly_ok) {
             if (y_lds) cand_steady<true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
             else cand_steady<false, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
