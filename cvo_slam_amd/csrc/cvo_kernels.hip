@@ -322,6 +322,14 @@ __device__ __forceinline__ LsConsts make_ls(const float* omega, const float* v, 
     L.s_beta = (float)(-2.0 * temp_coef); L.s_gamma = -temp_coef; L.s_delta = (float)(2.0 * temp_coef);
     return L;
 }
+// x / 6.0 correctly rounded without the division sequence: q = RN(x * RN(1/6)), r = x - 6 q exactly (fma), q + r * RN(1/6)
+// (the quotient by a constant c is right whenever q is within an ulp and x / c is no rounding tie, which x / 6 never is)
+__device__ __forceinline__ double div6(double x) {
+    const double y = 1.0 / 6.0;
+    const double q = x * y;
+    const double r = __builtin_fma(-6.0, q, x);
+    return __builtin_fma(r, y, q);
+}
 // one nonzero of A: adds its B, C, D, E terms (cvo.cpp:282-306)
 __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float A_ij, const LsConsts& L, double& Bi, double& Ci, double& Di, double& Ei) {
     const float y[3] = {yj.x, yj.y, yj.z};
@@ -340,7 +348,7 @@ __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float
     const float epsil_ij = L.s_gamma * (econst + sum3f((2.f * z4[0]) * df[0], (2.f * z4[1]) * df[1], (2.f * z4[2]) * df[2]));    // cvo.cpp:296-297
     Bi += double(A_ij * beta_ij);                                                                                              // cvo.cpp:301
     Ci += double(A_ij * (gamma_ij + beta_ij * beta_ij / 2.0));                                                                 // cvo.cpp:302
-    Di += double(A_ij * (delta_ij + beta_ij * gamma_ij + beta_ij * beta_ij * beta_ij / 6.0));                                  // cvo.cpp:303
+    Di += double(A_ij * (delta_ij + beta_ij * gamma_ij + div6((double)(beta_ij * beta_ij * beta_ij))));                        // cvo.cpp:303
     Ei += double(A_ij * (epsil_ij + beta_ij * delta_ij + 1 / 2.0 * beta_ij * beta_ij * gamma_ij                                // cvo.cpp:304-305
                          + 1 / 2.0 * gamma_ij * gamma_ij + 1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij));
 }
@@ -1007,21 +1015,14 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
     const LsConsts ls = make_ls(omega, v, sh->ell);
     double acc4[4] = {0, 0, 0, 0};
     if (!sh->dense_mode) {
-        // the waves' survivor segments, walked as one index space (one round of load latency, not one per segment)
-        int cum[MAX_WAVES + 1], off[MAX_WAVES];
-        cum[0] = 0;
-#pragma unroll
-        for (int w = 0; w < MAX_WAVES; ++w) {
-            cum[w + 1] = cum[w] + (w < nwaves ? sh->wcnt[w] : 0);
-            off[w] = (w < nwaves ? sh->wbase[w] : 0) - cum[w];
-        }
-        const int nsurv = cum[MAX_WAVES];
+        // every wave walks the nonzeros it compacted itself: the candidate phase deals the rows so that the waves' shares are
+        // near equal, and a wave's segment is one contiguous run
         const bool x_lds = sh->x_lds != 0;
-        for (int q = tid; q < nsurv; q += nthreads) {
-            int o = off[0];
-#pragma unroll
-            for (int w = 1; w < MAX_WAVES; ++w) o = (q >= cum[w]) ? off[w] : o;
-            const v2u rec = c.surv[c.fbase + (size_t)(q + o)];
+        const int wave = tid >> 6;
+        const int cnt_w = sh->wcnt[wave];
+        const gv2u* sp = c.surv + c.fbase + (size_t)sh->wbase[wave];
+        for (int q = lane; q < cnt_w; q += 64) {
+            const v2u rec = sp[q];
             const int slot = (int)(rec.y >> 16), j = (int)(rec.y & 0xFFFFu);
             float xi[3]; load_x(c, L, x_lds, slot, xi);
             const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
