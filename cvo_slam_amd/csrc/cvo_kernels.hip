@@ -1021,8 +1021,10 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
         const int wave = tid >> 6;
         const int cnt_w = sh->wcnt[wave];
         const gv2u* sp = c.surv + c.fbase + (size_t)sh->wbase[wave];
+        v2u rnext = sp[min(lane, max(cnt_w - 1, 0))];
         for (int q = lane; q < cnt_w; q += 64) {
-            const v2u rec = sp[q];
+            const v2u rec = rnext;
+            rnext = sp[min(q + 64, cnt_w - 1)];                     // next record in flight behind this one's arithmetic
             const int slot = (int)(rec.y >> 16), j = (int)(rec.y & 0xFFFFu);
             float xi[3]; load_x(c, L, x_lds, slot, xi);
             const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
