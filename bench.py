@@ -84,23 +84,41 @@ def host_threads() -> int:
 
 def cpu_baseline(pairs, threads, budget_s=20.0):
     """Oracle (CPU restatement with the reference's structure: KD-tree rebuilt every
-    iteration, row-parallel loops) on the host cores, on as many of the batch's pairs as
-    fit in ~budget_s seconds.  Returns align/s, seconds, transforms, iteration counts."""
+    iteration, row-parallel loops) on the host cores.  Pass 1 aligns as many of the batch's
+    pairs as fit in ~budget_s seconds once each (their transforms are the parity check);
+    the first 16 pairs are then repeated four more times (rate = median of the five passes over
+    those 16) and the first 3 pairs once on a single thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     po.build()
-    tfs, iters = [], []
-    t0 = time.perf_counter()
-    for (_, fx, ff, mx, mf) in pairs:
-        o = po.OracleCvo(search=po.SEARCH_KDTREE, threads=threads)
-        o.set_pcd(fx, ff); o.set_pcd(mx, mf)
-        o.align()
-        st = o.get_state()
-        tfs.append(st["transform"].copy()); iters.append(st["iter"] + 1)
-        if time.perf_counter() - t0 > budget_s:
+
+    def run(sel, nthreads):
+        tfs, iters = [], []
+        t0 = time.perf_counter()
+        for (_, fx, ff, mx, mf) in sel:
+            o = po.OracleCvo(search=po.SEARCH_KDTREE, threads=nthreads)
+            o.set_pcd(fx, ff); o.set_pcd(mx, mf)
+            o.align()
+            st = o.get_state()
+            tfs.append(st["transform"].copy()); iters.append(st["iter"] + 1)
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return tfs, iters, time.perf_counter() - t0
+
+    sub = pairs[: min(16, len(pairs))]
+    t_all0 = time.perf_counter()
+    tfs_s, it_s, dt_s = run(sub, threads)                               # pass 1, first 16
+    tfs_r, it_r, dt_r = run(pairs[len(sub):], threads) if len(pairs) > len(sub) else ([], [], 0.0)
+    rates = [len(tfs_s) / dt_s]
+    for _ in range(4):
+        if time.perf_counter() - t_all0 > 1.5 * budget_s:
             break
-    dt = time.perf_counter() - t0
-    return len(tfs) / dt, dt, tfs, iters
+        r_tfs, _, r_dt = run(sub, threads)
+        rates.append(len(r_tfs) / r_dt)
+    one = pairs[: min(3, len(pairs))]
+    o_tfs, _, o_dt = run(one, 1)
+    return dict(rate=float(np.median(rates)), rates=rates, first_pass_rate=(len(tfs_s) + len(tfs_r)) / (dt_s + dt_r), seconds=time.perf_counter() - t_all0,
+                tfs=tfs_s + tfs_r, iters=it_s + it_r, single_thread_rate=len(o_tfs) / o_dt, single_thread_pairs=len(o_tfs))
 
 
 def main():
@@ -266,11 +284,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cores = host_threads()
             print(f"[bench] GPU done ({value:.1f} alignments/s); timing the CPU baseline on {cores} threads ...", file=sys.stderr, flush=True)
-            cpu_rate, cpu_dt, cpu_tfs, cpu_its = cpu_baseline(pairs, cores)
+            cb = cpu_baseline(pairs, cores)
+            cpu_rate, cpu_tfs, cpu_its = cb["rate"], cb["tfs"], cb["iters"]
             errs = [rot_trans_err(results[i]["transform"], cpu_tfs[i]) for i in range(len(cpu_tfs))]
             out["cpu_baseline"] = {"value": cpu_rate, "unit": "alignments/s", "cores": cores, "kind": "port",
-                                   "sample": f"the first {len(cpu_tfs)} pairs of the timed batch, once each, oracle (KD-tree rebuilt per iteration, "
-                                             f"OpenMP rows) on {cores} host threads, {cpu_dt:.1f} s",
+                                   "sample": f"oracle (CPU restatement of the reference: KD-tree rebuilt per iteration, OpenMP rows; not the icpc binary) on "
+                                             f"{cores} host threads: {len(cpu_tfs)} pairs of the timed batch once each (parity check, {cb['first_pass_rate']:.1f}/s), "
+                                             f"value = median of {len(cb['rates'])} passes over the first 16 pairs; {cb['seconds']:.1f} s in all",
+                                   "passes": cb["rates"], "single_thread_value": cb["single_thread_rate"], "single_thread_pairs": cb["single_thread_pairs"],
                                    "iterations_mean": float(np.mean(cpu_its))}
             out["parity"] = {"pairs_checked": len(errs), "max_rot_err_rad": max(e[0] for e in errs), "max_trans_err_m": max(e[1] for e in errs),
                              "iterations_equal": bool(all(a == b for a, b in zip(its, cpu_its))), "tolerance": "1e-4 rad / 1e-4 m"}

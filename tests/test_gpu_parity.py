@@ -129,7 +129,10 @@ def test_workgroup_counts_tiles_and_overflow_fallback_agree(hiplib, oracle):
     ost = o.get_state()
     configs = [dict(wgs=1), dict(wgs=2), dict(wgs=7), dict(wgs=32), dict(wgs=1, CVO_HIP_TILE=128), dict(wgs=4, CVO_HIP_TILE=252),
                dict(wgs=1, CVO_HIP_FLAT_CAP=4), dict(wgs=5, CVO_HIP_FLAT_CAP=1, CVO_HIP_TILE=64), dict(wgs=3, CVO_HIP_FLAT_CAP=1),
-               dict(wgs=2, CVO_HIP_SKIN=0.0), dict(wgs=2, CVO_HIP_SKIN=0.02), dict(wgs=4, CVO_HIP_SKIN=1.5)]
+               dict(wgs=2, CVO_HIP_SKIN=0.0), dict(wgs=2, CVO_HIP_SKIN=0.02), dict(wgs=4, CVO_HIP_SKIN=1.5),
+               dict(wgs=1, CVO_HIP_NO_YLDS=1), dict(wgs=3, CVO_HIP_NO_YLDS=1, CVO_HIP_TILE=128),          # transformed cloud in HBM/L2, not LDS
+               dict(wgs=1, CVO_HIP_ROW_CAP=8), dict(wgs=2, CVO_HIP_ROW_CAP=16, CVO_HIP_SKIN=0.6),         # rows longer than the lists hold
+               dict(wgs=1, CVO_HIP_WGS_PER_CU=2)]                                                          # two 256-thread workgroups per CU
     for cfg in configs:
         envs = {k: v for k, v in cfg.items() if k.startswith("CVO_")}
         with env(**envs):
@@ -157,6 +160,27 @@ def test_full_size_pair_fresh_vs_oracle(hiplib, oracle):
     aa = g.function_inner_product(hiplib.api.SLOT_FIXED, None, hiplib.api.SLOT_FIXED)
     assert aa[1] >= p.fixed.n and aa[0] >= p.fixed.n * 0.01 * (1 - 1e-6)                         # every point pairs with itself: k*ck = sigma^2
     g.close()
+
+
+def test_eth3d_shape_pair_tile_sweep(hiplib, oracle):
+    """BASELINE config 5: ETH3D-shape 736x456 pair, ~9 k points per cloud (dense sampling).  The transformed cloud no longer
+    fits in LDS (HBM/L2 path), a workgroup owns at most 4096 rows (G >= 3), and the cull tile is swept over
+    512 ... 4096 columns: every setting must land on the oracle's pose, iteration count and final nnz."""
+    from cvo_slam_amd import synth
+    p = synth.make_pair(2, cam=synth.ETH3D)
+    assert p.fixed.n > 8000 and p.moving.n > 8000
+    fixed, moving = (p.fixed.xyz, p.fixed.feat), (p.moving.xyz, p.moving.feat)
+    o = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8)
+    o.set_pcd(*fixed); o.set_pcd(*moving); rc, _ = o.align(); assert rc == 0
+    ost = o.get_state()
+    for cfg in [dict(wgs=0), dict(wgs=3, CVO_HIP_TILE=512), dict(wgs=4, CVO_HIP_TILE=1024), dict(wgs=8, CVO_HIP_TILE=2048), dict(wgs=32, CVO_HIP_TILE=4096)]:
+        envs = {k: v for k, v in cfg.items() if k.startswith("CVO_")}
+        with env(**envs):
+            g, _ = gpu_align(hiplib, fixed, moving, wgs=cfg["wgs"])
+        re, te = rot_trans_err(g.transform, ost["transform"])
+        assert re <= 1e-6 and te <= 1e-6, (cfg, re, te)
+        assert g.get_iteration_number() == ost["iter"] and g.get_A_nonzero() == ost["A_nonzero"], cfg
+        g.close()
 
 
 # ----------------------------------------------------------------------------- scores
