@@ -27,9 +27,9 @@ int align_blocks_per_cu();
 hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         unsigned launch_tag, const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
-int score_grid(int na);
 int score_nout();
-hipError_t launch_score(const ScoreDesc& D, const DevParams& P, double* partials, hipStream_t stream);
+int score_row_blocks(int na);
+hipError_t launch_score(const ScoreBatch& B, int row_blocks, int chunks, const DevParams& P, double* partials, double* out_pinned, hipStream_t stream);
 }  // namespace cvohip
 
 using namespace cvohip;
@@ -173,7 +173,13 @@ struct Engine {
 
     int pick_workgroups(int n_pairs, int nf_max) const {
         int G = wg_request;
-        if (G <= 0) { G = 1; while (G * 2 * n_pairs <= num_cus * per_cu && G < 32) G *= 2; }
+        if (G <= 0) {
+            // lowest latency of this launch alone: as many workgroups per pair as the CUs allow, but not below ~768 rows per
+            // workgroup -- beyond that the partial-sum exchanges cost more than the shorter phases save (measured at 3072 points:
+            // 2.4 ms at 4, 2.5 at 8, 2.8 at 16, 3.6 at 32, 4.9 at 1)
+            int want = 1; while (want * 2 * 768 <= nf_max && want < 32) want *= 2;
+            G = 1; while (G * 2 * n_pairs <= num_cus * per_cu && G < want) G *= 2;
+        }
         const int g_min = (nf_max + MAX_ROWS_PER_WG - 1) / MAX_ROWS_PER_WG;     // a workgroup owns at most MAX_ROWS_PER_WG rows
         G = std::max(std::max(1, g_min), std::min(G, num_cus));
         return G;
@@ -298,24 +304,34 @@ struct Engine {
     const PairState* results() const { return static_cast<const PairState*>(h_states.p); }
 
     // function_inner_product / se3_Hessian: out[0]=sum_A, out[1]=count, out[2..22]=Hessian terms
-    int score(const Cloud& a, const float* tran, const Cloud& b, float ell, bool hessian, double out[24]) {
+    // A score block: up to SCORE_MAXREQ function_inner_product / se3_Hessian evaluations in one launch.
+    // out[r][0] = sum_A, out[r][1] = pair count, out[r][2..22] = Hessian terms.
+    struct ScoreReq { const Cloud* a; const float* tran; const Cloud* b; bool hessian; };
+    int score_many(const ScoreReq* rq, int n, float ell, double (*out)[24]) {
         HIP_TRY(hipSetDevice(device));
-        if (a.n <= 0 || b.n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "empty cloud");
-        ScoreDesc D;
-        D.a = a.rec(); D.b = b.rec(); D.na = a.n; D.nb = b.n; D.ell = ell; D.want_hessian = hessian ? 1 : 0; D.out = nullptr;
-        D.use_tran = tran ? 1 : 0;
-        for (int i = 0; i < 12; ++i) D.tran[i] = tran ? tran[i] : 0.f;
-        const int grid = score_grid(a.n), nout = score_nout();
+        if (n <= 0 || n > SCORE_MAXREQ) return fail(CVO_ERR_INVALID, "bad score request count");
+        ScoreBatch B; std::memset(&B, 0, sizeof(B));
+        B.n = n;
+        int row_blocks = 1;
+        for (int r = 0; r < n; ++r) {
+            if (!rq[r].a || !rq[r].b || rq[r].a->n <= 0 || rq[r].b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "empty cloud");
+            ScoreDesc& D = B.d[r];
+            D.a = rq[r].a->rec(); D.b = rq[r].b->rec(); D.na = rq[r].a->n; D.nb = rq[r].b->n; D.ell = ell;
+            D.want_hessian = rq[r].hessian ? 1 : 0; D.out = nullptr;
+            D.use_tran = rq[r].tran ? 1 : 0;
+            for (int i = 0; i < 12; ++i) D.tran[i] = rq[r].tran ? rq[r].tran[i] : 0.f;
+            row_blocks = std::max(row_blocks, score_row_blocks(D.na));
+        }
+        const int nout = score_nout();
+        const int chunks = std::max(1, std::min(16, 4 * num_cus / std::max(1, row_blocks * n)));   // ~4 workgroups (waves) per CU
         int rc;
-        if ((rc = d_partials.ensure(sizeof(double) * (size_t)grid * nout))) return rc;
-        if ((rc = h_partials.ensure(sizeof(double) * (size_t)grid * nout))) return rc;
-        hipError_t e = launch_score(D, P, static_cast<double*>(d_partials.p), stream);
+        if ((rc = d_partials.ensure(sizeof(double) * (size_t)n * row_blocks * chunks * nout))) return rc;
+        if ((rc = h_partials.ensure(sizeof(double) * (size_t)SCORE_MAXREQ * nout))) return rc;
+        hipError_t e = launch_score(B, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), stream);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("score kernel launch: ") + hipGetErrorString(e));
-        HIP_TRY(hipMemcpyAsync(h_partials.p, d_partials.p, sizeof(double) * (size_t)grid * nout, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         const double* hp = static_cast<const double*>(h_partials.p);
-        for (int q = 0; q < 24; ++q) out[q] = 0;
-        for (int g = 0; g < grid; ++g) for (int q = 0; q < nout && q < 24; ++q) out[q] += hp[(size_t)g * nout + q];
+        for (int r = 0; r < n; ++r) for (int q = 0; q < 24; ++q) out[r][q] = q < nout ? hp[(size_t)r * nout + q] : 0.0;
         return CVO_OK;
     }
 };
@@ -561,14 +577,21 @@ int cvo_match_keyframe(cvo_handle h, const float* xyz, const float* feat, int n,
     return cvo_match_odometry(h, xyz, feat, n, transform_out);       // cvo.cpp:563-576 is the same body
 }
 
+namespace {
+void finish_inn_p(const double r[24], cvo_inn_p* out) {
+    double sum = r[1]; if (sum == 0) sum = 1;                        // cvo.cpp:455-456
+    out->value = (float)r[0]; out->num = (int)sum; out->num_e = 0;   // cvo.cpp:457
+}
+}  // namespace
+
 int cvo_function_inner_product(cvo_handle h, int slot_a, const float* tran_a, int slot_b, cvo_inn_p* out) {
     if (!h || !out) return fail(CVO_ERR_INVALID, "null argument");
     Cloud* a = slot_cloud(h, slot_a); Cloud* b = slot_cloud(h, slot_b);
     if (!a || !b || a->n <= 0 || b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "function_inner_product: empty cloud slot");
-    double r[24];
-    int rc = h->eng.score(*a, tran_a, *b, h->ell, false, r); if (rc) return rc;
-    double sum = r[1]; if (sum == 0) sum = 1;                        // cvo.cpp:455-456
-    out->value = (float)r[0]; out->num = (int)sum; out->num_e = 0;   // cvo.cpp:457
+    double r[1][24];
+    const Engine::ScoreReq rq[1] = {{a, tran_a, b, false}};
+    int rc = h->eng.score_many(rq, 1, h->ell, r); if (rc) return rc;
+    finish_inn_p(r[0], out);
     return CVO_OK;
 }
 
@@ -576,24 +599,33 @@ int cvo_se3_hessian(cvo_handle h, int slot_a, const float* tran_a, int slot_b, d
     if (!h || !H || !inliers) return fail(CVO_ERR_INVALID, "null argument");
     Cloud* a = slot_cloud(h, slot_a); Cloud* b = slot_cloud(h, slot_b);
     if (!a || !b || a->n <= 0 || b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "se3_Hessian: empty cloud slot");
-    double r[24];
-    int rc = h->eng.score(*a, tran_a, *b, h->ell, true, r); if (rc) return rc;
-    *inliers += (int)r[1];                                           // cvo.cpp:708 increments the caller's variable
-    finish_hessian(r + 2, *inliers, H);
+    double r[1][24];
+    const Engine::ScoreReq rq[1] = {{a, tran_a, b, true}};
+    int rc = h->eng.score_many(rq, 1, h->ell, r); if (rc) return rc;
+    *inliers += (int)r[0][1];                                        // cvo.cpp:708 increments the caller's variable
+    finish_hessian(r[0] + 2, *inliers, H);
     return CVO_OK;
 }
 
+// The whole score block of the tracker is one launch (the reference runs 4 KD-tree builds + 5 sweeps, cvo.cpp:489-500).
 int cvo_compute_innerproduct(cvo_handle h, cvo_inn_p* inn_pre, cvo_inn_p* inn_post, double post_hessian[36], const float tran[12],
                              int* inliers, cvo_inn_p* inn_fixed_pcd, cvo_inn_p* inn_moving_pcd, float* cos_angle) {
     if (!h || !inn_pre || !inn_post || !post_hessian || !tran || !inliers || !inn_fixed_pcd || !inn_moving_pcd || !cos_angle)
         return fail(CVO_ERR_INVALID, "null argument");
-    int rc;
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, nullptr, CVO_SLOT_FIXED, inn_pre))) return rc;       // cvo.cpp:489
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, tran, CVO_SLOT_FIXED, inn_post))) return rc;         // cvo.cpp:491
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_FIXED, nullptr, CVO_SLOT_FIXED, inn_fixed_pcd))) return rc;  // cvo.cpp:496
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, nullptr, CVO_SLOT_MOVING, inn_moving_pcd))) return rc;   // cvo.cpp:497
+    Cloud* fx = slot_cloud(h, CVO_SLOT_FIXED); Cloud* mv = slot_cloud(h, CVO_SLOT_MOVING);
+    if (!fx || !mv || fx->n <= 0 || mv->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "function_inner_product: empty cloud slot");
+    const Engine::ScoreReq rq[5] = {{mv, nullptr, fx, false},        // cvo.cpp:489
+                                    {mv, tran, fx, false},           // cvo.cpp:491
+                                    {fx, nullptr, fx, false},        // cvo.cpp:496
+                                    {mv, nullptr, mv, false},        // cvo.cpp:497
+                                    {mv, tran, fx, true}};           // cvo.cpp:500
+    double r[5][24];
+    int rc = h->eng.score_many(rq, 5, h->ell, r); if (rc) return rc;
+    finish_inn_p(r[0], inn_pre); finish_inn_p(r[1], inn_post); finish_inn_p(r[2], inn_fixed_pcd); finish_inn_p(r[3], inn_moving_pcd);
     *cos_angle = inn_post->value / (sqrtf(inn_fixed_pcd->value) * sqrtf(inn_moving_pcd->value));                  // cvo.cpp:498
-    return cvo_se3_hessian(h, CVO_SLOT_MOVING, tran, CVO_SLOT_FIXED, post_hessian, inliers);                      // cvo.cpp:500
+    *inliers += (int)r[4][1];                                        // cvo.cpp:708
+    finish_hessian(r[4] + 2, *inliers, post_hessian);
+    return CVO_OK;
 }
 
 int cvo_compute_innerproduct_lc(cvo_handle h, cvo_inn_p* inn_prior, cvo_inn_p* inn_lc_prior, cvo_inn_p* inn_lc_pre, cvo_inn_p* inn_lc_post,
@@ -603,19 +635,25 @@ int cvo_compute_innerproduct_lc(cvo_handle h, cvo_inn_p* inn_prior, cvo_inn_p* i
     if (!h || !inn_prior || !inn_lc_prior || !inn_lc_pre || !inn_lc_post || !post_hessian || !prior_tran || !lc_prior_tran ||
         !lc_prior_tran_2 || !lc_tran || !inliers_svd || !inliers_pnpransac || !inn_fixed_pcd || !inn_moving_pcd || !cos_angle)
         return fail(CVO_ERR_INVALID, "null argument");
-    int rc;
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, prior_tran, CVO_SLOT_FIXED, inn_prior))) return rc;          // cvo.cpp:539
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, lc_prior_tran, CVO_SLOT_FIXED, inn_lc_prior))) return rc;    // cvo.cpp:541
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, nullptr, CVO_SLOT_FIXED, inn_lc_pre))) return rc;            // cvo.cpp:543
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, lc_tran, CVO_SLOT_FIXED, inn_lc_post))) return rc;           // cvo.cpp:545
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_FIXED, nullptr, CVO_SLOT_FIXED, inn_fixed_pcd))) return rc;          // cvo.cpp:550
-    if ((rc = cvo_function_inner_product(h, CVO_SLOT_MOVING, nullptr, CVO_SLOT_MOVING, inn_moving_pcd))) return rc;       // cvo.cpp:551
+    Cloud* fx = slot_cloud(h, CVO_SLOT_FIXED); Cloud* mv = slot_cloud(h, CVO_SLOT_MOVING);
+    if (!fx || !mv || fx->n <= 0 || mv->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "function_inner_product: empty cloud slot");
+    const Engine::ScoreReq rq[8] = {{mv, prior_tran, fx, false},     // cvo.cpp:539
+                                    {mv, lc_prior_tran, fx, false},  // cvo.cpp:541
+                                    {mv, nullptr, fx, false},        // cvo.cpp:543
+                                    {mv, lc_tran, fx, false},        // cvo.cpp:545
+                                    {fx, nullptr, fx, false},        // cvo.cpp:550
+                                    {mv, nullptr, mv, false},        // cvo.cpp:551
+                                    {mv, lc_tran, fx, true},         // cvo.cpp:555
+                                    {mv, lc_prior_tran_2, fx, true}};   // cvo.cpp:558
+    double r[8][24];
+    int rc = h->eng.score_many(rq, 8, h->ell, r); if (rc) return rc;
+    finish_inn_p(r[0], inn_prior); finish_inn_p(r[1], inn_lc_prior); finish_inn_p(r[2], inn_lc_pre); finish_inn_p(r[3], inn_lc_post);
+    finish_inn_p(r[4], inn_fixed_pcd); finish_inn_p(r[5], inn_moving_pcd);
     *cos_angle = inn_lc_post->value / (sqrtf(inn_fixed_pcd->value) * sqrtf(inn_moving_pcd->value));                       // cvo.cpp:552
-    *inliers_svd = 0;                                                                                                     // cvo.cpp:554
-    if ((rc = cvo_se3_hessian(h, CVO_SLOT_MOVING, lc_tran, CVO_SLOT_FIXED, post_hessian, inliers_svd))) return rc;        // cvo.cpp:555
-    double Hdummy[36];
-    *inliers_pnpransac = 0;                                                                                               // cvo.cpp:557
-    return cvo_se3_hessian(h, CVO_SLOT_MOVING, lc_prior_tran_2, CVO_SLOT_FIXED, Hdummy, inliers_pnpransac);               // cvo.cpp:558
+    *inliers_svd = (int)r[6][1];                                                                                          // cvo.cpp:554-555
+    finish_hessian(r[6] + 2, *inliers_svd, post_hessian);
+    *inliers_pnpransac = (int)r[7][1];                                                                                    // cvo.cpp:557-558 (only the inlier count is used)
+    return CVO_OK;
 }
 
 int cvo_update_fixed_pcd(cvo_handle h) { if (!h) return fail(CVO_ERR_INVALID, "null handle"); h->fixed = std::move(h->moving); return CVO_OK; }

@@ -91,4 +91,11 @@ struct ScoreDesc {
     double* out;
 };
 
+// a score block: up to 8 inner-product / Hessian requests evaluated by one launch
+constexpr int SCORE_MAXREQ = 8;
+struct ScoreBatch {
+    ScoreDesc d[SCORE_MAXREQ];
+    int n;
+};
+
 }  // namespace cvohip

@@ -1,13 +1,17 @@
 // cvo_score_kernels.hip -- function_inner_product (cvo.cpp:388-459) and
-// se3_Hessian (cvo.cpp:620-759) as one tiled all-pairs kernel.
+// se3_Hessian (cvo.cpp:620-759) as one tiled all-pairs kernel; a whole score block
+// (compute_innerproduct: 4 inner products + 1 Hessian, cvo.cpp:475-503; the loop-closure
+// variant: 6 + 2, cvo.cpp:505-561) is ONE launch.
 //
-// Thread = one point of cloud a (optionally transformed first, cvo.cpp:485-487);
-// cloud b streams through LDS tiles (SoA positions, broadcast reads).  The radius
-// gate IS binding here (no a>sp_thres test, Q6), so the fused cull is followed by
-// the reference's own un-fused d2 expression before a pair counts.  Per-row sums
-// are f32 (the reference keeps an f32 Hessian, cvo.cpp:622,707), rows are added in
-// f64 and written as one partial record per workgroup; the host adds the records
-// in workgroup order, so results are reproducible run to run.
+// Grid = (64-row blocks of cloud a) x (column chunks of cloud b) x (requests).  Thread = one
+// point of cloud a (optionally transformed first, cvo.cpp:485-487); the chunk of cloud b
+// sits in LDS (SoA positions, broadcast reads).  The radius gate IS binding here (no
+// a>sp_thres test, Q6), so the fused cull is followed by the reference's own un-fused d2
+// expression before a pair counts.  Per-thread sums are f32 for the Hessian (the reference
+// keeps an f32 Hessian, cvo.cpp:622,707), f64 across threads; every workgroup writes one
+// partial record and a second tiny kernel adds the records of a request in a fixed order
+// straight into pinned host memory, so results are reproducible run to run and no copy
+// engine is involved.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "cvo_device.h"
@@ -15,17 +19,17 @@
 
 namespace cvohip {
 
-constexpr int SCORE_BLOCK = 256;
-constexpr int SCORE_TILE = 2048;
+constexpr int SCORE_BLOCK = 64;
+constexpr int SCORE_TILE = 512;
 constexpr int SCORE_NOUT = 24;     // sum_A, count, 21 Hessian terms, pad
 
 __device__ __forceinline__ float4 ld4s(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-__global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreDesc D, DevParams P, double* __restrict__ partials) {
+__global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, DevParams P, double* __restrict__ partials) {
+    const ScoreDesc& D = B.d[blockIdx.z];
     __shared__ __attribute__((aligned(16))) float lx[SCORE_TILE];
     __shared__ __attribute__((aligned(16))) float ly[SCORE_TILE];
     __shared__ __attribute__((aligned(16))) float lz[SCORE_TILE];
-    __shared__ double red[SCORE_BLOCK / 64][SCORE_NOUT];
 
     const int tid = threadIdx.x, i = blockIdx.x * SCORE_BLOCK + tid;
     const float ell = D.ell, sigma = P.sigma;
@@ -51,8 +55,11 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreDesc D, Dev
 #pragma unroll
     for (int q = 0; q < 21; ++q) H[q] = 0.f;
 
-    for (int t0 = 0; t0 < D.nb; t0 += SCORE_TILE) {
-        const int tn = min(SCORE_TILE, D.nb - t0), tn4 = (tn + 3) & ~3;
+    // this workgroup's chunk of cloud b
+    const int csize = (((D.nb + (int)gridDim.y - 1) / (int)gridDim.y) + 3) & ~3;
+    const int c_begin = min(D.nb, (int)blockIdx.y * csize), c_end = min(D.nb, c_begin + csize);
+    for (int t0 = c_begin; t0 < c_end; t0 += SCORE_TILE) {
+        const int tn = min(SCORE_TILE, c_end - t0), tn4 = (tn + 3) & ~3;
         __syncthreads();
         for (int jj = tid; jj < tn4; jj += SCORE_BLOCK) {
             float b0 = -3.0e18f, b1 = -3.0e18f, b2 = -3.0e18f;
@@ -135,24 +142,34 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreDesc D, Dev
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, 64);
     }
-    const int lane = tid & 63, wave = tid >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < SCORE_NOUT; ++q) red[wave][q] = v[q];
-    }
-    __syncthreads();
+    const size_t rec = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     if (tid < SCORE_NOUT) {
-        double s = 0;
-        for (int w = 0; w < SCORE_BLOCK / 64; ++w) s += red[w][tid];
-        partials[(size_t)blockIdx.x * SCORE_NOUT + tid] = s;
+        double mine = 0;
+#pragma unroll
+        for (int q = 0; q < SCORE_NOUT; ++q) mine = (tid == q) ? v[q] : mine;
+        partials[rec * SCORE_NOUT + tid] = mine;                    // row blocks past the end of a request's cloud write zeros
     }
 }
 
-int score_grid(int na) { return (na + SCORE_BLOCK - 1) / SCORE_BLOCK; }
-int score_nout() { return SCORE_NOUT; }
+// one workgroup per request: its partial records, in record order, into out[request][24] (pinned host memory)
+__global__ __launch_bounds__(64) void cvo_score_reduce_kernel(const double* __restrict__ partials, int records_per_request, double* __restrict__ out) {
+    const int tid = threadIdx.x;
+    if (tid >= SCORE_NOUT) return;
+    const double* p = partials + (size_t)blockIdx.x * records_per_request * SCORE_NOUT;
+    double s = 0;
+    for (int r = 0; r < records_per_request; ++r) s += p[(size_t)r * SCORE_NOUT + tid];
+    out[blockIdx.x * SCORE_NOUT + tid] = s;
+}
 
-hipError_t launch_score(const ScoreDesc& D, const DevParams& P, double* partials, hipStream_t stream) {
-    hipLaunchKernelGGL(cvo_score_kernel, dim3(score_grid(D.na)), dim3(SCORE_BLOCK), 0, stream, D, P, partials);
+int score_nout() { return SCORE_NOUT; }
+int score_row_blocks(int na) { return (na + SCORE_BLOCK - 1) / SCORE_BLOCK; }
+
+// one launch for the whole batch of requests; out_pinned[request][24] is complete when the stream has drained
+hipError_t launch_score(const ScoreBatch& B, int row_blocks, int chunks, const DevParams& P, double* partials, double* out_pinned, hipStream_t stream) {
+    hipLaunchKernelGGL(cvo_score_kernel, dim3(row_blocks, chunks, B.n), dim3(SCORE_BLOCK), 0, stream, B, P, partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cvo_score_reduce_kernel, dim3(B.n), dim3(64), 0, stream, partials, row_blocks * chunks, out_pinned);
     return hipGetLastError();
 }
 
