@@ -121,6 +121,35 @@ def cpu_baseline(pairs, threads, budget_s=20.0):
                 tfs=tfs_s + tfs_r, iters=it_s + it_r, single_thread_rate=len(o_tfs) / o_dt, single_thread_pairs=len(o_tfs))
 
 
+def latency_probe(ca, pairs, device):
+    """BASELINE config 2 and SURVEY 8f next-2, for the record (not part of `value`): one pair alone through a cvo::cvo-style
+    object (align, then the tracker's score block, cvo.cpp:475-503), and ten loop-closure candidates through the batch API
+    (one align launch + one launch for all 10 x (6 inner products + 2 Hessians), keyframe_graph.cpp:693-717)."""
+    _, fx, ff, mx, mf = pairs[0]
+    al, sc = [], []
+    for _ in range(5):
+        g = ca.Cvo(device=device)
+        g.set_pcd(fx, ff); g.set_pcd(mx, mf)
+        t0 = time.perf_counter(); g.align(); al.append(time.perf_counter() - t0)
+        tf = g.transform
+        t0 = time.perf_counter(); g.compute_innerproduct(tf); sc.append(time.perf_counter() - t0)
+        g.close()
+    n = min(10, len(pairs))
+    B = ca.CvoBatch(n, device=device)
+    for i in range(n):
+        B.set_pair(i, pairs[i][1], pairs[i][2], pairs[i][3], pairs[i][4])
+    eye = np.tile(np.eye(3, 4, dtype=np.float32), (n, 1, 1))
+    la, ls = [], []
+    for _ in range(5):
+        B.reset_states()
+        t0 = time.perf_counter(); B.align(n); la.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); B.compute_innerproduct_lc(eye, eye, eye); ls.append(time.perf_counter() - t0)
+    B.close()
+    med = lambda v: 1e3 * float(np.median(v))
+    return {"single_pair_align_ms": med(al), "single_pair_score_block_ms": med(sc), "lc_candidates": n,
+            "lc_batch_align_ms": med(la), "lc_batch_score_block_ms": med(ls), "note": "host wall time per call, median of 5, automatic workgroup count"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +310,8 @@ def main():
                              "time per step): the share of the chip's plain-f32 issue slots the job keeps busy.  dense_pair_tests_per_s counts the "
                              "N*M tests per iteration the reference's radius search stands for; the kernel skips most of them (lists + box cull)"},
         }
+        if world == 1:
+            out["latency"] = latency_probe(ca, pairs, local_rank)
         if not args.no_cpu_baseline and world == 1:
             cores = host_threads()
             print(f"[bench] GPU done ({value:.1f} alignments/s); timing the CPU baseline on {cores} threads ...", file=sys.stderr, flush=True)

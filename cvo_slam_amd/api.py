@@ -48,6 +48,12 @@ class PairResult(C.Structure):
                 ("rebuilds", C.c_int), ("dense_fallbacks", C.c_int)]
 
 
+class LcScores(C.Structure):
+    _fields_ = [("inn_prior", InnP), ("inn_lc_prior", InnP), ("inn_pre", InnP), ("inn_post", InnP), ("inn_fixed_pcd", InnP),
+                ("inn_moving_pcd", InnP), ("post_hessian", C.c_double * 36), ("inliers_svd", C.c_int), ("inliers_pnpransac", C.c_int),
+                ("cos_angle", C.c_float), ("accept", C.c_int)]
+
+
 # every symbol include/cvo_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = [
     "cvo_last_error", "cvo_device_count", "cvo_default_params", "cvo_create", "cvo_destroy", "cvo_set_pcd", "cvo_align",
@@ -58,7 +64,7 @@ ABI_SYMBOLS = [
     "cvo_get_first_frame", "cvo_set_first_frame", "cvo_get_state", "cvo_set_state", "cvo_set_workgroups",
     "cvo_batch_create", "cvo_batch_destroy", "cvo_batch_set_pair", "cvo_batch_set_state", "cvo_batch_set_workgroups",
     "cvo_batch_reset_states", "cvo_batch_align_async", "cvo_batch_wait", "cvo_batch_last_launch",
-    "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds",
+    "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds", "cvo_batch_compute_innerproduct_lc",
 ]
 
 _lib = None
@@ -119,6 +125,7 @@ def load_library():
     L.cvo_batch_last_launch.argtypes = [vp, fp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.cvo_batch_results_to_device.argtypes = [vp, vp, C.c_int, vp]
     L.cvo_batch_last_phase_seconds.argtypes = [vp, dp]
+    L.cvo_batch_compute_innerproduct_lc.argtypes = [vp, C.c_int, fp, fp, fp, C.POINTER(LcScores)]
     _lib = L
     return L
 
@@ -354,6 +361,21 @@ class CvoBatch:
     def last_phase_seconds(self):
         out = np.zeros(10); _check(self.L.cvo_batch_last_phase_seconds(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
         return dict(zip(("cull", "candidates", "reduce1", "linesearch", "reduce2", "epilogue", "rb_sweep", "rb_scan", "rb_extract", "c2_rowsums"), out.tolist()))
+
+    # -- keyframe_graph.cpp:704-717 for every aligned pair, one launch
+    def compute_innerproduct_lc(self, prior_tran, lc_prior_tran, lc_prior_tran_2):
+        """prior_tran / lc_prior_tran / lc_prior_tran_2: (n, 3, 4) Affine3f each.  Returns one dict per pair with the
+        fields of `compute_innerproduct_lc` (cvo.cpp:505-561) plus `accept` (the reference's rule)."""
+        pt = np.ascontiguousarray(prior_tran, np.float32).reshape(-1, 12); n = pt.shape[0]
+        lp = np.ascontiguousarray(lc_prior_tran, np.float32).reshape(n, 12); l2 = np.ascontiguousarray(lc_prior_tran_2, np.float32).reshape(n, 12)
+        out = (LcScores * n)()
+        f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        _check(self.L.cvo_batch_compute_innerproduct_lc(self.h, n, f(pt), f(lp), f(l2), out))
+        tup = lambda r: (r.value, r.num, r.num_e)
+        return [dict(inn_prior=tup(o.inn_prior), inn_lc_prior=tup(o.inn_lc_prior), inn_lc_pre=tup(o.inn_pre), inn_lc_post=tup(o.inn_post),
+                     inn_fixed_pcd=tup(o.inn_fixed_pcd), inn_moving_pcd=tup(o.inn_moving_pcd),
+                     post_hessian=np.array(o.post_hessian[:]).reshape(6, 6), inliers_svd=o.inliers_svd, inliers_pnpransac=o.inliers_pnpransac,
+                     cos_angle=o.cos_angle, accept=bool(o.accept)) for o in out]
 
     def results_to_device(self, dst_device_ptr: int, n: int, stream: int | None = None):
         _check(self.L.cvo_batch_results_to_device(self.h, C.c_void_p(dst_device_ptr), n, C.c_void_p(stream) if stream else None))

@@ -29,7 +29,8 @@ hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 int score_nout();
 int score_row_blocks(int na);
-hipError_t launch_score(const ScoreBatch& B, int row_blocks, int chunks, const DevParams& P, double* partials, double* out_pinned, hipStream_t stream);
+hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
+                        double* out_pinned, hipStream_t stream);
 }  // namespace cvohip
 
 using namespace cvohip;
@@ -138,6 +139,7 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
+        d_scoredescs.release(); h_scoredescs.release();
         for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -304,19 +306,20 @@ struct Engine {
     const PairState* results() const { return static_cast<const PairState*>(h_states.p); }
 
     // function_inner_product / se3_Hessian: out[0]=sum_A, out[1]=count, out[2..22]=Hessian terms
-    // A score block: up to SCORE_MAXREQ function_inner_product / se3_Hessian evaluations in one launch.
+    // A score block: any number of function_inner_product / se3_Hessian evaluations in one launch.
     // out[r][0] = sum_A, out[r][1] = pair count, out[r][2..22] = Hessian terms.
-    struct ScoreReq { const Cloud* a; const float* tran; const Cloud* b; bool hessian; };
-    int score_many(const ScoreReq* rq, int n, float ell, double (*out)[24]) {
+    struct ScoreReq { const Cloud* a; const float* tran; const Cloud* b; bool hessian; float ell; };
+    DevBuf d_scoredescs; PinBuf h_scoredescs;
+    int score_many(const ScoreReq* rq, int n, double (*out)[24]) {
         HIP_TRY(hipSetDevice(device));
-        if (n <= 0 || n > SCORE_MAXREQ) return fail(CVO_ERR_INVALID, "bad score request count");
-        ScoreBatch B; std::memset(&B, 0, sizeof(B));
-        B.n = n;
+        if (n <= 0) return fail(CVO_ERR_INVALID, "bad score request count");
+        std::vector<ScoreDesc> descs(n);
         int row_blocks = 1;
         for (int r = 0; r < n; ++r) {
             if (!rq[r].a || !rq[r].b || rq[r].a->n <= 0 || rq[r].b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "empty cloud");
-            ScoreDesc& D = B.d[r];
-            D.a = rq[r].a->rec(); D.b = rq[r].b->rec(); D.na = rq[r].a->n; D.nb = rq[r].b->n; D.ell = ell;
+            ScoreDesc& D = descs[r];
+            std::memset(&D, 0, sizeof(D));
+            D.a = rq[r].a->rec(); D.b = rq[r].b->rec(); D.na = rq[r].a->n; D.nb = rq[r].b->n; D.ell = rq[r].ell;
             D.want_hessian = rq[r].hessian ? 1 : 0; D.out = nullptr;
             D.use_tran = rq[r].tran ? 1 : 0;
             for (int i = 0; i < 12; ++i) D.tran[i] = rq[r].tran ? rq[r].tran[i] : 0.f;
@@ -326,8 +329,19 @@ struct Engine {
         const int chunks = std::max(1, std::min(16, 4 * num_cus / std::max(1, row_blocks * n)));   // ~4 workgroups (waves) per CU
         int rc;
         if ((rc = d_partials.ensure(sizeof(double) * (size_t)n * row_blocks * chunks * nout))) return rc;
-        if ((rc = h_partials.ensure(sizeof(double) * (size_t)SCORE_MAXREQ * nout))) return rc;
-        hipError_t e = launch_score(B, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), stream);
+        if ((rc = h_partials.ensure(sizeof(double) * (size_t)std::max(n, SCORE_MAXREQ) * nout))) return rc;
+        ScoreBatch B; std::memset(&B, 0, sizeof(B));
+        const ScoreDesc* more = nullptr;
+        if (n <= SCORE_MAXREQ) { B.n = n; for (int r = 0; r < n; ++r) B.d[r] = descs[r]; }
+        else {
+            if ((rc = d_scoredescs.ensure(sizeof(ScoreDesc) * (size_t)n))) return rc;
+            if ((rc = h_scoredescs.ensure(sizeof(ScoreDesc) * (size_t)n))) return rc;
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::memcpy(h_scoredescs.p, descs.data(), sizeof(ScoreDesc) * (size_t)n);
+            HIP_TRY(hipMemcpyAsync(d_scoredescs.p, h_scoredescs.p, sizeof(ScoreDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
+            more = static_cast<const ScoreDesc*>(d_scoredescs.p);
+        }
+        hipError_t e = launch_score(B, more, n, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), stream);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("score kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipStreamSynchronize(stream));
         const double* hp = static_cast<const double*>(h_partials.p);
@@ -589,8 +603,8 @@ int cvo_function_inner_product(cvo_handle h, int slot_a, const float* tran_a, in
     Cloud* a = slot_cloud(h, slot_a); Cloud* b = slot_cloud(h, slot_b);
     if (!a || !b || a->n <= 0 || b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "function_inner_product: empty cloud slot");
     double r[1][24];
-    const Engine::ScoreReq rq[1] = {{a, tran_a, b, false}};
-    int rc = h->eng.score_many(rq, 1, h->ell, r); if (rc) return rc;
+    const Engine::ScoreReq rq[1] = {{a, tran_a, b, false, h->ell}};
+    int rc = h->eng.score_many(rq, 1, r); if (rc) return rc;
     finish_inn_p(r[0], out);
     return CVO_OK;
 }
@@ -600,8 +614,8 @@ int cvo_se3_hessian(cvo_handle h, int slot_a, const float* tran_a, int slot_b, d
     Cloud* a = slot_cloud(h, slot_a); Cloud* b = slot_cloud(h, slot_b);
     if (!a || !b || a->n <= 0 || b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "se3_Hessian: empty cloud slot");
     double r[1][24];
-    const Engine::ScoreReq rq[1] = {{a, tran_a, b, true}};
-    int rc = h->eng.score_many(rq, 1, h->ell, r); if (rc) return rc;
+    const Engine::ScoreReq rq[1] = {{a, tran_a, b, true, h->ell}};
+    int rc = h->eng.score_many(rq, 1, r); if (rc) return rc;
     *inliers += (int)r[0][1];                                        // cvo.cpp:708 increments the caller's variable
     finish_hessian(r[0] + 2, *inliers, H);
     return CVO_OK;
@@ -614,13 +628,13 @@ int cvo_compute_innerproduct(cvo_handle h, cvo_inn_p* inn_pre, cvo_inn_p* inn_po
         return fail(CVO_ERR_INVALID, "null argument");
     Cloud* fx = slot_cloud(h, CVO_SLOT_FIXED); Cloud* mv = slot_cloud(h, CVO_SLOT_MOVING);
     if (!fx || !mv || fx->n <= 0 || mv->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "function_inner_product: empty cloud slot");
-    const Engine::ScoreReq rq[5] = {{mv, nullptr, fx, false},        // cvo.cpp:489
-                                    {mv, tran, fx, false},           // cvo.cpp:491
-                                    {fx, nullptr, fx, false},        // cvo.cpp:496
-                                    {mv, nullptr, mv, false},        // cvo.cpp:497
-                                    {mv, tran, fx, true}};           // cvo.cpp:500
+    const Engine::ScoreReq rq[5] = {{mv, nullptr, fx, false, h->ell},        // cvo.cpp:489
+                                    {mv, tran, fx, false, h->ell},           // cvo.cpp:491
+                                    {fx, nullptr, fx, false, h->ell},        // cvo.cpp:496
+                                    {mv, nullptr, mv, false, h->ell},        // cvo.cpp:497
+                                    {mv, tran, fx, true, h->ell}};           // cvo.cpp:500
     double r[5][24];
-    int rc = h->eng.score_many(rq, 5, h->ell, r); if (rc) return rc;
+    int rc = h->eng.score_many(rq, 5, r); if (rc) return rc;
     finish_inn_p(r[0], inn_pre); finish_inn_p(r[1], inn_post); finish_inn_p(r[2], inn_fixed_pcd); finish_inn_p(r[3], inn_moving_pcd);
     *cos_angle = inn_post->value / (sqrtf(inn_fixed_pcd->value) * sqrtf(inn_moving_pcd->value));                  // cvo.cpp:498
     *inliers += (int)r[4][1];                                        // cvo.cpp:708
@@ -637,16 +651,16 @@ int cvo_compute_innerproduct_lc(cvo_handle h, cvo_inn_p* inn_prior, cvo_inn_p* i
         return fail(CVO_ERR_INVALID, "null argument");
     Cloud* fx = slot_cloud(h, CVO_SLOT_FIXED); Cloud* mv = slot_cloud(h, CVO_SLOT_MOVING);
     if (!fx || !mv || fx->n <= 0 || mv->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "function_inner_product: empty cloud slot");
-    const Engine::ScoreReq rq[8] = {{mv, prior_tran, fx, false},     // cvo.cpp:539
-                                    {mv, lc_prior_tran, fx, false},  // cvo.cpp:541
-                                    {mv, nullptr, fx, false},        // cvo.cpp:543
-                                    {mv, lc_tran, fx, false},        // cvo.cpp:545
-                                    {fx, nullptr, fx, false},        // cvo.cpp:550
-                                    {mv, nullptr, mv, false},        // cvo.cpp:551
-                                    {mv, lc_tran, fx, true},         // cvo.cpp:555
-                                    {mv, lc_prior_tran_2, fx, true}};   // cvo.cpp:558
+    const Engine::ScoreReq rq[8] = {{mv, prior_tran, fx, false, h->ell},     // cvo.cpp:539
+                                    {mv, lc_prior_tran, fx, false, h->ell},  // cvo.cpp:541
+                                    {mv, nullptr, fx, false, h->ell},        // cvo.cpp:543
+                                    {mv, lc_tran, fx, false, h->ell},        // cvo.cpp:545
+                                    {fx, nullptr, fx, false, h->ell},        // cvo.cpp:550
+                                    {mv, nullptr, mv, false, h->ell},        // cvo.cpp:551
+                                    {mv, lc_tran, fx, true, h->ell},         // cvo.cpp:555
+                                    {mv, lc_prior_tran_2, fx, true, h->ell}};   // cvo.cpp:558
     double r[8][24];
-    int rc = h->eng.score_many(rq, 8, h->ell, r); if (rc) return rc;
+    int rc = h->eng.score_many(rq, 8, r); if (rc) return rc;
     finish_inn_p(r[0], inn_prior); finish_inn_p(r[1], inn_lc_prior); finish_inn_p(r[2], inn_lc_pre); finish_inn_p(r[3], inn_lc_post);
     finish_inn_p(r[4], inn_fixed_pcd); finish_inn_p(r[5], inn_moving_pcd);
     *cos_angle = inn_lc_post->value / (sqrtf(inn_fixed_pcd->value) * sqrtf(inn_moving_pcd->value));                       // cvo.cpp:552
@@ -811,6 +825,45 @@ int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]) {
         double cyc = 0, tk = 0;
         for (int i = 0; i < b->last_n; ++i) { cyc += (double)r[i].clk_cycles; tk += (double)r[i].clk_ticks; }
         if (std::getenv("CVO_HIP_REPORT_CLOCK") && tk > 0) std::fprintf(stderr, "[cvo_hip] shader clock %.3f GHz\n", cyc / tk * 0.1);
+    }
+    return CVO_OK;
+}
+int cvo_batch_compute_innerproduct_lc(cvo_batch b, int n, const float* prior_tran, const float* lc_prior_tran, const float* lc_prior_tran_2,
+                                      cvo_lc_scores* out) {
+    if (!b || !prior_tran || !lc_prior_tran || !lc_prior_tran_2 || !out) return fail(CVO_ERR_INVALID, "null argument");
+    if (n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "more pairs than the last launch aligned");
+    int rc = b->eng.wait(); if (rc) return rc;
+    const PairState* res = b->eng.results();
+    std::vector<Engine::ScoreReq> rq((size_t)n * 8);
+    for (int i = 0; i < n; ++i) {
+        const Cloud* fx = b->fixed[i].get(); const Cloud* mv = b->moving[i].get();
+        if (!fx || !mv || fx->n <= 0 || mv->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "compute_innerproduct_lc: empty cloud in the batch");
+        const float* lc_tran = res[i].transform;                     // lc_post = result.transform, keyframe_graph.cpp:702
+        const float ell = res[i].ell;                                // the ell align() left behind (Q1), cvo.cpp:395
+        Engine::ScoreReq* q = &rq[(size_t)i * 8];
+        q[0] = {mv, prior_tran + 12 * i, fx, false, ell};            // cvo.cpp:539
+        q[1] = {mv, lc_prior_tran + 12 * i, fx, false, ell};         // cvo.cpp:541
+        q[2] = {mv, nullptr, fx, false, ell};                        // cvo.cpp:543
+        q[3] = {mv, lc_tran, fx, false, ell};                        // cvo.cpp:545
+        q[4] = {fx, nullptr, fx, false, ell};                        // cvo.cpp:550
+        q[5] = {mv, nullptr, mv, false, ell};                        // cvo.cpp:551
+        q[6] = {mv, lc_tran, fx, true, ell};                         // cvo.cpp:555
+        q[7] = {mv, lc_prior_tran_2 + 12 * i, fx, true, ell};        // cvo.cpp:558
+    }
+    std::vector<double> r((size_t)n * 8 * 24);
+    rc = b->eng.score_many(rq.data(), n * 8, reinterpret_cast<double (*)[24]>(r.data())); if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        const double (*ri)[24] = reinterpret_cast<const double (*)[24]>(r.data() + (size_t)i * 8 * 24);
+        cvo_lc_scores& o = out[i];
+        finish_inn_p(ri[0], &o.inn_prior); finish_inn_p(ri[1], &o.inn_lc_prior); finish_inn_p(ri[2], &o.inn_pre); finish_inn_p(ri[3], &o.inn_post);
+        finish_inn_p(ri[4], &o.inn_fixed_pcd); finish_inn_p(ri[5], &o.inn_moving_pcd);
+        o.cos_angle = o.inn_post.value / (sqrtf(o.inn_fixed_pcd.value) * sqrtf(o.inn_moving_pcd.value));   // cvo.cpp:552
+        o.inliers_svd = (int)ri[6][1];
+        finish_hessian(ri[6] + 2, o.inliers_svd, o.post_hessian);
+        o.inliers_pnpransac = (int)ri[7][1];
+        const bool reject = (o.inn_post.value <= o.inn_pre.value) || (o.inn_post.value <= o.inn_lc_prior.value) ||
+                            (o.inn_post.value <= o.inn_prior.value) || o.cos_angle < 0.1f;          // keyframe_graph.cpp:711-712
+        o.accept = reject ? 0 : 1;
     }
     return CVO_OK;
 }

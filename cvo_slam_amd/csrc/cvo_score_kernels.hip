@@ -25,8 +25,8 @@ constexpr int SCORE_NOUT = 24;     // sum_A, count, 21 Hessian terms, pad
 
 __device__ __forceinline__ float4 ld4s(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-__global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, DevParams P, double* __restrict__ partials) {
-    const ScoreDesc& D = B.d[blockIdx.z];
+__global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, const ScoreDesc* __restrict__ more, DevParams P, double* __restrict__ partials) {
+    const ScoreDesc& D = more ? more[blockIdx.z] : B.d[blockIdx.z];     // a tracker's score block travels in the kernel arguments, a batch's in HBM
     __shared__ __attribute__((aligned(16))) float lx[SCORE_TILE];
     __shared__ __attribute__((aligned(16))) float ly[SCORE_TILE];
     __shared__ __attribute__((aligned(16))) float lz[SCORE_TILE];
@@ -165,11 +165,12 @@ int score_nout() { return SCORE_NOUT; }
 int score_row_blocks(int na) { return (na + SCORE_BLOCK - 1) / SCORE_BLOCK; }
 
 // one launch for the whole batch of requests; out_pinned[request][24] is complete when the stream has drained
-hipError_t launch_score(const ScoreBatch& B, int row_blocks, int chunks, const DevParams& P, double* partials, double* out_pinned, hipStream_t stream) {
-    hipLaunchKernelGGL(cvo_score_kernel, dim3(row_blocks, chunks, B.n), dim3(SCORE_BLOCK), 0, stream, B, P, partials);
+hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
+                        double* out_pinned, hipStream_t stream) {
+    hipLaunchKernelGGL(cvo_score_kernel, dim3(row_blocks, chunks, nreq), dim3(SCORE_BLOCK), 0, stream, B, more, P, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cvo_score_reduce_kernel, dim3(B.n), dim3(64), 0, stream, partials, row_blocks * chunks, out_pinned);
+    hipLaunchKernelGGL(cvo_score_reduce_kernel, dim3(nreq), dim3(64), 0, stream, partials, row_blocks * chunks, out_pinned);
     return hipGetLastError();
 }
 

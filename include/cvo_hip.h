@@ -190,6 +190,22 @@ int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]);
 #define CVO_RESULT_FLOATS 16
 int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stream);
 
+/* Loop-closure verification of the aligned pairs (keyframe_graph.cpp:704-717): per pair the
+ * compute_innerproduct_lc block (cvo.cpp:505-561: 6 inner products + 2 Hessians, lc_tran = the pair's
+ * own align() result, ell = what that align() left behind, Q1) and the reference's accept rule.  All
+ * pairs' 8 evaluations are ONE launch.  prior_tran / lc_prior_tran / lc_prior_tran_2: n row-major 3x4
+ * Affine3f each (keyframe_graph.cpp: prior, lc_prior, lc_prior_2).  Waits for the align launch first. */
+typedef struct cvo_lc_scores {
+    cvo_inn_p inn_prior, inn_lc_prior, inn_pre, inn_post, inn_fixed_pcd, inn_moving_pcd;   /* cvo.cpp:539-551 */
+    double post_hessian[36];           /* cvo.cpp:555 */
+    int    inliers_svd;                /* cvo.cpp:554-555 */
+    int    inliers_pnpransac;          /* cvo.cpp:557-558 */
+    float  cos_angle;                  /* cvo.cpp:552 */
+    int    accept;                     /* keyframe_graph.cpp:711-712: inn_post > inn_pre, inn_lc_prior, inn_prior and cos_angle >= 0.1 */
+} cvo_lc_scores;
+int cvo_batch_compute_innerproduct_lc(cvo_batch b, int n, const float* prior_tran, const float* lc_prior_tran,
+                                      const float* lc_prior_tran_2, cvo_lc_scores* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -381,6 +381,48 @@ def test_batch_matches_single_objects_and_warm_start(hiplib, oracle):
     B.close()
 
 
+def test_batch_loop_closure_verification_block(hiplib, oracle):
+    """keyframe_graph.cpp:693-717 for a batch of candidates: fresh objects warm-started by reset_initial(lc_prior), aligned in
+    one launch, then every pair's compute_innerproduct_lc block (6 inner products + 2 Hessians) in ONE score launch, with the
+    reference's accept rule; checked pair by pair against single oracle objects driven the way the reference drives cvo::cvo."""
+    from cvo_slam_amd import synth
+    sizes = (300, 520, 64, 900, 410, 777, 333, 640, 250, 1000)              # detectLoopClousure_top10: up to 10 candidates (11 requests > 8 too)
+    pairs = [synth.make_small_pair(400 + i, n=n) for i, n in enumerate(sizes)]
+    n = len(pairs)
+    priors = np.stack([make_tf([0, 1, 0], 0.002 * (i + 1), [0.001 * i, 0, -0.001]) for i in range(n)])
+    lc_priors = np.stack([make_tf([1, 0, 0], 0.003 * (i % 4), [0, 0.002, 0.001 * (i % 3)]) for i in range(n)])
+    lc_priors2 = np.stack([make_tf([0, 0, 1], 0.004, [0.002, -0.001 * (i % 2), 0]) for i in range(n)])
+    B = hiplib.CvoBatch(n)
+    single = []
+    for i, p in enumerate(pairs):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+        o = oracle.OracleCvo()
+        guess = o.reset_initial(lc_priors[i])                                  # keyframe_graph.cpp:696 on a fresh object
+        o.set_pcd(p.fixed.xyz, p.fixed.feat); o.set_pcd(p.moving.xyz, p.moving.feat)
+        st0 = o.get_state()
+        B.set_state(i, st0["R"], st0["T"], st0["ell"])
+        single.append(o)
+    res = B.align(n)
+    got = B.compute_innerproduct_lc(priors, lc_priors, lc_priors2)
+    assert len(got) == n
+    for i, (o, r, g) in enumerate(zip(single, res, got)):
+        rc, _ = o.align(); assert rc == 0
+        st = o.get_state()
+        assert_pose_close(r["transform"], st["transform"])
+        rc, want = o.compute_innerproduct_lc(priors[i], lc_priors[i], lc_priors2[i], st["transform"]); assert rc == 0
+        for key in ("inn_prior", "inn_lc_prior", "inn_lc_pre", "inn_lc_post", "inn_fixed_pcd", "inn_moving_pcd"):
+            assert g[key][1] == want[key][1], (i, key)
+            assert g[key][0] == pytest.approx(want[key][0], rel=1e-5), (i, key)
+        assert (g["inliers_svd"], g["inliers_pnpransac"]) == (want["inliers_svd"], want["inliers_pnpransac"])
+        assert g["cos_angle"] == pytest.approx(want["cos_angle"], rel=1e-5)
+        np.testing.assert_allclose(g["post_hessian"], want["post_hessian"], rtol=1e-3, atol=1e-3 * np.abs(want["post_hessian"]).max())
+        post, pre, lcp, pri = want["inn_lc_post"][0], want["inn_lc_pre"][0], want["inn_lc_prior"][0], want["inn_prior"][0]
+        margin = min(abs(post - pre), abs(post - lcp), abs(post - pri)) / max(abs(post), 1e-30)
+        if margin > 1e-4 and abs(want["cos_angle"] - 0.1) > 1e-4:               # the rule itself, away from ties
+            assert g["accept"] == (not (post <= pre or post <= lcp or post <= pri or want["cos_angle"] < 0.1)), i
+    B.close()
+
+
 def test_batch_results_to_device_records(hiplib):
     import torch
     from cvo_slam_amd import shard, synth
