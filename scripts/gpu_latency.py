@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import cvo_slam_amd as ca
 from cvo_slam_amd import synth
-pr = synth.make_pair(int(os.environ.get("PAIR", "0")))
+pr = synth.make_pair(int(os.environ.get("PAIR", "0")), cam=synth.ETH3D if os.environ.get("SHAPE") == "eth3d" else synth.TUM1)
+print("points", pr.fixed.n, pr.moving.n)
 for wgs in [int(x) for x in os.environ.get("WGS", "0,32,16,8,4,1").split(",")]:
     ts = []
     for rep in range(5):
