@@ -48,6 +48,11 @@ class PairResult(C.Structure):
                 ("rebuilds", C.c_int), ("dense_fallbacks", C.c_int)]
 
 
+class Camera(C.Structure):
+    """cvo::camera_info (data_type.h:33-39)."""
+    _fields_ = [("scaling_factor", C.c_float), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
 class LcScores(C.Structure):
     _fields_ = [("inn_prior", InnP), ("inn_lc_prior", InnP), ("inn_pre", InnP), ("inn_post", InnP), ("inn_fixed_pcd", InnP),
                 ("inn_moving_pcd", InnP), ("post_hessian", C.c_double * 36), ("inliers_svd", C.c_int), ("inliers_pnpransac", C.c_int),
@@ -65,6 +70,7 @@ ABI_SYMBOLS = [
     "cvo_batch_create", "cvo_batch_destroy", "cvo_batch_set_pair", "cvo_batch_set_state", "cvo_batch_set_workgroups",
     "cvo_batch_reset_states", "cvo_batch_align_async", "cvo_batch_wait", "cvo_batch_last_launch",
     "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds", "cvo_batch_compute_innerproduct_lc",
+    "cvo_set_pcd_images", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
 ]
 
 _lib = None
@@ -126,6 +132,12 @@ def load_library():
     L.cvo_batch_results_to_device.argtypes = [vp, vp, C.c_int, vp]
     L.cvo_batch_last_phase_seconds.argtypes = [vp, dp]
     L.cvo_batch_compute_innerproduct_lc.argtypes = [vp, C.c_int, fp, fp, fp, C.POINTER(LcScores)]
+    L.cvo_set_pcd_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera)]
+    L.cvo_set_num_want.argtypes = [vp, C.c_int]
+    L.cvo_match_odometry_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera), dp]
+    L.cvo_match_keyframe_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera), dp]
+    L.cvo_get_cloud.argtypes = [vp, C.c_int, fp, fp, C.c_int, ip]
+    L.cvo_get_selected_points.argtypes = [vp, C.c_int, vp, C.c_int, ip]
     _lib = L
     return L
 
@@ -184,6 +196,51 @@ class Cvo:
     def set_pcd(self, xyz, feat):
         x, xp, f, fpt = _cloud_args(xyz, feat)
         _check(self.L.cvo_set_pcd(self.h, xp, fpt, x.shape[0]))
+
+    # -- cvo.cpp:345-386 with the images, as the reference's signature has it (pcd_generator on the GPU)
+    @staticmethod
+    def _images(bgr8, depth16):
+        bgr = np.ascontiguousarray(bgr8, np.uint8); dep = np.ascontiguousarray(depth16, np.uint16)
+        h, w = dep.shape
+        if bgr.shape != (h, w, 3):
+            raise ValueError("bgr8 must be (h, w, 3) for a (h, w) depth image")
+        return bgr, dep, w, h
+
+    def set_pcd_images(self, bgr8, depth16, camera):
+        """camera = (scaling_factor, fx, fy, cx, cy)."""
+        bgr, dep, w, h = self._images(bgr8, depth16); cam = Camera(*[float(v) for v in camera])
+        _check(self.L.cvo_set_pcd_images(self.h, bgr.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p), w, h, C.byref(cam)))
+
+    def set_num_want(self, num_want: int):
+        _check(self.L.cvo_set_num_want(self.h, int(num_want)))
+
+    def match_keyframe_images(self, bgr8, depth16, camera):
+        bgr, dep, w, h = self._images(bgr8, depth16); cam = Camera(*[float(v) for v in camera]); out = np.zeros(12, np.float64)
+        _check(self.L.cvo_match_keyframe_images(self.h, bgr.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p), w, h, C.byref(cam),
+                                                out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.reshape(3, 4)
+
+    def match_odometry_images(self, bgr8, depth16, camera):
+        bgr, dep, w, h = self._images(bgr8, depth16); cam = Camera(*[float(v) for v in camera]); out = np.zeros(12, np.float64)
+        _check(self.L.cvo_match_odometry_images(self.h, bgr.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p), w, h, C.byref(cam),
+                                                out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.reshape(3, 4)
+
+    def get_cloud(self, slot: int):
+        n = C.c_int(0)
+        _check(self.L.cvo_get_cloud(self.h, slot, None, None, 0, C.byref(n)))
+        xyz = np.zeros((n.value, 3), np.float32); feat = np.zeros((5, n.value), np.float32)
+        if n.value:
+            _check(self.L.cvo_get_cloud(self.h, slot, xyz.ctypes.data_as(C.POINTER(C.c_float)), feat.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)))
+        return xyz, feat
+
+    def get_selected_points(self, slot: int):
+        n = C.c_int(0)
+        _check(self.L.cvo_get_selected_points(self.h, slot, None, 0, C.byref(n)))
+        px = np.zeros((n.value, 2), np.uint16)
+        if n.value:
+            _check(self.L.cvo_get_selected_points(self.h, slot, px.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return px
 
     # -- cvo.cpp:763-821
     def align(self, trace_cap: int = 0):

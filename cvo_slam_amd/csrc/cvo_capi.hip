@@ -27,6 +27,14 @@ int align_blocks_per_cu();
 hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         unsigned launch_tag, const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
+hipError_t pcd_launch_pyramid(const uint8_t* bgr, int w, int h, float* I0, float* I1, float* I2, float* dx0, float* dy0, float* abs0, float* abs1, float* abs2,
+                              hipStream_t s);
+hipError_t pcd_launch_thresholds(const float* abs0, int w, int h, float* ths, float* ths_smoothed, hipStream_t s);
+hipError_t pcd_launch_select(const float* abs0, const float* abs1, const float* abs2, const float* ths_smoothed, int w, int h, int pot, uint8_t* map, int* counts,
+                             hipStream_t s);
+hipError_t pcd_launch_compact(uint8_t* map, const uint8_t* pattern, int subsample, int char_th, const uint16_t* depth, const uint8_t* bgr, const float* dx0,
+                              const float* dy0, int w, int h, const float cam[5], int write, int n_points, float* cloud, uint16_t* px, int* result, hipStream_t s);
+hipError_t pcd_launch_unpack(const float* cloud, int n, float* xyz, float* feat, hipStream_t s);
 int score_nout();
 int score_row_blocks(int na);
 hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
@@ -77,8 +85,9 @@ struct PinBuf {
 // a point cloud resident in HBM: two planes of n float4, {x,y,z,f0} then {f1..f4} (cvo_device.h)
 struct Cloud {
     DevBuf buf; int n = 0;
+    DevBuf px; int n_px = 0;        // selected pixel (x, y) per point, when the cloud was generated from images
     float* rec() const { return static_cast<float*>(buf.p); }
-    ~Cloud() { buf.release(); }
+    ~Cloud() { buf.release(); px.release(); }
 };
 
 DevParams to_dev(const cvo_params& p) {
@@ -139,7 +148,8 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        d_scoredescs.release(); h_scoredescs.release();
+        d_scoredescs.release(); h_scoredescs.release(); h_counts.release();
+        for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts}) b->release();
         for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -168,6 +178,110 @@ struct Engine {
             for (int ch = 1; ch < 5; ++ch) hi[ch - 1] = feat[(size_t)ch * n + i];
         }
         HIP_TRY(hipMemcpyAsync(c.buf.p, s, bytes, hipMemcpyHostToDevice, stream));
+        return CVO_OK;
+    }
+
+    // ---- pcd_generator on the GPU (cvo_pcd_kernels.hip).  Image-sized scratch lives with the engine.
+    DevBuf d_bgr, d_depth, d_I0, d_I1, d_I2, d_dx0, d_dy0, d_abs0, d_abs1, d_abs2, d_ths, d_thsS, d_map, d_pattern, d_counts;
+    PinBuf h_counts;
+    int pattern_len = 0;
+    // glibc srand(seed); rand() & 0xFF, n times (PixelSelector2.cpp:36-38): TYPE_3 additive feedback generator
+    static void rand_pattern(unsigned seed, unsigned char* out, size_t n) {
+        std::vector<uint32_t> r(344 + n);
+        r[0] = seed ? seed : 1;
+        for (int i = 1; i < 31; ++i) {
+            const long long hi = (int32_t)r[i - 1] / 127773, lo = (int32_t)r[i - 1] % 127773;
+            long long word = 16807 * lo - 2836 * hi;
+            if (word < 0) word += 2147483647;
+            r[i] = (uint32_t)word;
+        }
+        for (int i = 31; i < 34; ++i) r[i] = r[i - 31];
+        for (size_t i = 34; i < 344 + n; ++i) r[i] = r[i - 31] + r[i - 3];
+        for (size_t k = 0; k < n; ++k) out[k] = (unsigned char)((r[344 + k] >> 1) & 0xFF);
+    }
+    int generate_pcd(Cloud& c, const unsigned char* bgr8, const unsigned short* depth16, int w, int h, const cvo_camera& cam, int num_want) {
+        HIP_TRY(hipSetDevice(device));
+        if (!bgr8 || !depth16) return fail(CVO_ERR_INVALID, "null image pointer");
+        if (w < 64 || h < 64 || (size_t)w * h > (size_t)1 << 26) return fail(CVO_ERR_INVALID, "image size out of range");
+        if (num_want <= 0) return fail(CVO_ERR_INVALID, "num_want must be positive");
+        const size_t n = (size_t)w * h;
+        const int w1 = w / 2, h1 = h / 2, w2 = w1 / 2, h2 = h1 / 2, w32 = w / 32, h32 = h / 32;
+        int rc;
+        if ((rc = d_bgr.ensure(3 * n))) return rc;
+        if ((rc = d_depth.ensure(2 * n))) return rc;
+        for (DevBuf* b : {&d_I0, &d_dx0, &d_dy0, &d_abs0}) if ((rc = b->ensure(sizeof(float) * n))) return rc;
+        for (DevBuf* b : {&d_I1, &d_abs1}) if ((rc = b->ensure(sizeof(float) * (size_t)w1 * h1))) return rc;
+        for (DevBuf* b : {&d_I2, &d_abs2}) if ((rc = b->ensure(sizeof(float) * (size_t)w2 * h2))) return rc;
+        const size_t nths = (size_t)w32 * h32 + 100;                    // +100 zeroed slack, read for rows past h/32 (PixelSelector2.cpp:44-45)
+        if ((rc = d_ths.ensure(sizeof(float) * nths))) return rc;
+        if ((rc = d_thsS.ensure(sizeof(float) * nths))) return rc;
+        if ((rc = d_map.ensure(n))) return rc;
+        if ((rc = d_counts.ensure(sizeof(int) * 8))) return rc;
+        if ((rc = h_counts.ensure(sizeof(int) * 8))) return rc;
+        if ((rc = h_stage.ensure(5 * n))) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (pattern_len != (int)n) {                                    // the byte pattern only depends on w*h: made once
+            if ((rc = d_pattern.ensure(n))) return rc;
+            std::vector<unsigned char> pat(n);
+            rand_pattern(3141592u, pat.data(), n);
+            HIP_TRY(hipMemcpy(d_pattern.p, pat.data(), n, hipMemcpyHostToDevice));
+            pattern_len = (int)n;
+        }
+        unsigned char* st = static_cast<unsigned char*>(h_stage.p);
+        std::memcpy(st, bgr8, 3 * n); std::memcpy(st + 3 * n, depth16, 2 * n);
+        HIP_TRY(hipMemcpyAsync(d_bgr.p, st, 3 * n, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_depth.p, st + 3 * n, 2 * n, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(d_ths.p, 0, sizeof(float) * nths, stream));
+        HIP_TRY(hipMemsetAsync(d_thsS.p, 0, sizeof(float) * nths, stream));
+        float* I0 = (float*)d_I0.p; float* dx0 = (float*)d_dx0.p; float* dy0 = (float*)d_dy0.p; float* abs0 = (float*)d_abs0.p;
+        hipError_t e = pcd_launch_pyramid((const uint8_t*)d_bgr.p, w, h, I0, (float*)d_I1.p, (float*)d_I2.p, dx0, dy0, abs0, (float*)d_abs1.p, (float*)d_abs2.p, stream);
+        if (e == hipSuccess) e = pcd_launch_thresholds(abs0, w, h, (float*)d_ths.p, (float*)d_thsS.p, stream);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd kernels: ") + hipGetErrorString(e));
+        // PixelSelector::makeMaps (PixelSelector2.cpp:136-282), a fresh selector per frame: potential 3, one re-selection allowed
+        int pot = 3, recursions_left = 1, ideal = 3;
+        float num_have = 0, quotia = 0;
+        const float num_want_f = (float)num_want;
+        int* hc = static_cast<int*>(h_counts.p);
+        for (;;) {
+            HIP_TRY(hipMemsetAsync(d_map.p, 0, n, stream));
+            HIP_TRY(hipMemsetAsync(d_counts.p, 0, sizeof(int) * 8, stream));
+            e = pcd_launch_select(abs0, (const float*)d_abs1.p, (const float*)d_abs2.p, (const float*)d_thsS.p, w, h, pot, (uint8_t*)d_map.p, (int*)d_counts.p, stream);
+            if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd select: ") + hipGetErrorString(e));
+            HIP_TRY(hipMemcpyAsync(hc, d_counts.p, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            num_have = (float)(hc[0] + hc[1] + hc[2]);                  // :191
+            quotia = num_want_f / num_have;                             // :192
+            const float K = num_have * (pot + 1) * (pot + 1);           // :195
+            ideal = (int)(sqrtf(K / num_want_f) - 1);                   // :196
+            if (ideal < 1) ideal = 1;
+            if (recursions_left > 0 && quotia > 1.25 && pot > 1) {      // :199-213
+                if (ideal >= pot) ideal = pot - 1;
+                pot = ideal; --recursions_left; continue;
+            }
+            if (recursions_left > 0 && quotia < 0.25) {                 // :214-229
+                if (ideal <= pot) ideal = pot + 1;
+                pot = ideal; --recursions_left; continue;
+            }
+            break;
+        }
+        const int subsample = (quotia < 0.95) ? 1 : 0;                  // :252-268
+        const int char_th = subsample ? (int)(unsigned char)(255 * quotia) : 255;
+        const float camv[5] = {cam.scaling_factor, cam.fx, cam.fy, cam.cx, cam.cy};
+        e = pcd_launch_compact((uint8_t*)d_map.p, (const uint8_t*)d_pattern.p, subsample, char_th, (const uint16_t*)d_depth.p, (const uint8_t*)d_bgr.p, dx0, dy0,
+                               w, h, camv, 0, 0, nullptr, nullptr, (int*)d_counts.p, stream);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd count: ") + hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(hc, d_counts.p, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const int npts = hc[0];
+        if (npts > 65535) return fail(CVO_ERR_INVALID, "more than 65535 points per cloud is not supported (16-bit column indices)");
+        c.n = npts; c.n_px = npts;
+        if (npts == 0) return CVO_OK;
+        if ((rc = c.buf.ensure((size_t)npts * REC * sizeof(float)))) return rc;
+        if ((rc = c.px.ensure((size_t)npts * 2 * sizeof(uint16_t)))) return rc;
+        e = pcd_launch_compact((uint8_t*)d_map.p, (const uint8_t*)d_pattern.p, subsample, char_th, (const uint16_t*)d_depth.p, (const uint8_t*)d_bgr.p, dx0, dy0,
+                               w, h, camv, 1, npts, c.rec(), (uint16_t*)c.px.p, (int*)d_counts.p, stream);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd compact: ") + hipGetErrorString(e));
+        HIP_TRY(hipStreamSynchronize(stream));
         return CVO_OK;
     }
 
@@ -460,6 +574,7 @@ struct cvo_handle_s {
     float R[9], T[3], ell;
     Aff transform, prev_transform, accum_transform;
     int iter = 0, A_nonzero = 0;
+    int num_want = 3000;                                             // pcd_generator.cpp:22
 };
 
 struct cvo_batch_s {
@@ -572,6 +687,56 @@ int cvo_set_pcd(cvo_handle h, const float* xyz, const float* feat, int n) {
     return CVO_OK;
 }
 
+int cvo_set_num_want(cvo_handle h, int num_want) {
+    if (!h || num_want <= 0) return fail(CVO_ERR_INVALID, "bad argument");
+    h->num_want = num_want; return CVO_OK;
+}
+
+int cvo_set_pcd_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera* cam) {
+    if (!h || !cam) return fail(CVO_ERR_INVALID, "null argument");
+    if (!h->init) {                                                  // cvo.cpp:352-360
+        if (!h->fixed) h->fixed.reset(new Cloud());
+        int rc = h->eng.generate_pcd(*h->fixed, bgr8, depth16, width, height, *cam, h->num_want); if (rc) return rc;
+        h->init = true;
+        return CVO_OK;
+    }
+    h->moving.reset(new Cloud());                                    // cvo.cpp:362-366
+    int rc = h->eng.generate_pcd(*h->moving, bgr8, depth16, width, height, *cam, h->num_want); if (rc) return rc;
+    h->num_fixed = h->fixed ? h->fixed->n : 0; h->num_moving = h->moving->n;   // cvo.cpp:370-371
+    h->A_nonzero = 0;                                                // cvo.cpp:385
+    return CVO_OK;
+}
+
+int cvo_get_cloud(cvo_handle h, int slot, float* xyz, float* feat, int cap, int* n) {
+    if (!h || !n) return fail(CVO_ERR_INVALID, "null argument");
+    Cloud* c = slot_cloud(h, slot);
+    *n = c ? c->n : 0;
+    if (!c || c->n == 0 || cap < c->n) return CVO_OK;
+    if (!xyz || !feat) return fail(CVO_ERR_INVALID, "null output array");
+    HIP_TRY(hipSetDevice(h->eng.device));
+    DevBuf tmp; int rc = tmp.ensure(sizeof(float) * 8 * (size_t)c->n); if (rc) return rc;
+    float* dx = static_cast<float*>(tmp.p); float* df = dx + 3 * (size_t)c->n;
+    hipError_t e = pcd_launch_unpack(c->rec(), c->n, dx, df, h->eng.stream);
+    if (e != hipSuccess) { tmp.release(); return fail(CVO_ERR_HIP, std::string("unpack kernel: ") + hipGetErrorString(e)); }
+    hipError_t e1 = hipMemcpyAsync(xyz, dx, sizeof(float) * 3 * (size_t)c->n, hipMemcpyDeviceToHost, h->eng.stream);
+    hipError_t e2 = hipMemcpyAsync(feat, df, sizeof(float) * 5 * (size_t)c->n, hipMemcpyDeviceToHost, h->eng.stream);
+    hipError_t e3 = hipStreamSynchronize(h->eng.stream);
+    tmp.release();
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(CVO_ERR_HIP, "cloud download failed");
+    return CVO_OK;
+}
+
+int cvo_get_selected_points(cvo_handle h, int slot, unsigned short* px, int cap, int* n) {
+    if (!h || !n) return fail(CVO_ERR_INVALID, "null argument");
+    Cloud* c = slot_cloud(h, slot);
+    *n = c ? c->n_px : 0;
+    if (!c || c->n_px == 0 || cap < c->n_px) return CVO_OK;
+    if (!px) return fail(CVO_ERR_INVALID, "null output array");
+    HIP_TRY(hipSetDevice(h->eng.device));
+    HIP_TRY(hipMemcpy(px, c->px.p, sizeof(unsigned short) * 2 * (size_t)c->n_px, hipMemcpyDeviceToHost));
+    return CVO_OK;
+}
+
 int cvo_align_traced(cvo_handle h, cvo_trace_row* trace, int trace_cap, int* trace_len) {
     if (!h) return fail(CVO_ERR_INVALID, "null handle");
     if (trace && !trace_len) return fail(CVO_ERR_INVALID, "trace_len required with trace");
@@ -586,6 +751,19 @@ int cvo_match_odometry(cvo_handle h, const float* xyz, const float* feat, int n,
     rc = cvo_align(h); if (rc) return rc;
     if (transform_out) for (int i = 0; i < 12; ++i) transform_out[i] = (double)h->transform.m[i];   // cvo.cpp:472
     return CVO_OK;
+}
+int cvo_match_odometry_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera* cam,
+                              double transform_out[12]) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (!h->init) return fail(CVO_ERR_NOT_INITIALIZED, "cvo not initialized !");    // cvo.cpp:463-466
+    int rc = cvo_set_pcd_images(h, bgr8, depth16, width, height, cam); if (rc) return rc;
+    rc = cvo_align(h); if (rc) return rc;
+    if (transform_out) for (int i = 0; i < 12; ++i) transform_out[i] = (double)h->transform.m[i];   // cvo.cpp:472
+    return CVO_OK;
+}
+int cvo_match_keyframe_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera* cam,
+                              double transform_out[12]) {
+    return cvo_match_odometry_images(h, bgr8, depth16, width, height, cam, transform_out);   // cvo.cpp:563-576 is the same body
 }
 int cvo_match_keyframe(cvo_handle h, const float* xyz, const float* feat, int n, double transform_out[12]) {
     return cvo_match_odometry(h, xyz, feat, n, transform_out);       // cvo.cpp:563-576 is the same body

@@ -153,6 +153,23 @@ def make_pair(index: int, cam=TUM1, max_deg: float = 2.0, max_trans: float = 0.0
     return Pair(fixed=fixed, moving=moving, true_transform=true_tf)
 
 
+def make_frames(index: int, cam=TUM1, max_deg: float = 2.0, max_trans: float = 0.03, base_seed: int = 20240):
+    """The two RGB-D frames of pair `index` as images (what cvo::set_pcd is given, cvo.cpp:345): (bgr8 h x w x 3,
+    depth16 h x w) for frame A and for frame B, plus the true transform.  Same scene / motion / noise as make_pair."""
+    rng = np.random.default_rng(base_seed + index)
+    planes = _make_scene(rng)
+    R_a, t_a = np.eye(3), np.zeros(3)
+    R_ab, t_ab = random_motion(rng, max_deg, max_trans)
+    img_a, dep_a = _render(planes, R_a, t_a, cam, rng)
+    img_b, dep_b = _render(planes, R_ab, t_ab, cam, rng)
+    return (img_a, dep_a), (img_b, dep_b), np.concatenate([R_ab, t_ab[:, None]], axis=1)
+
+
+def camera_tuple(cam):
+    """(scaling_factor, fx, fy, cx, cy) = cvo::camera_info (data_type.h:33-39)."""
+    return (float(cam["depth_factor"]), float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]))
+
+
 def make_small_pair(seed: int, n: int = 300, max_deg: float = 2.0, max_trans: float = 0.03) -> Pair:
     """Small unstructured pair for second-scale oracle tests: points on a few
     random surfaces with smooth colour fields, moving = rigidly displaced + noise."""

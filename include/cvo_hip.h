@@ -97,6 +97,30 @@ int cvo_set_pcd(cvo_handle h, const float* xyz, const float* feat, int n);
 int cvo_align(cvo_handle h);
 int cvo_align_traced(cvo_handle h, cvo_trace_row* trace, int trace_cap, int* trace_len);
 
+/* ---- set_pcd(RGB_img, dep_img) with the reference's pcd_generator on the GPU  cvo.cpp:345-386
+ * (SURVEY 8f next-1): gray image, 3-level gradient pyramid (pcd_generator.cpp:50-143), DSO pixel selection
+ * (thirdparty/PixelSelector2.cpp:34-436, num_want points, srand(3141592) sub-sampling pattern), back-projection
+ * and (B,G,R,dx,dy) features (pcd_generator.cpp:456-499, 590-612), written straight into the HBM cloud the
+ * alignment reads.  bgr8: height x width x 3 bytes (cv::Mat CV_8UC3, row stride 3*width); depth16: height x
+ * width uint16 (0 = invalid); cam = cvo::camera_info (data_type.h:33-39, read from the calib file by the ctor).
+ * Same slot semantics as cvo_set_pcd. */
+typedef struct cvo_camera { float scaling_factor, fx, fy, cx, cy; } cvo_camera;
+int cvo_set_pcd_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height,
+                       const cvo_camera* cam);
+/* pcd_generator::num_want (3000, pcd_generator.cpp:22) for this handle's later cvo_set_pcd_images calls */
+int cvo_set_num_want(cvo_handle h, int num_want);
+/* match_odometry / match_keyframe taking the images, exactly as the reference's signatures do */
+int cvo_match_odometry_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height,
+                              const cvo_camera* cam, double transform_out[12]);
+int cvo_match_keyframe_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height,
+                              const cvo_camera* cam, double transform_out[12]);
+/* a slot's cloud back in the reference layout (xyz: n x 3, feat: 5 channel-major arrays of n); *n = points, cap = room in
+ * the arrays (in points); nothing is written if cap < n */
+int cvo_get_cloud(cvo_handle h, int slot, float* xyz, float* feat, int cap, int* n);
+/* get_fixed_frame_selected_points / get_moving_frame_selected_points  cvo.hpp:272-276: pixel (x, y) of every point of a
+ * cloud made by cvo_set_pcd_images (n x 2 uint16); *n = 0 for clouds handed in by cvo_set_pcd */
+int cvo_get_selected_points(cvo_handle h, int slot, unsigned short* px, int cap, int* n);
+
 /* ---- match_odometry / match_keyframe  cvo.cpp:461-473, 563-576:
  * set_pcd + align; transform_out = 3x4 row-major double (Affine3d). */
 int cvo_match_odometry(cvo_handle h, const float* xyz, const float* feat, int n, double transform_out[12]);

@@ -16,9 +16,8 @@ REF_LIB_PATH = os.path.join(HERE, "_ref", "libref_nanoflann.so")
 
 def build(force: bool = False) -> None:
     """Compile the oracle (and oracle/_ref when /root/reference exists)."""
-    src = os.path.join(HERE, "cvo_oracle.cpp")
-    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "cvo_oracle.h")))
+    srcs = [os.path.join(HERE, f) for f in ("cvo_oracle.cpp", "pcd_oracle.cpp", "cvo_oracle.h")]
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", HERE, "-s", os.path.join(HERE, "libcvo_oracle.so")])
     if os.path.exists("/root/reference/thirdparty/cvo/thirdparty/nanoflann.hpp") and (force or not os.path.exists(REF_LIB_PATH)):
@@ -252,3 +251,36 @@ def radius_search(cloud_xyz, query, r2, use_kdtree, cap=4096):
     n = lib().orc_radius_search(cp, c.shape[0], qp, float(r2), idx.ctypes.data_as(C.POINTER(C.c_int)),
                                 d2.ctypes.data_as(C.POINTER(C.c_float)), cap, int(use_kdtree))
     return idx[:n], d2[:n]
+
+
+# ----------------------------------------------------------------------------- point-cloud generator (oracle/pcd_oracle.cpp)
+class Camera(C.Structure):
+    _fields_ = [("scaling_factor", C.c_float), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
+def glibc_rand_bytes(seed: int, n: int) -> np.ndarray:
+    out = np.zeros(n, np.uint8)
+    lib().orc_glibc_rand_bytes(C.c_uint(seed), out.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_long(n))
+    return out
+
+
+def pcd_generate(bgr8, depth16, camera, num_want: int = 3000, cap: int = 20000, debug: bool = False):
+    """pcd_generator::create_pointcloud(1, ...) of the reference on one frame (cvo.cpp:355-366).
+    camera = (scaling_factor, fx, fy, cx, cy).  Returns dict(xyz (n,3), feat (5,n), px (n,2)[, gray, map, ths, info])."""
+    bgr = np.ascontiguousarray(bgr8, np.uint8); dep = np.ascontiguousarray(depth16, np.uint16)
+    h, w = dep.shape
+    assert bgr.shape == (h, w, 3)
+    cam = Camera(*[float(v) for v in camera])
+    xyz = np.zeros((cap, 3), np.float32); feat = np.zeros((5, cap), np.float32); px = np.zeros((cap, 2), np.uint16)
+    gray = np.zeros((h, w), np.uint8); mp = np.zeros((h, w), np.float32); ths = np.zeros((h // 32, w // 32), np.float32); info = np.zeros(4, np.int32)
+    L = lib()
+    L.orc_pcd_generate.restype = C.c_int
+    n = L.orc_pcd_generate(bgr.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p), C.c_int(w), C.c_int(h), C.byref(cam), C.c_int(num_want),
+                           xyz.ctypes.data_as(C.c_void_p), feat.ctypes.data_as(C.c_void_p), px.ctypes.data_as(C.c_void_p), C.c_int(cap),
+                           gray.ctypes.data_as(C.c_void_p), mp.ctypes.data_as(C.c_void_p), ths.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p))
+    if n < 0:
+        raise ValueError(f"cap {cap} too small: {-n} points")
+    out = dict(xyz=xyz[:n].copy(), feat=feat[:, :n].copy(), px=px[:n].copy(), n=n)
+    if debug:
+        out.update(gray=gray, map=mp, ths=ths, info=info)
+    return out

@@ -9,6 +9,8 @@ run here, so the fixtures are:
                      (single thread, brute-force search) -- regression pins for the oracle
                      and known inputs/outputs for the HIP path
   tum_pair_0.npz     one full-size (3072-point) synthetic TUM-shape pair, same content
+  pcd_frame_small.npz  a 208x160 crop of a synthetic RGB-D frame + the oracle's point cloud for it (pcd generator,
+                     SURVEY 8f next-1)
 Run:  python tests/golden/make_golden.py
 """
 import json
@@ -80,10 +82,24 @@ def run_pair(pair, trace_cap=400):
         cos_angle=np.float32(sc["cos_angle"]), post_hessian=sc["post_hessian"], inliers=np.int32(sc["inliers"]))
 
 
+def pcd_fixture():
+    (fa, da), _, _ = synth.make_frames(7)
+    bgr = np.ascontiguousarray(fa[100:260, 200:408]); dep = np.ascontiguousarray(da[100:260, 200:408])      # 160 x 208
+    cam = synth.camera_tuple(synth.TUM1)
+    r = po.pcd_generate(bgr, dep, cam, num_want=260, debug=True)
+    np.savez_compressed(os.path.join(HERE, "pcd_frame_small.npz"), bgr=bgr, depth=dep, camera=np.array(cam, np.float32), num_want=260,
+                        px=r["px"], xyz=r["xyz"], feat=r["feat"], info=r["info"])
+    print("pcd_frame_small.npz:", r["n"], "points, info", r["info"])
+
+
+
 if __name__ == "__main__":
     po.build()
+    if "--pcd-only" in sys.argv:
+        pcd_fixture(); sys.exit(0)
     closed_forms()
     for seed in (11, 12, 13):
         np.savez_compressed(os.path.join(HERE, f"small_pair_{seed}.npz"), **run_pair(synth.make_small_pair(seed, n=300)))
     np.savez_compressed(os.path.join(HERE, "tum_pair_0.npz"), **run_pair(synth.make_pair(0)))
+    pcd_fixture()
     print("golden fixtures written to", HERE)
