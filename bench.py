@@ -145,8 +145,30 @@ def latency_probe(ca, pairs, device):
         t0 = time.perf_counter(); B.align(n); la.append(time.perf_counter() - t0)
         t0 = time.perf_counter(); B.compute_innerproduct_lc(eye, eye, eye); ls.append(time.perf_counter() - t0)
     B.close()
+    # the point-cloud generator (cvo.set_pcd on the images): GPU vs the oracle's CPU restatement
+    from cvo_slam_amd import synth
+    (fa, da), _, _ = synth.make_frames(0)
+    camt = synth.camera_tuple(synth.TUM1)
+    g = ca.Cvo(device=device)
+    pg = []
+    for _ in range(7):
+        t0 = time.perf_counter(); g.set_pcd_images(fa, da, camt); pg.append(time.perf_counter() - t0)
+    n_pts = g.get_fixed_and_moving_number()[1] or g.get_cloud(0)[0].shape[0]
+    g.close()
+    pc = []
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as po
+        po.build()
+        for _ in range(5):
+            t0 = time.perf_counter(); po.pcd_generate(fa, da, camt); pc.append(time.perf_counter() - t0)
+    except Exception:
+        pc = [float("nan")]
     med = lambda v: 1e3 * float(np.median(v))
+    img_bytes = fa.size + 2 * da.size
     return {"single_pair_align_ms": med(al), "single_pair_score_block_ms": med(sc), "lc_candidates": n,
+            "set_pcd_images_ms": med(pg[2:]), "set_pcd_images_points": int(n_pts), "set_pcd_images_input_MB": img_bytes / 1e6,
+            "set_pcd_images_cpu_port_ms": med(pc),
             "lc_batch_align_ms": med(la), "lc_batch_score_block_ms": med(ls), "note": "host wall time per call, median of 5, automatic workgroup count"}
 
 

@@ -32,8 +32,10 @@ hipError_t pcd_launch_pyramid(const uint8_t* bgr, int w, int h, float* I0, float
 hipError_t pcd_launch_thresholds(const float* abs0, int w, int h, float* ths, float* ths_smoothed, hipStream_t s);
 hipError_t pcd_launch_select(const float* abs0, const float* abs1, const float* abs2, const float* ths_smoothed, int w, int h, int pot, uint8_t* map, int* counts,
                              hipStream_t s);
-hipError_t pcd_launch_compact(uint8_t* map, const uint8_t* pattern, int subsample, int char_th, const uint16_t* depth, const uint8_t* bgr, const float* dx0,
-                              const float* dy0, int w, int h, const float cam[5], int write, int n_points, float* cloud, uint16_t* px, int* result, hipStream_t s);
+int pcd_tiles(int w, int h);
+hipError_t pcd_launch_subsample(uint8_t* map, const uint8_t* pattern, int subsample, int char_th, const uint16_t* depth, int w, int h, int* tile_counts, hipStream_t s);
+hipError_t pcd_launch_cloud(const uint8_t* map, const uint16_t* depth, const uint8_t* bgr, const float* dx0, const float* dy0, int w, int h, const float cam[5],
+                            const int* tile_counts, int n_points, float* cloud, uint16_t* px, hipStream_t s);
 hipError_t pcd_launch_unpack(const float* cloud, int n, float* xyz, float* feat, hipStream_t s);
 int score_nout();
 int score_row_blocks(int na);
@@ -149,7 +151,7 @@ struct Engine {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
         d_scoredescs.release(); h_scoredescs.release(); h_counts.release();
-        for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts}) b->release();
+        for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts, &d_tiles}) b->release();
         for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -182,7 +184,7 @@ struct Engine {
     }
 
     // ---- pcd_generator on the GPU (cvo_pcd_kernels.hip).  Image-sized scratch lives with the engine.
-    DevBuf d_bgr, d_depth, d_I0, d_I1, d_I2, d_dx0, d_dy0, d_abs0, d_abs1, d_abs2, d_ths, d_thsS, d_map, d_pattern, d_counts;
+    DevBuf d_bgr, d_depth, d_I0, d_I1, d_I2, d_dx0, d_dy0, d_abs0, d_abs1, d_abs2, d_ths, d_thsS, d_map, d_pattern, d_counts, d_tiles;
     PinBuf h_counts;
     int pattern_len = 0;
     // glibc srand(seed); rand() & 0xFF, n times (PixelSelector2.cpp:36-38): TYPE_3 additive feedback generator
@@ -267,20 +269,24 @@ struct Engine {
         const int subsample = (quotia < 0.95) ? 1 : 0;                  // :252-268
         const int char_th = subsample ? (int)(unsigned char)(255 * quotia) : 255;
         const float camv[5] = {cam.scaling_factor, cam.fx, cam.fy, cam.cx, cam.cy};
-        e = pcd_launch_compact((uint8_t*)d_map.p, (const uint8_t*)d_pattern.p, subsample, char_th, (const uint16_t*)d_depth.p, (const uint8_t*)d_bgr.p, dx0, dy0,
-                               w, h, camv, 0, 0, nullptr, nullptr, (int*)d_counts.p, stream);
-        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd count: ") + hipGetErrorString(e));
-        HIP_TRY(hipMemcpyAsync(hc, d_counts.p, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
+        const int nt = pcd_tiles(w, h);
+        if ((rc = d_tiles.ensure(sizeof(int) * 3 * (size_t)nt))) return rc;
+        if ((rc = h_counts.ensure(sizeof(int) * std::max(8, 3 * nt)))) return rc;
+        hc = static_cast<int*>(h_counts.p);
+        e = pcd_launch_subsample((uint8_t*)d_map.p, (const uint8_t*)d_pattern.p, subsample, char_th, (const uint16_t*)d_depth.p, w, h, (int*)d_tiles.p, stream);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd sub-sampling: ") + hipGetErrorString(e));
+        HIP_TRY(hipMemcpyAsync(hc, d_tiles.p, sizeof(int) * 3 * (size_t)nt, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        const int npts = hc[0];
+        int npts = 0;
+        for (int t = 0; t < nt; ++t) npts += hc[nt + t];                 // kept pixels with a valid depth = points (pcd_generator.cpp:471)
         if (npts > 65535) return fail(CVO_ERR_INVALID, "more than 65535 points per cloud is not supported (16-bit column indices)");
         c.n = npts; c.n_px = npts;
         if (npts == 0) return CVO_OK;
         if ((rc = c.buf.ensure((size_t)npts * REC * sizeof(float)))) return rc;
         if ((rc = c.px.ensure((size_t)npts * 2 * sizeof(uint16_t)))) return rc;
-        e = pcd_launch_compact((uint8_t*)d_map.p, (const uint8_t*)d_pattern.p, subsample, char_th, (const uint16_t*)d_depth.p, (const uint8_t*)d_bgr.p, dx0, dy0,
-                               w, h, camv, 1, npts, c.rec(), (uint16_t*)c.px.p, (int*)d_counts.p, stream);
-        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd compact: ") + hipGetErrorString(e));
+        e = pcd_launch_cloud((const uint8_t*)d_map.p, (const uint16_t*)d_depth.p, (const uint8_t*)d_bgr.p, dx0, dy0, w, h, camv, (const int*)d_tiles.p, npts, c.rec(),
+                             (uint16_t*)c.px.p, stream);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd cloud: ") + hipGetErrorString(e));
         HIP_TRY(hipStreamSynchronize(stream));
         return CVO_OK;
     }

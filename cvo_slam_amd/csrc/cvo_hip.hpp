@@ -62,6 +62,23 @@ public:
         if (rc != CVO_OK) throw std::runtime_error(std::string("match_keyframe: ") + cvo_last_error());
         sync();
     }
+    // the reference's own signatures take the images (cvo.cpp:345, 461, 563): point-cloud generation on the GPU
+    void set_pcd(const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera& cam) {
+        if (cvo_set_pcd_images(h_, bgr8, depth16, width, height, &cam) != CVO_OK) throw std::runtime_error(std::string("set_pcd: ") + cvo_last_error());
+        sync();
+    }
+    void match_keyframe(const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera& cam, Affine3d& transformd) {
+        const int rc = cvo_match_keyframe_images(h_, bgr8, depth16, width, height, &cam, transformd.m);
+        if (rc == CVO_ERR_NOT_INITIALIZED) { std::printf("cvo not initialized !\n"); return; }
+        if (rc != CVO_OK) throw std::runtime_error(std::string("match_keyframe: ") + cvo_last_error());
+        sync();
+    }
+    void match_odometry(const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera& cam, Affine3d& transformd) {
+        const int rc = cvo_match_odometry_images(h_, bgr8, depth16, width, height, &cam, transformd.m);
+        if (rc == CVO_ERR_NOT_INITIALIZED) { std::printf("cvo not initialized !\n"); return; }
+        if (rc != CVO_OK) throw std::runtime_error(std::string("match_odometry: ") + cvo_last_error());
+        sync();
+    }
     void align() { if (cvo_align(h_) != CVO_OK) throw std::runtime_error(std::string("align: ") + cvo_last_error()); sync(); }
 
     void compute_innerproduct(inn_p& inn_pre, inn_p& inn_post, Matrix6d& post_hessian, Affine3f& tran, int& inliers,

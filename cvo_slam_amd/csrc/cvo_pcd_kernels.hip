@@ -8,8 +8,8 @@
 //   cloud                 get_points_from_pixels + get_features(type 1), pcd_generator.cpp:456-499, 590-612
 // Image-sized, memory-bound work: every kernel is one pass over w*h (or fewer) elements with
 // coalesced accesses; the selection has no cross-block dependence (the reference's random
-// direction table is read but unused, setting_selectDirectionDistribution = false), so a
-// thread owns one 4pot x 4pot block.  The cloud is written straight into the two float4
+// direction table is read but unused, setting_selectDirectionDistribution = false), so 16
+// lanes share one 4pot x 4pot block.  The cloud is written straight into the two float4
 // planes the alignment kernels read: no host round trip for the points.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -88,109 +88,167 @@ __global__ void pcd_smooth_kernel(const float* __restrict__ ths, int w32, int h3
     ths_smoothed[i] = (sum / num) * (sum / num);
 }
 
-// ---- select (PixelSelector2.cpp:286-433): one thread walks one 4pot x 4pot block in the reference's order.
+// ---- select (PixelSelector2.cpp:286-433).  16 lanes share one 4pot x 4pot block, one lane per pot x pot cell, cells numbered
+// in the reference's traversal order (2pot block by 2pot block).  With setting_selectDirectionDistribution = false the walk
+// reduces to three order-free rules, each a "first maximum in traversal order":
+//   a cell picks its largest |grad|^2 above the level-0 threshold (map = 1);
+//   a 2pot block none of whose pixels passes level 0 picks its largest level-1 value above the level-1 threshold (map = 2);
+//   a 4pot block none of whose pixels passes level 0 or level 1 picks its largest level-2 value above its threshold (map = 4).
+// (In the reference a level-0 hit sets bestIdx3 = bestIdx4 = -2 for good and a level-1 hit sets bestIdx4 = -2 for good: whatever
+// was found at the coarser levels before is dropped, and nothing is looked for after.)
 // map: 0 / 1 / 2 / 4 per pixel (pre-zeroed); counts[0..2] += n2, n3, n4.
-__global__ __launch_bounds__(64) void pcd_select_kernel(const float* __restrict__ abs0, const float* __restrict__ abs1, const float* __restrict__ abs2,
-                                                        const float* __restrict__ ths_smoothed, int w, int h, int pot, uint8_t* __restrict__ map,
-                                                        int* __restrict__ counts) {
+__global__ __launch_bounds__(256) void pcd_select_kernel(const float* __restrict__ abs0, const float* __restrict__ abs1, const float* __restrict__ abs2,
+                                                         const float* __restrict__ ths_smoothed, int w, int h, int pot, uint8_t* __restrict__ map,
+                                                         int* __restrict__ counts) {
     const int nbx = (w + 4 * pot - 1) / (4 * pot), nby = (h + 4 * pot - 1) / (4 * pot);
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gt >> 4, sub = gt & 15, lane = threadIdx.x & 63;
+    const int b3 = sub >> 2, c2 = sub & 3;                            // 2pot block inside the 4pot block, cell inside the 2pot block
     int n2 = 0, n3 = 0, n4 = 0;
+    bool q0 = false, q1 = false, q2 = false;
+    int best0 = -1, best1 = -1, best2 = -1; float val0 = 0.f, val1 = 0.f, val2 = 0.f;
     if (b < nbx * nby) {
         const int x4 = (b % nbx) * 4 * pot, y4 = (b / nbx) * 4 * pot;
+        const int x0 = x4 + (b3 & 1) * 2 * pot + (c2 & 1) * pot, y0 = y4 + (b3 >> 1) * 2 * pot + (c2 >> 1) * pot;
         const int w1 = w / 2, w2 = w / 4, w32 = w / 32;
         const float dw1 = 0.75f, dw2 = dw1 * dw1;                     // setting_gradDownweightPerLevel
-        const int my3 = min(4 * pot, h - y4), mx3 = min(4 * pot, w - x4);
-        int best4 = -1; float val4 = 0.f;
-        for (int y3 = 0; y3 < my3; y3 += 2 * pot) for (int x3 = 0; x3 < mx3; x3 += 2 * pot) {
-            const int x34 = x3 + x4, y34 = y3 + y4;
-            const int my2 = min(2 * pot, h - y34), mx2 = min(2 * pot, w - x34);
-            int best3 = -1; float val3 = 0.f;
-            for (int y2 = 0; y2 < my2; y2 += pot) for (int x2 = 0; x2 < mx2; x2 += pot) {
-                const int x234 = x2 + x34, y234 = y2 + y34;
-                const int my1 = min(pot, h - y234), mx1 = min(pot, w - x234);
-                int best2 = -1; float val2 = 0.f;
-                for (int y1 = 0; y1 < my1; ++y1) for (int x1 = 0; x1 < mx1; ++x1) {
-                    const int xf = x1 + x234, yf = y1 + y234, idx = xf + w * yf;
-                    if (xf < 4 || xf >= w - 5 || yf < 4 || yf > h - 4) continue;
-                    const float th0 = ths_smoothed[(xf >> 5) + (yf >> 5) * w32];   // rows past h/32 read the zeroed slack, like the reference
-                    const float th1 = th0 * dw1, th2 = th1 * dw2;
-                    const float ag0 = abs0[idx];
-                    if (ag0 > th0 && ag0 > val2) { val2 = ag0; best2 = idx; best3 = -2; best4 = -2; }
-                    if (best3 == -2) continue;
-                    const float ag1 = abs1[(int)(xf * 0.5f + 0.25f) + (int)(yf * 0.5f + 0.25f) * w1];
-                    if (ag1 > th1 && ag1 > val3) { val3 = ag1; best3 = idx; best4 = -2; }
-                    if (best4 == -2) continue;
-                    const float ag2 = abs2[(int)(xf * 0.25f + 0.125f) + (int)(yf * 0.25f + 0.125f) * w2];
-                    if (ag2 > th2 && ag2 > val4) { val4 = ag2; best4 = idx; }
-                }
-                if (best2 > 0) { map[best2] = 1; val3 = 1e10f; ++n2; }
-            }
-            if (best3 > 0) { map[best3] = 2; val4 = 1e10f; ++n3; }
+        const int my1 = min(pot, h - y0), mx1 = min(pot, w - x0);
+        for (int y1 = 0; y1 < my1; ++y1) for (int x1 = 0; x1 < mx1; ++x1) {
+            const int xf = x1 + x0, yf = y1 + y0, idx = xf + w * yf;
+            if (xf < 4 || xf >= w - 5 || yf < 4 || yf > h - 4) continue;
+            const float th0 = ths_smoothed[(xf >> 5) + (yf >> 5) * w32];   // rows past h/32 read the zeroed slack, like the reference
+            const float th1 = th0 * dw1, th2 = th1 * dw2;
+            const float ag0 = abs0[idx];
+            const float ag1 = abs1[(int)(xf * 0.5f + 0.25f) + (int)(yf * 0.5f + 0.25f) * w1];
+            const float ag2 = abs2[(int)(xf * 0.25f + 0.125f) + (int)(yf * 0.25f + 0.125f) * w2];
+            if (ag0 > th0) { q0 = true; if (ag0 > val0) { val0 = ag0; best0 = idx; } }
+            if (ag1 > th1) { q1 = true; if (ag1 > val1) { val1 = ag1; best1 = idx; } }
+            if (ag2 > th2) { q2 = true; if (ag2 > val2) { val2 = ag2; best2 = idx; } }
         }
-        if (best4 > 0) { map[best4] = 4; ++n4; }
+        if (best0 > 0) { map[best0] = 1; ++n2; }
     }
+    // level 1: the first lane of every group of 4 walks its group's cells in order
+    const int g4 = lane & ~3, g16 = lane & ~15;
+    bool any0_4 = false; int pick1 = -1; float pv1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool k0 = __shfl((int)q0, g4 + k, 64) != 0, k1 = __shfl((int)q1, g4 + k, 64) != 0;
+        const float v = __shfl(val1, g4 + k, 64); const int ix = __shfl(best1, g4 + k, 64);
+        any0_4 |= k0;
+        if (k1 && v > pv1) { pv1 = v; pick1 = ix; }
+    }
+    if (c2 == 0 && !any0_4 && pick1 > 0) { map[pick1] = 2; ++n3; }
+    // level 2: the first lane of every group of 16
+    bool any01_16 = false; int pick2 = -1; float pv2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const bool k01 = (__shfl((int)q0, g16 + k, 64) | __shfl((int)q1, g16 + k, 64)) != 0, k2 = __shfl((int)q2, g16 + k, 64) != 0;
+        const float v = __shfl(val2, g16 + k, 64); const int ix = __shfl(best2, g16 + k, 64);
+        any01_16 |= k01;
+        if (k2 && v > pv2) { pv2 = v; pick2 = ix; }
+    }
+    if (sub == 0 && !any01_16 && pick2 > 0) { map[pick2] = 4; ++n4; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { n2 += __shfl_xor(n2, off, 64); n3 += __shfl_xor(n3, off, 64); n4 += __shfl_xor(n4, off, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[0], n2); atomicAdd(&counts[1], n3); atomicAdd(&counts[2], n4); }
+    if (lane == 0) { atomicAdd(&counts[0], n2); atomicAdd(&counts[1], n3); atomicAdd(&counts[2], n4); }
 }
 
-// ---- makeMaps sub-sampling (PixelSelector2.cpp:252-268) + get_points_from_pixels' filter (pcd_generator.cpp:471): ONE workgroup of
-// 1024 threads scans the image in order.  Pass `write` = 0 only counts (result[0] = points with valid depth, result[1] = pixels left
-// in the map); pass 1 also writes the cloud planes, the selected pixels and clears dropped map entries.
-constexpr int PCD_SCAN_THREADS = 1024;
-__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* lds, int& total) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
-    if (lane == 63) lds[wave] = inc;
-    __syncthreads();
-    int base = 0, tot = 0;
-    for (int k = 0; k < PCD_SCAN_THREADS / 64; ++k) { const int s = lds[k]; if (k < wave) base += s; tot += s; }
-    __syncthreads();
-    total = tot;
-    return base + inc - v;
-}
+// ---- makeMaps sub-sampling (PixelSelector2.cpp:252-268) + get_points_from_pixels' filter (pcd_generator.cpp:471), order
+// preserving and coalesced: a workgroup owns a tile of PCD_TILE consecutive pixels, its waves take 64 consecutive pixels at a
+// time (ballot + popcount give every marked pixel its rank), tiles are chained by per-tile counts (a tile adds up the counts
+// of the tiles before it: there are only w*h/4096 of them).
+//   pass 1  marked pixels per tile
+//   pass 2  rank among ALL marked pixels -> position in the random byte pattern -> dropped pixels leave the map;
+//           per tile: pixels kept, and kept with a valid depth
+//   pass 3  (the cloud is allocated by then) rank among the kept, valid pixels = index of the point: planes + pixel list
+constexpr int PCD_TILE = 4096;
+constexpr int PCD_TILE_THREADS = 256;
 
 struct PcdCam { float scaling_factor, fx, fy, cx, cy; };
 
-__global__ __launch_bounds__(PCD_SCAN_THREADS) void pcd_compact_kernel(uint8_t* __restrict__ map, const uint8_t* __restrict__ pattern, int subsample, int char_th,
-                                                                       const uint16_t* __restrict__ depth, const uint8_t* __restrict__ bgr,
-                                                                       const float* __restrict__ dx0, const float* __restrict__ dy0, int w, int h, PcdCam cam,
-                                                                       int write, int n_points, float* __restrict__ cloud, uint16_t* __restrict__ px,
-                                                                       int* __restrict__ result) {
-    __shared__ int lds[PCD_SCAN_THREADS / 64];
-    const int tid = threadIdx.x, n = w * h;
-    const int per = (n + PCD_SCAN_THREADS - 1) / PCD_SCAN_THREADS;
-    const int i0 = min(n, tid * per), i1 = min(n, i0 + per);
-    int marked = 0;
-    for (int i = i0; i < i1; ++i) marked += map[i] != 0;
-    int total_marked = 0;
-    int rn = block_exclusive_scan_1024(marked, lds, total_marked);      // position in the random pattern of this thread's first marked pixel
-    int kept_valid = 0, kept = 0;
-    for (int i = i0; i < i1; ++i) {
-        if (map[i] == 0) continue;
-        const bool keep = !(subsample && pattern[rn] > char_th);
-        ++rn;
-        if (keep) { ++kept; kept_valid += depth[i] != 0; }
+// exclusive prefix of `flag` over the workgroup's current 256 pixels, in pixel order; `run` carries on across chunks
+__device__ __forceinline__ int chunk_rank(bool flag, int* wsum, int& run) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int before = run, all = 0;
+#pragma unroll
+    for (int k = 0; k < PCD_TILE_THREADS / 64; ++k) { const int c = wsum[k]; if (k < wave) before += c; all += c; }
+    __syncthreads();
+    run += all;
+    return before + __popcll(m & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ int tiles_before(const int* counts, int tile, int* lds) {
+    int v = 0;
+    for (int k = threadIdx.x; k < tile; k += PCD_TILE_THREADS) v += counts[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < PCD_TILE_THREADS / 64; ++k) s += lds[k];
+    __syncthreads();
+    return s;
+}
+
+__global__ __launch_bounds__(PCD_TILE_THREADS) void pcd_count_marked_kernel(const uint8_t* __restrict__ map, int n, int* __restrict__ tile_marked) {
+    __shared__ int wsum[PCD_TILE_THREADS / 64];
+    const int base = blockIdx.x * PCD_TILE;
+    int cnt = 0;
+    for (int k = threadIdx.x; k < PCD_TILE; k += PCD_TILE_THREADS) { const int i = base + k; cnt += (i < n && map[i] != 0) ? 1 : 0; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int k = 0; k < PCD_TILE_THREADS / 64; ++k) s += wsum[k]; tile_marked[blockIdx.x] = s; }
+}
+
+__global__ __launch_bounds__(PCD_TILE_THREADS) void pcd_subsample_kernel(uint8_t* __restrict__ map, const uint8_t* __restrict__ pattern, int subsample, int char_th,
+                                                                         const uint16_t* __restrict__ depth, int n, const int* __restrict__ tile_marked,
+                                                                         int* __restrict__ tile_valid, int* __restrict__ tile_kept) {
+    __shared__ int wsum[PCD_TILE_THREADS / 64];
+    const int base = blockIdx.x * PCD_TILE;
+    int run = tiles_before(tile_marked, blockIdx.x, wsum);            // marked pixels in front of this tile = index into the byte pattern
+    int valid = 0, kept = 0;
+    for (int k0 = 0; k0 < PCD_TILE; k0 += PCD_TILE_THREADS) {
+        const int i = base + k0 + threadIdx.x;
+        const bool marked = i < n && map[i] != 0;
+        const int rn = chunk_rank(marked, wsum, run);
+        if (marked) {
+            const bool keep = !(subsample && pattern[rn] > char_th);  // PixelSelector2.cpp:261-265
+            if (!keep) map[i] = 0;
+            else { ++kept; valid += depth[i] != 0; }
+        }
     }
-    int total_valid = 0, total_kept = 0;
-    int at = block_exclusive_scan_1024(kept_valid, lds, total_valid);
-    (void)block_exclusive_scan_1024(kept, lds, total_kept);
-    if (tid == 0) { result[0] = total_valid; result[1] = total_kept; result[2] = total_marked; }
-    if (!write) return;
-    rn -= marked;                                                       // back to this thread's first marked pixel
-    for (int i = i0; i < i1; ++i) {
-        if (map[i] == 0) continue;
-        const bool keep = !(subsample && pattern[rn] > char_th);
-        ++rn;
-        if (!keep) { map[i] = 0; continue; }
-        const int dep = depth[i];
-        if (dep == 0) continue;
-        if (at < n_points) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { valid += __shfl_xor(valid, off, 64); kept += __shfl_xor(kept, off, 64); }
+    __shared__ int red[2][PCD_TILE_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = valid; red[1][threadIdx.x >> 6] = kept; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < PCD_TILE_THREADS / 64; ++k) { a += red[0][k]; b += red[1][k]; }
+        tile_valid[blockIdx.x] = a; tile_kept[blockIdx.x] = b;
+    }
+}
+
+__global__ __launch_bounds__(PCD_TILE_THREADS) void pcd_cloud_kernel(const uint8_t* __restrict__ map, const uint16_t* __restrict__ depth, const uint8_t* __restrict__ bgr,
+                                                                     const float* __restrict__ dx0, const float* __restrict__ dy0, int w, int n, PcdCam cam,
+                                                                     const int* __restrict__ tile_valid, int n_points, float* __restrict__ cloud,
+                                                                     uint16_t* __restrict__ px) {
+    __shared__ int wsum[PCD_TILE_THREADS / 64];
+    const int base = blockIdx.x * PCD_TILE;
+    int run = tiles_before(tile_valid, blockIdx.x, wsum);
+    for (int k0 = 0; k0 < PCD_TILE; k0 += PCD_TILE_THREADS) {
+        const int i = base + k0 + threadIdx.x;
+        const int dep = i < n ? (int)depth[i] : 0;
+        const bool ok = i < n && map[i] != 0 && dep != 0;             // pcd_generator.cpp:471
+        const int at = chunk_rank(ok, wsum, run);
+        if (ok && at < n_points) {
             const int x = i % w, y = i / w;
-            const float p2 = (float)dep / cam.scaling_factor;           // pcd_generator.cpp:473-476
+            const float p2 = (float)dep / cam.scaling_factor;         // pcd_generator.cpp:473-476
             const float p0 = ((float)x - cam.cx) * p2 / cam.fx;
             const float p1 = ((float)y - cam.cy) * p2 / cam.fy;
             float* lo = cloud + lo_off(at); float* hi = cloud + hi_off(n_points, at);
@@ -199,7 +257,6 @@ __global__ __launch_bounds__(PCD_SCAN_THREADS) void pcd_compact_kernel(uint8_t* 
             hi[2] = dx0[i]; hi[3] = dy0[i];                                                      // :608-609
             px[2 * at] = (uint16_t)x; px[2 * at + 1] = (uint16_t)y;
         }
-        ++at;
     }
 }
 
@@ -237,14 +294,23 @@ hipError_t pcd_launch_thresholds(const float* abs0, int w, int h, float* ths, fl
 hipError_t pcd_launch_select(const float* abs0, const float* abs1, const float* abs2, const float* ths_smoothed, int w, int h, int pot, uint8_t* map, int* counts,
                              hipStream_t s) {
     const int nb = ((w + 4 * pot - 1) / (4 * pot)) * ((h + 4 * pot - 1) / (4 * pot));
-    hipLaunchKernelGGL(pcd_select_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, abs0, abs1, abs2, ths_smoothed, w, h, pot, map, counts);
+    hipLaunchKernelGGL(pcd_select_kernel, dim3((nb * 16 + 255) / 256), dim3(256), 0, s, abs0, abs1, abs2, ths_smoothed, w, h, pot, map, counts);
     return hipGetLastError();
 }
-hipError_t pcd_launch_compact(uint8_t* map, const uint8_t* pattern, int subsample, int char_th, const uint16_t* depth, const uint8_t* bgr, const float* dx0,
-                              const float* dy0, int w, int h, const float cam[5], int write, int n_points, float* cloud, uint16_t* px, int* result, hipStream_t s) {
+int pcd_tiles(int w, int h) { return (w * h + PCD_TILE - 1) / PCD_TILE; }
+// tile_counts: 3 arrays of pcd_tiles() ints {marked, valid, kept}
+hipError_t pcd_launch_subsample(uint8_t* map, const uint8_t* pattern, int subsample, int char_th, const uint16_t* depth, int w, int h, int* tile_counts, hipStream_t s) {
+    const int nt = pcd_tiles(w, h);
+    hipLaunchKernelGGL(pcd_count_marked_kernel, dim3(nt), dim3(PCD_TILE_THREADS), 0, s, map, w * h, tile_counts);
+    hipLaunchKernelGGL(pcd_subsample_kernel, dim3(nt), dim3(PCD_TILE_THREADS), 0, s, map, pattern, subsample, char_th, depth, w * h, tile_counts, tile_counts + nt,
+                       tile_counts + 2 * nt);
+    return hipGetLastError();
+}
+hipError_t pcd_launch_cloud(const uint8_t* map, const uint16_t* depth, const uint8_t* bgr, const float* dx0, const float* dy0, int w, int h, const float cam[5],
+                            const int* tile_counts, int n_points, float* cloud, uint16_t* px, hipStream_t s) {
+    const int nt = pcd_tiles(w, h);
     PcdCam c{cam[0], cam[1], cam[2], cam[3], cam[4]};
-    hipLaunchKernelGGL(pcd_compact_kernel, dim3(1), dim3(PCD_SCAN_THREADS), 0, s, map, pattern, subsample, char_th, depth, bgr, dx0, dy0, w, h, c, write, n_points,
-                       cloud, px, result);
+    hipLaunchKernelGGL(pcd_cloud_kernel, dim3(nt), dim3(PCD_TILE_THREADS), 0, s, map, depth, bgr, dx0, dy0, w, w * h, c, tile_counts + nt, n_points, cloud, px);
     return hipGetLastError();
 }
 hipError_t pcd_launch_unpack(const float* cloud, int n, float* xyz, float* feat, hipStream_t s) {

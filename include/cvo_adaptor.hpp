@@ -6,9 +6,10 @@
 // `cvo_hip`.  local_tracker.cpp / keyframe_graph.cpp compile unchanged: every
 // public member and signature they use is here (cvo.hpp:139-144, 216-276).
 //
-// Needs the reference's own dependencies (Eigen3, OpenCV core) and its pcd_generator
-// (thirdparty/cvo/include/pcd_generator.hpp), which stays on the CPU side of the boundary:
-// images -> selected pixels -> cloud is SURVEY 8f "next-1", not part of this hot path.
+// Needs the reference's own dependencies (Eigen3, OpenCV core).  Images -> selected pixels -> cloud
+// (the reference's pcd_generator + DSO PixelSelector) runs on the GPU too (cvo_set_pcd_images); define
+// CVO_ADAPTOR_CPU_PCD to keep the reference's own CPU pcd_generator in front of the boundary instead
+// (it then needs thirdparty/cvo/include/pcd_generator.hpp and its sources in the `cvo` target).
 // NOT compiled in the build container (no Eigen/OpenCV there); the dependency-free twin that IS
 // compiled and run is cvo_slam_amd/csrc/cvo_hip.hpp.
 #ifndef CVO_H
@@ -24,7 +25,9 @@
 #include <opencv2/core/mat.hpp>
 
 #include "data_type.h"        // reference: cvo::frame, cvo::point_cloud, cvo::camera_info
-#include "pcd_generator.hpp"  // reference: image -> point cloud (CPU)
+#ifdef CVO_ADAPTOR_CPU_PCD
+#include "pcd_generator.hpp"  // reference: image -> point cloud on the CPU
+#endif
 #include "cvo_hip.h"
 
 namespace cvo {
@@ -52,15 +55,31 @@ class cvo {
         from12(t, transform); from12(p, prev_transform); from12(ac, accum_transform);
         int i = 0; cvo_get_init(h_, &i); init = i != 0; cvo_get_iteration_number(h_, &iter);
     }
-    // pcd_generator on the CPU (cvo.cpp:348-366), then hand the cloud over.  Eigen's N x 5 feature matrix is
-    // column-major (data_type.h:75): features.data() already is 5 channel-major arrays of N.
-    void generate_and_upload(const cv::Mat& RGB_img, const cv::Mat& dep_img, frame* fr) {
+    // set_pcd's cloud (cvo.cpp:348-366).  Default: the images cross the boundary and the generator runs on the GPU; the
+    // selected pixels come back for get_*_selected_points.
+    void generate_and_upload(const cv::Mat& RGB_img, const cv::Mat& dep_img, frame* fr, int slot) {
+#ifdef CVO_ADAPTOR_CPU_PCD
+        // Eigen's N x 5 feature matrix is column-major (data_type.h:75): features.data() already is 5 channel-major arrays of N
         pcd_generator pcd_gen; pcd_gen.set_calib(cam_info);
         point_cloud pc;
         pcd_gen.load_image(RGB_img, dep_img, fr);
         pcd_gen.create_pointcloud(1, fr, &pc);
         static_assert(sizeof(Eigen::Vector3f) == 12, "cloud_t must be 12-byte AoS");
         cvo_set_pcd(h_, pc.num_points ? pc.positions[0].data() : nullptr, pc.features.data(), pc.num_points);
+        (void)slot;
+#else
+        cv::Mat rgb = RGB_img.isContinuous() ? RGB_img : RGB_img.clone(), dep = dep_img.isContinuous() ? dep_img : dep_img.clone();
+        const cvo_camera cam = {cam_info.scaling_factor, cam_info.fx, cam_info.fy, cam_info.cx, cam_info.cy};
+        if (cvo_set_pcd_images(h_, rgb.data, reinterpret_cast<const unsigned short*>(dep.data), rgb.cols, rgb.rows, &cam) != CVO_OK) {
+            std::cerr << "cvo set_pcd: " << cvo_last_error() << "\n"; return;
+        }
+        fr->image = RGB_img; fr->depth = dep_img; fr->h = rgb.rows; fr->w = rgb.cols;        // pcd_generator.cpp:621-629
+        int n = 0; cvo_get_selected_points(h_, slot, nullptr, 0, &n);
+        std::vector<unsigned short> px(2 * (size_t)n);
+        if (n) cvo_get_selected_points(h_, slot, px.data(), n, &n);
+        fr->selected_points.clear();
+        for (int i = 0; i < n; ++i) fr->selected_points.push_back(cv::Point2f(px[2 * i], px[2 * i + 1]));   // pcd_generator.cpp:488-489
+#endif
     }
     static void to(const cvo_inn_p& a, inn_p& b) { b.value = a.value; b.num = a.num; b.num_e = a.num_e; }
 
@@ -82,9 +101,9 @@ public:
     ~cvo() { cvo_destroy(h_); }
 
     void set_pcd(const cv::Mat& RGB_img, const cv::Mat& dep_img) {      // cvo.cpp:345-386
-        if (!init) { generate_and_upload(RGB_img, dep_img, ptr_fixed_fr.get()); sync(); return; }
+        if (!init) { generate_and_upload(RGB_img, dep_img, ptr_fixed_fr.get(), CVO_SLOT_FIXED); sync(); return; }
         ptr_moving_fr.reset(new frame);
-        generate_and_upload(RGB_img, dep_img, ptr_moving_fr.get());
+        generate_and_upload(RGB_img, dep_img, ptr_moving_fr.get(), CVO_SLOT_MOVING);
     }
     void align() { if (cvo_align(h_) != CVO_OK) std::cerr << "cvo align: " << cvo_last_error() << "\n"; sync(); }   // cvo.cpp:763-821
 
