@@ -417,7 +417,7 @@ class CvoBatch:
 
     def last_phase_seconds(self):
         out = np.zeros(10); _check(self.L.cvo_batch_last_phase_seconds(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
-        return dict(zip(("cull", "candidates", "reduce1", "linesearch", "reduce2", "epilogue", "rb_sweep", "rb_scan", "rb_extract", "c2_rowsums"), out.tolist()))
+        return dict(zip(("lists", "candidates", "cand_reduce", "linesearch", "cand_exchange", "epilogue", "lists_cull", "cand_prologue", "lists_sort", "cand_rows"), out.tolist()))
 
     # -- keyframe_graph.cpp:704-717 for every aligned pair, one launch
     def compute_innerproduct_lc(self, prior_tran, lc_prior_tran, lc_prior_tran_2):

@@ -35,10 +35,9 @@ struct PairState {
     int rebuilds;             // dense culls executed
     int dense_fallbacks;      // rebuilds whose candidates did not fit the lists (dense per-row path taken)
     long long candidates_total;
-    // wall time (100 MHz ticks) workgroup 0 of the pair spent per phase:
-    // transform+cull+compaction, candidates, reduce/exchange 1, line-search sums, reduce/exchange 2, epilogue
+    // wall time (100 MHz ticks) workgroup 0 of the pair spent per phase (slots as cvo_batch_last_phase_seconds documents them)
     unsigned long long clk_cycles, clk_ticks;   // shader-clock cycles and 100 MHz ticks workgroup 0 spent on the pair: cycles/ticks*100 MHz = clock
-    unsigned long long phase_ticks[10];   // [6..8]: inside a rebuild: dense cull, row-offset scan, list extraction
+    unsigned long long phase_ticks[10];
 };
 
 struct TraceRow {        // == cvo_trace_row (include/cvo_hip.h)

@@ -202,10 +202,10 @@ int cvo_batch_align_async(cvo_batch b, int n_pairs, void* stream);
 int cvo_batch_wait(cvo_batch b, cvo_pair_result* results, int n);
 /* device time of the last launch in ms (HIP events on the launch stream), total loop trips it executed */
 int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_total, long long* candidates_total);
-/* where the last launch spent its time: seconds summed over pairs (as seen by workgroup 0 of each
- * pair) in the phases {transform + list rebuild, candidates, reduce/exchange 1, line-search sums,
- * reduce/exchange 2, scalar epilogue, then inside rebuilds: dense cull, row-offset scan, list extraction,
- * unused} */
+/* where the last launch spent its time: seconds summed over pairs, as seen by workgroup 0 of each pair:
+ * [0] transform + list upkeep (cull, sort, refine)   [1] candidate phase   [2] candidates: workgroup reduction (incl. waiting
+ * for the slowest wave)   [3] line-search phase   [4] candidates: exchange between the pair's workgroups   [5] scalar epilogue
+ * [6] inside [0]: dense culls   [7] candidates: prologue   [8] inside [0]: row sorts   [9] candidates: the row walk */
 int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]);
 /* pack the last launch's results into a caller-owned DEVICE buffer of n records of
  * CVO_RESULT_FLOATS floats {transform[12], iter, A_nonzero, iterations_run, status},

@@ -16,8 +16,8 @@ for wgs in [int(x) for x in os.environ.get("WGS", "1,2,4").split(",")]:
         B.reset_states(); res = B.align(npairs)
     info = B.last_launch(); ph = B.last_phase_seconds()
     its = info["iterations_total"]
-    cand_sub = {"prologue": ph.pop("rb_scan"), "rows": ph.pop("c2_rowsums"), "wg_reduce": ph.pop("reduce1"), "exchange": ph.pop("reduce2")}
-    rb_sweep = ph.pop("rb_sweep"); rb_sort = ph.pop("rb_extract")
+    cand_sub = {"prologue": ph.pop("cand_prologue"), "rows": ph.pop("cand_rows"), "wg_reduce": ph.pop("cand_reduce"), "exchange": ph.pop("cand_exchange")}
+    rb_sweep = ph.pop("lists_cull"); rb_sort = ph.pop("lists_sort")
     tot = sum(ph.values())
     print(f"wgs={wgs} kernel {info['kernel_ms']:.2f} ms, iterations {its} (max {max(r['iterations_run'] for r in res)}), cand/iter {info['candidates_total']/its:.0f}")
     rb = sum(r["rebuilds"] for r in res); df = sum(r["dense_fallbacks"] for r in res)
