@@ -162,6 +162,39 @@ def test_full_size_pair_fresh_vs_oracle(hiplib, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("changes", [
+    dict(sp_thres=1.0e-3),                                   # wide radius: exponents beyond the range-reduction-free polynomial (general exp path)
+    dict(sp_thres=9.0e-3, sigma=0.12),
+    dict(c_ell=40.0, c_sigma=1.0),                           # the colour gate binds: most pairs fail it (NaN-marked entries)
+    dict(c_ell=25.0, c_sigma=0.8, sp_thres=4.0e-3),
+    dict(c=3.0, d=11.0, min_step=0.35),
+    dict(ell=0.10, eps=2e-4, eps_2=5e-5),
+    dict(max_iter=7)])
+def test_non_default_parameters_vs_oracle(hiplib, oracle, changes):
+    """Every hyper-parameter of cvo.cpp:35-51 away from its default: the kernel's fast paths are selected from the parameters
+    (polynomial exp only when the exponent range allows it, colour factors kept per list entry), the results must not depend
+    on which path runs."""
+    from cvo_slam_amd import synth
+    p = synth.make_small_pair(91, n=700)
+    fixed, moving = (p.fixed.xyz, p.fixed.feat), (p.moving.xyz, p.moving.feat)
+    gp, op = hiplib.default_params(), oracle.default_params()
+    for k, v in changes.items():
+        setattr(gp, k, v); setattr(op, k, v)
+    o, otr = oracle_align(oracle, fixed, moving, trace_cap=2000, params=op)
+    ost = o.get_state()
+    for wgs in (1, 3):
+        g, gtr = gpu_align(hiplib, fixed, moving, wgs=wgs, trace_cap=2000, params=gp)
+        assert [r["nnz"] for r in gtr] == [r["nnz"] for r in otr], (changes, wgs)
+        re, te = rot_trans_err(g.transform, ost["transform"])
+        assert re <= 1e-6 and te <= 1e-6, (changes, wgs, re, te)
+        if "max_iter" not in changes:
+            assert g.get_iteration_number() == ost["iter"]
+        assert g.get_A_nonzero() == ost["A_nonzero"]
+        sg = g.compute_innerproduct(ost["transform"]); rc, so = o.compute_innerproduct(ost["transform"]); assert rc == 0
+        assert sg["inn_post"][1] == so["inn_post"][1] and sg["inn_post"][0] == pytest.approx(so["inn_post"][0], rel=1e-5)
+        g.close()
+
+
 def test_eth3d_shape_pair_tile_sweep(hiplib, oracle):
     """BASELINE config 5: ETH3D-shape 736x456 pair, ~9 k points per cloud (dense sampling).  The transformed cloud no longer
     fits in LDS (HBM/L2 path), a workgroup owns at most 4096 rows (G >= 3), and the cull tile is swept over
