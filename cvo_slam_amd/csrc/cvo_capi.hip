@@ -322,7 +322,9 @@ struct Engine {
         const int grid = slots * G;
         const int nf_pad = round_up(std::max(nf_max, 1), 64), nm_pad = round_up(std::max(nm_max, 1), 64);
         int capf = capf_request;
-        if (capf <= 0) capf = std::max(96, nm_max / 12);                                 // flat lists, average per row
+        // room for the nonzero records: nm/6 per row on average (512 at 3 k points; a fronto-parallel wall half a metre from the
+        // camera gives ~300 neighbours per row at the first ell), beyond that the dense per-row fallback takes over
+        if (capf <= 0) capf = std::max(128, nm_max / 6);
         const int tgran = align_tile_granule();
         // LDS budget of one workgroup; the resident moving cloud (16 B/point) has priority over a long cull tile
         const size_t lds_cap = (size_t)(160 / per_cu - 4) * 1024;
@@ -347,7 +349,7 @@ struct Engine {
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
         const size_t plane = (size_t)(nf_pad + G) * capf;
         const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
-        int capn = 64; while (capn < nm_max / 8 && capn < 4096) capn *= 2;   // longest transposed row: 512 at 3k points, 2048 at 10k
+        int capn = 64; while (capn < nm_max / 3 && capn < 4096) capn *= 2;   // longest list a row may have: 1024 at 3 k points, 4096 at 10 k
         if (const char* e = std::getenv("CVO_HIP_ROW_CAP")) capn = std::max(1, std::atoi(e));
         capn = std::max(8, round_up(capn, 4));                               // the candidate phase reads entries four at a time, one step ahead
         const size_t tplane = (size_t)G * capn * rows_pad;

@@ -195,6 +195,33 @@ def test_non_default_parameters_vs_oracle(hiplib, oracle, changes):
         g.close()
 
 
+def test_dense_near_surface_keeps_the_list_path(hiplib, oracle):
+    """A wall 0.6 m from the camera sampled every ~8 mm: ~450 neighbours per point inside the first radius.  The lists must
+    hold that (no dense per-row fallback) and the result must still be the oracle's."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    uv = rng.uniform(-1, 1, size=(n, 2)) * np.array([0.28, 0.21])
+    fixed_xyz = np.stack([uv[:, 0], uv[:, 1], 0.6 + 0.02 * np.sin(9 * uv[:, 0]) * np.cos(7 * uv[:, 1])], axis=1).astype(np.float32)
+    feat = np.stack([128 + 80 * np.sin(11 * uv[:, 0]), 128 + 70 * np.cos(13 * uv[:, 1]), 128 + 60 * np.sin(9 * (uv[:, 0] + uv[:, 1])),
+                     15 * np.cos(17 * uv[:, 0]), 15 * np.sin(19 * uv[:, 1])], axis=0).astype(np.float32)
+    tf = make_tf([0.2, 1.0, 0.1], 0.012, [0.006, -0.004, 0.003])
+    moving_xyz = ((fixed_xyz - tf[:, 3]) @ tf[:, :3] + rng.normal(0, 5e-4, size=fixed_xyz.shape)).astype(np.float32)
+    fixed, moving = (fixed_xyz, feat), (moving_xyz, feat + rng.normal(0, 1.0, size=feat.shape).astype(np.float32))
+    o = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8)
+    o.set_pcd(*fixed); o.set_pcd(*moving); rc, otr = o.align(trace_cap=400); assert rc == 0
+    assert otr[0]["nnz"] > 150 * n                                         # really dense: > 150 nonzeros per row in the first iteration
+    ost = o.get_state()
+    B = hiplib.CvoBatch(1)
+    B.set_pair(0, fixed[0], fixed[1], moving[0], moving[1])
+    for wgs in (1, 4):
+        B.set_workgroups(wgs); B.reset_states()
+        r = B.align(1)[0]
+        assert r["status"] == 0 and r["dense_fallbacks"] == 0, r
+        re, te = rot_trans_err(r["transform"], ost["transform"])
+        assert re <= 1e-6 and te <= 1e-6 and r["iter"] == ost["iter"] and r["A_nonzero"] == ost["A_nonzero"]
+    B.close()
+
+
 def test_eth3d_shape_pair_tile_sweep(hiplib, oracle):
     """BASELINE config 5: ETH3D-shape 736x456 pair, ~9 k points per cloud (dense sampling).  The transformed cloud no longer
     fits in LDS (HBM/L2 path), a workgroup owns at most 4096 rows (G >= 3), and the cull tile is swept over
