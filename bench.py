@@ -42,10 +42,11 @@ def _gen_pair(idx):
     return idx, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat
 
 
-def generate_pairs(first: int, count: int):
+def generate_pairs(first: int, count: int, workers: int = 0):
     """Seeded synthetic pairs first..first+count-1, rendered on host worker processes
-    (forked before anything touches the GPU)."""
-    workers = max(1, min(host_threads(), count))
+    (forked before anything touches the GPU).  workers = 1: in this process (under rocprofv3 --pmc the profiler has
+    initialised the GPU before the program starts, and forking after that hangs now and then)."""
+    workers = max(1, min(workers or host_threads(), count))
     if workers == 1:
         return [_gen_pair(first + i) for i in range(count)]
     ctx = mp.get_context("fork")
@@ -194,6 +195,8 @@ def main():
     ap.add_argument("--workgroups", type=int, default=1, help="workgroups per pair (0 = auto: lowest latency of one batch alone; 1 = highest throughput)")
     ap.add_argument("--streams", type=int, default=8, help="steps in flight (batch objects on separate HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-workers", type=int, default=0, help="host processes rendering the synthetic pairs (0 = one per host thread, 1 = no fork)")
+    ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,7 +206,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     # host-side input generation first (forks; no GPU state yet)
-    pairs = generate_pairs(rank * args.pairs, args.pairs)
+    pairs = generate_pairs(rank * args.pairs, args.pairs, args.gen_workers)
     if rank == 0:
         print(f"[bench] generated {len(pairs)} pairs per rank; starting GPU work", file=sys.stderr, flush=True)
 
@@ -345,7 +348,7 @@ def main():
                              "time per step): the share of the chip's plain-f32 issue slots the job keeps busy.  dense_pair_tests_per_s counts the "
                              "N*M tests per iteration the reference's radius search stands for; the kernel skips most of them (lists + box cull)"},
         }
-        if world == 1:
+        if world == 1 and not args.no_latency_probe:
             out["latency"] = latency_probe(ca, pairs, local_rank)
         if not args.no_cpu_baseline and world == 1:
             cores = host_threads()

@@ -14,7 +14,7 @@ C[write]="WRITE_SIZE"
 C[tcc]="TCC_HIT_sum TCC_MISS_sum"
 for name in "$@"; do
   echo "$(date +%T) start $name: ${C[$name]}" >> $OUT/progress.log
-  timeout -k 5 150 rocprofv3 --pmc ${C[$name]} --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 > $OUT/$name.log 2>&1
+  timeout -k 5 150 rocprofv3 --pmc ${C[$name]} --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency-probe --gen-workers 1 --streams 1 > $OUT/$name.log 2>&1
   echo "$(date +%T) end $name rc=$?" >> $OUT/progress.log
 done
 cat $OUT/progress.log
