@@ -6,21 +6,26 @@
 // resident for all of its iterations; R, T, ell never leave the device.
 //
 // One iteration (cvo.cpp:768-813), each phase a non-inlined device function:
-//   T   transform_pcd (cvo.cpp:336-341): y_j = M p_j into ybuf and an LDS-resident copy; exact
-//       displacement of every point since the candidate lists were built
-//   S   [only when the lists are stale]  dense cull straight into per-row candidate lists:
-//       the moving cloud sits in an LDS tile (SoA, ds_read_b128 broadcasts), a lane carries
-//       two rows, 3 sub + 3 fma + 1 v_alignbit per pair test; 32-column groups whose bounding
-//       box is out of reach of the wave's rows are skipped; hits are appended in ascending
-//       column order (= the CSR order of Eigen::setFromTriplets, cvo.cpp:182) to the
-//       transposed list jT[n][row].  Lists are built with radius (1+skin)*r and stay valid
-//       until some point has moved skin*r, or ell changes.
-//   C   one lane per row walks its list: the reference's own pair arithmetic (cvo.cpp:166-175:
-//       un-fused f32 d2, colour gate, double exp, a > sp_thres), f32 row sums in column order
-//       (cvo.cpp:213-223), f64 across rows (cvo.cpp:226-230) by wave shuffles + LDS, exchanged
-//       between the pair's workgroups as tagged 8-byte granules; survivors {x_i,a},{y_j} are
-//       compacted per wave
-//   L   one lane per survivor: beta..epsil and the B..E terms (cvo.cpp:282-306), f64
+//   T   transform_pcd (cvo.cpp:336-341): y_j = M p_j into LDS (HBM when the cloud is too large);
+//       exact displacement of every point since the candidate lists were built (the build
+//       transform is kept, not a snapshot); decision: keep the lists / cull / refine
+//   S   [lists stale by motion]  dense cull straight into per-row candidate lists: the moving
+//       cloud sits in an LDS tile (SoA, ds_read_b128 broadcasts), a lane carries two rows,
+//       3 sub + 3 fma + 1 v_alignbit per pair test; 32-column groups whose box (x, y, z and the
+//       ray slope y/z) is out of reach of the wave's rows are skipped; hits are appended in
+//       ascending column order (= the CSR order of Eigen::setFromTriplets, cvo.cpp:182) to
+//       jT[n][row].  Lists are built with radius (1+skin)*r and stay valid until some point has
+//       moved skin*r
+//   X   [after S]  rows sorted by list length (deterministic counting sort) into slots; 64
+//       slots = one block of near-equal lists, blocks dealt to the waves in serpentine order
+//   R   [ell dropped]  the old lists are a superset of the new radius: filtered in place
+//   C   one lane per slot walks its list, 4 entries per step: the reference's own pair
+//       arithmetic (cvo.cpp:166-175: un-fused f32 d2, colour gate, double exp, a > sp_thres),
+//       f32 row sums in column order (cvo.cpp:213-223), f64 across rows (cvo.cpp:226-230) by
+//       wave shuffles + LDS, exchanged between the pair's workgroups as tagged 8-byte granules;
+//       nonzeros {a, slot, column} are compacted per wave.  The first pass over new lists also
+//       evaluates the colour gate / factor once per entry
+//   L   one lane per nonzero: beta..epsil and the B..E terms (cvo.cpp:282-306), f64
 //   E   one lane: cubic, stop tests, Exp_SEK3, pose update, ell schedule
 //       (cvo.cpp:317-333, 782-812)
 // The cull uses fused arithmetic and a widened radius (a superset of the reference's
@@ -28,8 +33,8 @@
 // sparse set, every kernel value and every per-row sum follow the oracle's float sequence
 // regardless of when the lists were built.
 //
-// MFMA is deliberately not used: S is a distance test + compare, C1/L are
-// exp-heavy survivor work; neither is a contraction.
+// MFMA is deliberately not used: S is a distance test + compare, C/L are exp-heavy
+// per-nonzero work; neither is a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "cvo_device.h"
