@@ -473,12 +473,11 @@ __device__ __forceinline__ void load_x(const Ctx& c, const Lds& L, bool x_lds, i
     else { const float4 lo = ld4(c.fixed + lo_off(c.g + c.G * (int)L.row_of[slot])); xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; }
 }
 
-// ---- T: transform_pcd (cvo.cpp:336-341) into ybuf (+ the LDS-resident copy); how far has any point moved since
-// the candidate lists were built (exact displacement of the very positions the tests use); rebuild decision.
-static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh;
-    const Ctx c = make_ctx(Dp, g, G);
+// ---- T: transform_pcd (cvo.cpp:336-341) into LDS (or ybuf); how far has any point moved since the candidate lists were
+// built (exact displacement of the very positions the tests use); rebuild decision.  The first PRE_T points of a thread may
+// arrive pre-loaded (the epilogue of the previous iteration fetches them while one lane does the scalar work).
+constexpr int PRE_T = 8;
+__device__ __forceinline__ void transform_body(const Ctx& c, const Lds& L, Shared* sh, int y_lds, const float4 (&pre)[PRE_T], bool have_pre) {
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
     float M[12];
     {
@@ -494,8 +493,7 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
 #pragma unroll
     for (int i = 0; i < 12; ++i) Mb[i] = sh->Mb[i];
     float dmax2 = 0.f;
-    for (int j = tid; j < c.nm; j += nthreads) {
-        const float4 lo = ld4(c.moving + lo_off(j));
+    auto one = [&](int j, const float4 lo) {
         float y0, y1, y2;
         apply_transform(M, lo.x, lo.y, lo.z, y0, y1, y2);
         if (y_lds) L.ylds[j] = make_float4(y0, y1, y2, lo.w);       // the cloud stays in LDS for the whole iteration ...
@@ -506,7 +504,13 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
             const float e0 = y0 - b0, e1 = y1 - b1, e2 = y2 - b2;
             dmax2 = fmaxf(dmax2, __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)));
         }
+    };
+    int j = tid;
+    if (have_pre) {
+#pragma unroll
+        for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u]); j += nthreads; }
     }
+    for (; j < c.nm; j += nthreads) one(j, ld4(c.moving + lo_off(j)));
     dmax2 = block_max(dmax2, sh, tid, nwaves);                      // also makes ybuf / ylds visible to the workgroup
     if (tid == 0) {
         const float ell = sh->ell;
@@ -522,6 +526,15 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
         for (int i = 0; i < 12; ++i) sh->M[i] = M[i];
     }
     __syncthreads();
+}
+static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tile);
+    const Ctx c = make_ctx(Dp, g, G);
+    float4 none[PRE_T];
+#pragma unroll
+    for (int u = 0; u < PRE_T; ++u) none[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    transform_body(c, L, L.sh, y_lds, none, false);
 }
 
 // ---- S: dense cull straight into the transposed candidate lists.
@@ -1060,9 +1073,17 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
 }
 
 // ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
-static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int tile_in, int k_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), tile = uni(tile_in), k = uni(k_in);
-    Shared* sh = lds_layout(tile).sh;
+static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in, int max_iter_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in), max_iter = uni(max_iter_in);
+    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
+    // every lane fetches its share of the moving cloud for the NEXT iteration's transform while lane 0 does the scalar work
+    float4 pre[PRE_T];
+    {
+        int j = threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < PRE_T; ++u) { pre[u] = (j < c.nm) ? ld4(c.moving + lo_off(j)) : make_float4(0.f, 0.f, 0.f, 0.f); j += blockDim.x; }
+    }
     if (threadIdx.x == 0) {
         const DevParams& P = sh->P;
         const double B = sh->vals[0], C = sh->vals[1], Dd = sh->vals[2], E = sh->vals[3];
@@ -1106,6 +1127,7 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         }
     }
     __syncthreads();
+    if (!sh->stop && k + 1 < max_iter) transform_body(c, L, sh, y_lds, pre, true);   // T of iteration k+1 (cvo.cpp:770-771)
 }
 
 __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, unsigned launch_tag, DevParams P) {
@@ -1143,8 +1165,8 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
         const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
         if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
 
+        if (ok_pair && k < P.max_iter) phase_transform(Dp, g, G, tile, y_lds);   // later iterations: done by the epilogue before them
         for (; ok_pair && k < P.max_iter; ++k) {
-            phase_transform(Dp, g, G, tile, y_lds);
             if (sh->rebuild == 1) {
                 const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
                 phase_cull(Dp, g, G, tile, y_lds);
@@ -1162,7 +1184,7 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
             phase_linesearch(Dp, g, G, tile, y_lds, k);
             CVO_PHASE(3);
             if (sh->status != 0) break;
-            phase_epilogue(Dp, g, tile, k);
+            phase_epilogue(Dp, g, G, tile, y_lds, k, P.max_iter);
             CVO_PHASE(5);
 #ifdef CVO_KTRACE   // experiment builds only: the trace row's B..E carry this iteration's phase times (100 MHz ticks) instead
             if (tid == 0 && g == 0 && Dp->trace && k < Dp->trace_cap) {
