@@ -165,6 +165,23 @@ def make_frames(index: int, cam=TUM1, max_deg: float = 2.0, max_trans: float = 0
     return (img_a, dep_a), (img_b, dep_b), np.concatenate([R_ab, t_ab[:, None]], axis=1)
 
 
+def make_sequence(index: int, n_frames: int = 4, cam=TUM1, max_deg: float = 1.5, max_trans: float = 0.025, base_seed: int = 30300):
+    """An RGB-D sequence of one static scene: frames[k] = (bgr8, depth16) seen from camera k, poses[k] = (4, 4) pose of camera k
+    in the frame of camera 0 (random inter-frame motion up to max_deg / max_trans, like make_pair)."""
+    rng = np.random.default_rng(base_seed + index)
+    planes = _make_scene(rng)
+    R, t = np.eye(3), np.zeros(3)
+    frames, poses = [], []
+    for k in range(n_frames):
+        if k > 0:
+            dR, dt = random_motion(rng, max_deg, max_trans)           # pose of camera k in the frame of camera k-1
+            t = R @ dt + t; R = R @ dR
+        frames.append(_render(planes, R, t, cam, rng))
+        P = np.eye(4); P[:3, :3] = R; P[:3, 3] = t
+        poses.append(P)
+    return frames, poses
+
+
 def camera_tuple(cam):
     """(scaling_factor, fx, fy, cx, cy) = cvo::camera_info (data_type.h:33-39)."""
     return (float(cam["depth_factor"]), float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]))
