@@ -483,6 +483,37 @@ def test_batch_loop_closure_verification_block(hiplib, oracle):
     B.close()
 
 
+def test_handles_are_independent_across_host_threads(hiplib, oracle):
+    """keyframe_graph.cpp:212-240: the optional back-end thread owns its own cvo objects while the tracker thread uses its.
+    Handles share nothing (own stream, own buffers, thread-local error text): four host threads, each with its own object and
+    pair, must all get their own oracle's answer."""
+    import threading
+    from cvo_slam_amd import synth
+    pairs = [synth.make_small_pair(500 + i, n=400 + 150 * i) for i in range(4)]
+    want = []
+    for p in pairs:
+        o, _ = oracle_align(oracle, (p.fixed.xyz, p.fixed.feat), (p.moving.xyz, p.moving.feat))
+        want.append(o.get_state())
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(3):                                              # a few rounds each, interleaving on the GPU
+                g, _ = gpu_align(hiplib, (pairs[i].fixed.xyz, pairs[i].fixed.feat), (pairs[i].moving.xyz, pairs[i].moving.feat), wgs=[1, 2, 4, 0][i])
+                got[i] = (g.transform.copy(), g.get_iteration_number(), g.get_A_nonzero())
+                g.compute_innerproduct(g.transform)
+                g.close()
+        except Exception as e:                                              # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    for i in range(4):
+        re, te = rot_trans_err(got[i][0], want[i]["transform"])
+        assert re <= 1e-6 and te <= 1e-6 and got[i][1] == want[i]["iter"] and got[i][2] == want[i]["A_nonzero"], i
+
+
 def test_batch_results_to_device_records(hiplib):
     import torch
     from cvo_slam_amd import shard, synth
