@@ -36,9 +36,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 FP32_VALU_PEAK_TF = 157.3      # MI355X_MICROARCH.md: peak FP32 vector
 
 
+_SHAPE = "tum"
+
+
 def _gen_pair(idx):
     from cvo_slam_amd import synth
-    p = synth.make_pair(idx)
+    p = synth.make_pair(idx, cam=synth.ETH3D if _SHAPE == "eth3d" else synth.TUM1)
     return idx, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat
 
 
@@ -195,6 +198,7 @@ def main():
     ap.add_argument("--workgroups", type=int, default=1, help="workgroups per pair (0 = auto: lowest latency of one batch alone; 1 = highest throughput)")
     ap.add_argument("--streams", type=int, default=8, help="steps in flight (batch objects on separate HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shape", choices=("tum", "eth3d"), default="tum", help="tum: 640x480, ~3 k points per cloud (the metric's configuration); eth3d: 736x456, ~9.3 k points (BASELINE config 5)")
     ap.add_argument("--gen-workers", type=int, default=0, help="host processes rendering the synthetic pairs (0 = one per host thread, 1 = no fork)")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
     args = ap.parse_args()
@@ -205,6 +209,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    global _SHAPE
+    _SHAPE = args.shape
     # host-side input generation first (forks; no GPU state yet)
     pairs = generate_pairs(rank * args.pairs, args.pairs, args.gen_workers)
     if rank == 0:
@@ -327,7 +333,7 @@ def main():
             "value": value, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n} independent synthetic 640x480 TUM-shape RGB-D pairs per GPU per step "
+            "config": {"workload": f"{n} independent synthetic {'640x480 TUM' if args.shape == 'tum' else '736x456 ETH3D'}-shape RGB-D pairs per GPU per step "
                                    f"(BASELINE config 3; {world * n} pairs per step at {world} GPU(s); config 4 = 512 pairs at 8 GPUs), "
                                    f"full align() from R=I,T=0,ell=0.15 to convergence",
                        "pairs_per_gpu": n, "points_fixed_mean": float(np.mean(nfs)), "points_moving_mean": float(np.mean(nms)),
