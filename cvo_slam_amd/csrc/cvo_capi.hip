@@ -21,10 +21,10 @@
 #include "cvo_math.hpp"
 
 namespace cvohip {
-size_t align_shared_bytes(int tile, int y_points);
+size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap);
 int align_tile_granule();
 int align_blocks_per_cu();
-hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         unsigned launch_tag, const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 hipError_t pcd_launch_pyramid(const uint8_t* bgr, int w, int h, float* I0, float* I1, float* I2, float* dx0, float* dy0, float* abs0, float* abs1, float* abs2,
@@ -326,13 +326,30 @@ struct Engine {
         // camera gives ~300 neighbours per row at the first ell), beyond that the dense per-row fallback takes over
         if (capf <= 0) capf = std::max(128, nm_max / 6);
         const int tgran = align_tile_granule();
-        // LDS budget of one workgroup; the resident moving cloud (16 B/point) has priority over a long cull tile
+        // LDS budget of one workgroup.  The transformed moving cloud is kept resident if at all possible: as float4 {y, g0}
+        // (mode 1) beside a cull tile that holds the whole cloud; else as three float planes (mode 2, 12 B/point) beside a
+        // tile just large enough to keep the fixed points in slot order; else it stays in HBM/L2 (mode 0).
         const size_t lds_cap = (size_t)(160 / per_cu - 4) * 1024;
-        int tile = tile_request > 0 ? round_up(tile_request, tgran) : std::min(round_up(std::max(nm_max, tgran), tgran), 4096);
-        if (tile_request <= 0) {
-            while (tile > 512 && align_shared_bytes(tile, nm_pad) > lds_cap) tile -= tgran;
-            if (align_shared_bytes(tile, nm_pad) > lds_cap) tile = std::min(round_up(std::max(nm_max, tgran), tgran), 2048);   // cloud stays in HBM/L2
-            while (tile > tgran && align_shared_bytes(tile, 0) > lds_cap) tile -= tgran;
+        const int rows_per_w = (nf_max + G - 1) / G;
+        const int rows_cap = round_up(std::max(rows_per_w, 1), 128) + 64;
+        const int tile_full = std::min(round_up(std::max(nm_max, tgran), tgran), 4096);
+        const int tile_rows = round_up(std::max(round_up(std::max(rows_per_w, 1), 64), 512), tgran);   // >= the slots: x_i by slot fits the idle tile
+        const bool allow_lds = !std::getenv("CVO_HIP_NO_YLDS");
+        int y_mode = 0, tile = tile_request > 0 ? round_up(tile_request, tgran) : tile_full;
+        if (const char* e = std::getenv("CVO_HIP_Y_MODE")) {                                // test knob: force a layout (must fit)
+            y_mode = std::max(0, std::min(2, std::atoi(e)));
+            if (tile_request <= 0) { tile = y_mode == 1 ? tile_full : std::min(tile_full, std::max(tile_rows, 512)); while (tile > tgran && align_shared_bytes(tile, rows_cap, y_mode, nm_pad) > lds_cap) tile -= tgran; }
+            if (align_shared_bytes(tile, rows_cap, y_mode, nm_pad) > lds_cap) return fail(CVO_ERR_INVALID, "CVO_HIP_Y_MODE: the requested LDS layout does not fit");
+        } else if (tile_request > 0) {
+            if (allow_lds && align_shared_bytes(tile, rows_cap, 1, nm_pad) <= lds_cap) y_mode = 1;
+            else if (allow_lds && align_shared_bytes(tile, rows_cap, 2, nm_pad) <= lds_cap) y_mode = 2;
+            else while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0) > lds_cap) tile -= tgran;
+        } else {
+            int t1 = tile_full; while (t1 > 512 && align_shared_bytes(t1, rows_cap, 1, nm_pad) > lds_cap) t1 -= tgran;
+            int t2 = std::min(tile_full, tile_rows); while (t2 > 512 && align_shared_bytes(t2, rows_cap, 2, nm_pad) > lds_cap) t2 -= tgran;
+            if (allow_lds && align_shared_bytes(t1, rows_cap, 1, nm_pad) <= lds_cap) { y_mode = 1; tile = t1; }
+            else if (allow_lds && align_shared_bytes(t2, rows_cap, 2, nm_pad) <= lds_cap) { y_mode = 2; tile = t2; }
+            else { tile = std::min(tile_full, 2048); while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0) > lds_cap) tile -= tgran; }
         }
         const int rows_per = (nf_max + G - 1) / G;
         int block = rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64));
@@ -406,10 +423,7 @@ struct Engine {
             xch_zeroed_bytes = d_xch.bytes;
         }
         HIP_TRY(hipEventRecord(ev0, s));
-        // keep the transformed moving cloud resident in LDS (16 B per point) when it fits beside the rest
-        int y_points = 0;
-        if (align_shared_bytes(tile, nm_pad) <= lds_cap && !std::getenv("CVO_HIP_NO_YLDS")) y_points = nm_pad;
-        hipError_t e = launch_align(grid, block, tile, y_points, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, P);
+        hipError_t e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, P);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));
         launched = true;

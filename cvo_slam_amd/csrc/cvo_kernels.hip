@@ -39,6 +39,7 @@
 #include <stdint.h>
 #include "cvo_device.h"
 #include "cvo_math.hpp"
+#include <type_traits>
 
 namespace cvohip {
 
@@ -79,6 +80,8 @@ struct __attribute__((aligned(16))) Shared {
     int refines;           // list rebuilds done by filtering the old lists (ell drops)
     int dense_fallbacks;
     int rebuild;           // this iteration rebuilds the candidate lists
+    int rows_cap;          // entries of the three row/slot tables in LDS (the workgroup's rows, padded)
+    int y_cap;             // points the LDS-resident moving cloud has room for (stride of the SoA planes)
     int x_lds;             // the fixed points, by slot, sit in the (otherwise idle) cull tile: lx/ly/lz[slot]
     unsigned launch_tag;   // high 16 bits of every exchange tag: this launch's sequence number (granules of earlier launches never match)
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
@@ -418,25 +421,30 @@ template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
 
 constexpr int PF = 4;                 // list entries a lane evaluates side by side
 constexpr int NCLS = 128;             // list-length classes (ceil(len / PF), the last one open-ended) the rows are sorted by
-constexpr int ROWS_LDS = MAX_ROWS_PER_WG + 128;
-
+// The transformed moving cloud lives in LDS as float4 {y, g0} (mode 1), as three float planes when that does not fit but
+// 12 bytes a point do (mode 2, e.g. 9 k-point clouds), or in HBM/L2 (mode 0).
 struct Lds {
     Shared* sh; uint16_t* lenS; uint16_t* row_of; uint16_t* rowlen; int* hist; int* base; float* gbox; float* lx; float* ly; float* lz; float4* ylds;
+    float* ysx; float* ysy; float* ysz;
 };
-// Shared | list length per slot | row of a slot | list length per local row | sort histograms | group boxes (6 planes) |
-// cull tile, SoA | resident transformed moving cloud (optional)
-__device__ __forceinline__ Lds lds_layout(int tile) {
+// Shared | list length per slot | row of a slot | list length per local row | sort histograms | group boxes (8 planes) |
+// cull tile, SoA | resident transformed moving cloud (optional).  The table and cloud sizes are launch parameters kept in Shared.
+// tgeo packs the launch's LDS geometry into one scalar every phase receives: tile | rows_cap/64 << 13 | y_cap/64 << 20
+__device__ __forceinline__ int pack_geometry(int tile, int rows_cap, int y_cap) { return tile | ((rows_cap >> 6) << 13) | ((y_cap >> 6) << 20); }
+__device__ __forceinline__ Lds lds_layout(int tgeo) {
     Lds L;
     L.sh = reinterpret_cast<Shared*>(cvo_smem);
+    const int tile = tgeo & 0x1FFF, rows_cap = ((tgeo >> 13) & 0x7F) << 6, y_cap = ((tgeo >> 20) & 0x7FF) << 6;
     L.lenS = reinterpret_cast<uint16_t*>(cvo_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
-    L.row_of = L.lenS + ROWS_LDS;
-    L.rowlen = L.row_of + ROWS_LDS;
-    L.hist = reinterpret_cast<int*>(L.rowlen + ROWS_LDS);
+    L.row_of = L.lenS + rows_cap;
+    L.rowlen = L.row_of + rows_cap;
+    L.hist = reinterpret_cast<int*>(L.rowlen + rows_cap);
     L.base = L.hist + MAX_WAVES * NCLS;
     L.gbox = reinterpret_cast<float*>(L.base + MAX_WAVES * NCLS);
     L.lx = L.gbox + 8 * (tile >> 5);
     L.ly = L.lx + tile; L.lz = L.ly + tile;
     L.ylds = reinterpret_cast<float4*>(L.lz + tile);
+    L.ysx = reinterpret_cast<float*>(L.ylds); L.ysy = L.ysx + y_cap; L.ysz = L.ysy + y_cap;
     return L;
 }
 
@@ -473,11 +481,23 @@ __device__ __forceinline__ void load_x(const Ctx& c, const Lds& L, bool x_lds, i
     else { const float4 lo = ld4(c.fixed + lo_off(c.g + c.G * (int)L.row_of[slot])); xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; }
 }
 
+// transformed moving point j; .w = first feature channel in modes 0 and 1, not available (0) in mode 2
+template <int YM>
+__device__ __forceinline__ float4 load_y(const Ctx& c, const Lds& L, int j) {
+    if (YM == 1) return L.ylds[j];
+    if (YM == 2) return make_float4(L.ysx[j], L.ysy[j], L.ysz[j], 0.f);
+    return c.ybuf[j];
+}
+__device__ __forceinline__ float4 load_y_rt(const Ctx& c, const Lds& L, int y_mode, int j) {
+    return y_mode == 1 ? load_y<1>(c, L, j) : (y_mode == 2 ? load_y<2>(c, L, j) : load_y<0>(c, L, j));
+}
+
 // ---- T: transform_pcd (cvo.cpp:336-341) into LDS (or ybuf); how far has any point moved since the candidate lists were
 // built (exact displacement of the very positions the tests use); rebuild decision.  The first PRE_T points of a thread may
 // arrive pre-loaded (the epilogue of the previous iteration fetches them while one lane does the scalar work).
 constexpr int PRE_T = 8;
-__device__ __forceinline__ void transform_body(const Ctx& c, const Lds& L, Shared* sh, int y_lds, const float4 (&pre)[PRE_T], bool have_pre) {
+template <int YM>
+__device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Shared* sh, const float4 (&pre)[PRE_T], bool have_pre) {
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
     float M[12];
     {
@@ -496,7 +516,8 @@ __device__ __forceinline__ void transform_body(const Ctx& c, const Lds& L, Share
     auto one = [&](int j, const float4 lo) {
         float y0, y1, y2;
         apply_transform(M, lo.x, lo.y, lo.z, y0, y1, y2);
-        if (y_lds) L.ylds[j] = make_float4(y0, y1, y2, lo.w);       // the cloud stays in LDS for the whole iteration ...
+        if (YM == 1) L.ylds[j] = make_float4(y0, y1, y2, lo.w);     // the cloud stays in LDS for the whole iteration ...
+        else if (YM == 2) { L.ysx[j] = y0; L.ysy[j] = y1; L.ysz[j] = y2; }
         else c.ybuf.set(j, make_float4(y0, y1, y2, lo.w));          // ... or, too large for that, in HBM/L2
         if (have_list) {                                            // where the point was when the lists were built: the same arithmetic, then
             float b0, b1, b2;
@@ -527,14 +548,25 @@ __device__ __forceinline__ void transform_body(const Ctx& c, const Lds& L, Share
     }
     __syncthreads();
 }
-static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tile);
+// the layouts of large clouds (12-byte LDS planes, HBM): out of line, nothing pre-loaded -- keeps the common path's code small
+static __device__ __noinline__ void transform_large(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tgeo);
     const Ctx c = make_ctx(Dp, g, G);
     float4 none[PRE_T];
 #pragma unroll
     for (int u = 0; u < PRE_T; ++u) none[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    transform_body(c, L, L.sh, y_lds, none, false);
+    if (y_lds == 2) transform_body_t<2>(c, L, L.sh, none, false); else transform_body_t<0>(c, L, L.sh, none, false);
+}
+static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tgeo);
+    const Ctx c = make_ctx(Dp, g, G);
+    if (y_lds != 1) { transform_large(Dp, g, G, tgeo, y_lds); return; }
+    float4 none[PRE_T];
+#pragma unroll
+    for (int u = 0; u < PRE_T; ++u) none[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    transform_body_t<1>(c, L, L.sh, none, false);
 }
 
 // ---- S: dense cull straight into the transposed candidate lists.
@@ -544,8 +576,8 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
 // comes within the cull radius of the wave's rows' bounding box are tested at all (one lane per group decides, a ballot
 // turns the decisions into a scalar mask the wave then iterates).
 static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh; uint16_t* rowlen = L.rowlen;
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tgeo); Shared* sh = L.sh; uint16_t* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
@@ -567,7 +599,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             // cover the whole width and depth range but only a few image rows
             float lo[4] = {INF, INF, INF, INF}, hi[4] = {-INF, -INF, -INF, -INF};
             if (jj < tn) {
-                y = y_lds ? L.ylds[t0 + jj] : c.ybuf[t0 + jj];
+                y = load_y_rt(c, L, y_lds, t0 + jj);
                 lo[0] = hi[0] = y.x; lo[1] = hi[1] = y.y; lo[2] = hi[2] = y.z;
                 if (y.z > 1.0e-3f) { lo[3] = hi[3] = y.y / y.z; } else { lo[3] = -INF; hi[3] = INF; }   // behind / at the camera: no slope bound
             }
@@ -660,8 +692,8 @@ __device__ __forceinline__ int len_class(int len) { return min(NCLS - 1, (len + 
 __device__ __forceinline__ int wave_block(int i, int wave, int nwaves) { return i * nwaves + ((i & 1) ? nwaves - 1 - wave : wave); }
 
 static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF;
+    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
@@ -774,7 +806,7 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
 }
 
 // every iteration but the first after a rebuild: entries {ck, j} stream in, PF per lane per step, the next step's in flight
-template <bool YLDS, bool FLAT>
+template <int YM, bool FLAT>
 __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                             double (&acc8)[8]) {
     const size_t sbase = c.fbase + sh->wbase[wave];
@@ -805,7 +837,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
             for (int u = 0; u < PF; ++u) {                          // independent until folded: PF exp chains in flight per lane
                 const bool act = n0 + u < len;
                 const int j = act ? (int)eq[u].y : 0;               // slots past the row's end hold stale entries
-                yv4[u] = YLDS ? L.ylds[j] : c.ybuf[j];
+                yv4[u] = load_y<YM>(c, L, j);
                 const float ck = __uint_as_float(eq[u].x);
                 if (FLAT) av[u] = se_kernel_value_flat(xi, yv4[u], ck, act, gates);
                 else av[u] = act ? se_kernel_value_ck(xi, yv4[u], ck, gates) : 0.f;
@@ -826,7 +858,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
 // (cvo.cpp:169-173) are evaluated once and kept with the column in the slot-ordered entries.  Three stages in flight per
 // lane: columns of step s+2 (gathered from the raw lists), second feature plane of the columns of step s+1, arithmetic
 // of step s.
-template <bool YLDS, bool FLAT>
+template <int YM, bool FLAT>
 __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                            double (&acc8)[8]) {
     const size_t sbase = c.fbase + sh->wbase[wave];
@@ -865,8 +897,9 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
             for (int u = 0; u < PF; ++u) {
                 const bool act = n0 + u < len;
                 const int j = j0[u];
-                yv4[u] = YLDS ? L.ylds[j] : c.ybuf[j];
-                const float fb[5] = {yv4[u].w, g0[u].x, g0[u].y, g0[u].z, g0[u].w};
+                yv4[u] = load_y<YM>(c, L, j);
+                const float f0 = (YM == 2) ? ld4(c.moving + lo_off(j)).w : yv4[u].w;   // the first channel rides with y, except in the 12-byte LDS layout
+                const float fb[5] = {f0, g0[u].x, g0[u].y, g0[u].z, g0[u].w};
                 const float d2c = feat_d2(fi, fb);
                 const float ckv = (float)((double)gates.csig2 * exp_neg((double)(-d2c) * gates.inv_den_c));
                 const float ck = (d2c < gates.d2c_thres) ? ckv : __builtin_nanf("");
@@ -887,7 +920,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
 
 // ---- R: ell has dropped: the lists shrink to the new radius in place.  The test is the cull's (same fused arithmetic on the
 // current positions), so the result is the list a dense cull would build now, with the colour factors it already carries.
-template <bool YLDS>
+template <int YM>
 __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* sh, float nthr, int lane, int wave, int nwaves) {
     int kept = 0;
     const int nb = sh->wnb[wave];
@@ -914,7 +947,7 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
             for (int u = 0; u < PF; ++u) {
                 const bool act = n0 + u < len;
                 const int j = act ? (int)eq[u].y : 0;
-                const float4 y = YLDS ? L.ylds[j] : c.ybuf[j];
+                const float4 y = load_y<YM>(c, L, j);
                 const float dx = xi[0] - y.x, dy = xi[1] - y.y, dz = xi[2] - y.z;
                 const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nthr)));
                 if (act && t < 0.f) { *wp = eq[u]; wp += c.rows_pad; ++cnt; }
@@ -931,14 +964,14 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
 }
 
 static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
     const float Rb = r_c * (1.0f + sh->P.skin);
     const float nthr = -(Rb * Rb * 1.00001f);                       // = the cull's threshold for this ell
-    const int kept = y_lds ? refine_lists<true>(c, L, sh, nthr, lane, wave, nwaves) : refine_lists<false>(c, L, sh, nthr, lane, wave, nwaves);
+    const int kept = y_lds == 1 ? refine_lists<1>(c, L, sh, nthr, lane, wave, nwaves) : (y_lds == 2 ? refine_lists<2>(c, L, sh, nthr, lane, wave, nwaves) : refine_lists<0>(c, L, sh, nthr, lane, wave, nwaves));
     if (lane == 0) sh->wsum[wave] = kept;
     __syncthreads();
     if (tid == 0) {
@@ -951,8 +984,8 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
 }
 
 static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in);
+    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
@@ -963,21 +996,12 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
     double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // omega[3], v[3], nnz, candidates
     const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
     if (!dense_mode) {
-        if (fresh_list) {
-            if (gates.poly_ok) {
-                if (y_lds) cand_fresh<true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-                else cand_fresh<false, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-            } else {
-                if (y_lds) cand_fresh<true, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-                else cand_fresh<false, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-            }
-        } else if (gates.poly_ok) {
-            if (y_lds) cand_steady<true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-            else cand_steady<false, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-        } else {
-            if (y_lds) cand_steady<true, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-            else cand_steady<false, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
-        }
+#define CVO_CAND(fn, flat) do { if (y_lds == 1) fn<1, flat>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8); \
+                                else if (y_lds == 2) fn<2, flat>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8); \
+                                else fn<0, flat>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8); } while (0)
+        if (fresh_list) { if (gates.poly_ok) CVO_CAND(cand_fresh, true); else CVO_CAND(cand_fresh, false); }
+        else { if (gates.poly_ok) CVO_CAND(cand_steady, true); else CVO_CAND(cand_steady, false); }
+#undef CVO_CAND
         if (tid == 0) acc8[7] = (double)sh->total;
     } else {
         for (int li = tid; li < nrows; li += nthreads) {            // dense fallback: every column of the row
@@ -988,7 +1012,8 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
             float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
             int nz = 0;
             for (int j = 0; j < c.nm; ++j) {
-                const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
+                float4 yj = load_y_rt(c, L, y_lds, j);
+                if (y_lds == 2) yj.w = ld4(c.moving + lo_off(j)).w;
                 const float a = se_kernel_value(xi, fi, yj, ld4(c.moving + hi_off(c.nm, j)), gates);
                 if (a > 0.f) {
                     const float yv[3] = {yj.x, yj.y, yj.z};
@@ -1023,8 +1048,8 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 
 // ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
 static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in);
+    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6;
     float omega[3], v[3];
@@ -1040,14 +1065,18 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
         const int cnt_w = sh->wcnt[wave];
         const gv2u* sp = c.surv + c.fbase + (size_t)sh->wbase[wave];
         v2u rnext = sp[min(lane, max(cnt_w - 1, 0))];
-        for (int q = lane; q < cnt_w; q += 64) {
-            const v2u rec = rnext;
-            rnext = sp[min(q + 64, cnt_w - 1)];                     // next record in flight behind this one's arithmetic
-            const int slot = (int)(rec.y >> 16), j = (int)(rec.y & 0xFFFFu);
-            float xi[3]; load_x(c, L, x_lds, slot, xi);
-            const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
-            ls_terms(xi, yj, __uint_as_float(rec.x), ls, acc4[0], acc4[1], acc4[2], acc4[3]);
-        }
+        auto walk = [&](auto ym) {
+            constexpr int YM = decltype(ym)::value;
+            for (int q = lane; q < cnt_w; q += 64) {
+                const v2u rec = rnext;
+                rnext = sp[min(q + 64, cnt_w - 1)];                 // next record in flight behind this one's arithmetic
+                const int slot = (int)(rec.y >> 16), j = (int)(rec.y & 0xFFFFu);
+                float xi[3]; load_x(c, L, x_lds, slot, xi);
+                const float4 yj = load_y<YM>(c, L, j);
+                ls_terms(xi, yj, __uint_as_float(rec.x), ls, acc4[0], acc4[1], acc4[2], acc4[3]);
+            }
+        };
+        if (y_lds == 1) walk(std::integral_constant<int, 1>{}); else if (y_lds == 2) walk(std::integral_constant<int, 2>{}); else walk(std::integral_constant<int, 0>{});
     } else {
         const Gates gates = make_gates(sh->ell, sh->P);
         for (int li = tid; li < c.nrows; li += nthreads) {
@@ -1057,7 +1086,8 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
             const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
             double Bi = 0, Ci = 0, Di = 0, Ei = 0;
             for (int j = 0; j < c.nm; ++j) {
-                const float4 yj = y_lds ? L.ylds[j] : c.ybuf[j];
+                float4 yj = load_y_rt(c, L, y_lds, j);
+                if (y_lds == 2) yj.w = ld4(c.moving + lo_off(j)).w;
                 const float A_ij = se_kernel_value(xi, fi, yj, ld4(c.moving + hi_off(c.nm, j)), gates);
                 if (A_ij > 0.f) ls_terms(xi, yj, A_ij, ls, Bi, Ci, Di, Ei);
             }
@@ -1074,8 +1104,8 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
 
 // ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
 static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in, int max_iter_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tile = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in), max_iter = uni(max_iter_in);
-    const Lds L = lds_layout(tile); Shared* sh = L.sh;
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in), max_iter = uni(max_iter_in);
+    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     // every lane fetches its share of the moving cloud for the NEXT iteration's transform while lane 0 does the scalar work
     float4 pre[PRE_T];
@@ -1127,15 +1157,19 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         }
     }
     __syncthreads();
-    if (!sh->stop && k + 1 < max_iter) transform_body(c, L, sh, y_lds, pre, true);   // T of iteration k+1 (cvo.cpp:770-771)
+    if (!sh->stop && k + 1 < max_iter) {                             // T of iteration k+1 (cvo.cpp:770-771)
+        if (y_lds == 1) transform_body_t<1>(c, L, sh, pre, true); else transform_large(Dp, g, G, tgeo, y_lds);
+    }
 }
 
-__global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, unsigned launch_tag, DevParams P) {
+__global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
+                                                                         unsigned launch_tag, DevParams P) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
     const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
-    if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; }
+    if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; }
+    const int tgeo = pack_geometry(tile, rows_cap, y_cap);
 
     for (int p = slot; p < n_pairs; p += slots) {
         const PairDesc* Dp = descs + p;
@@ -1165,26 +1199,26 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
         const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
         if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
 
-        if (ok_pair && k < P.max_iter) phase_transform(Dp, g, G, tile, y_lds);   // later iterations: done by the epilogue before them
+        if (ok_pair && k < P.max_iter) phase_transform(Dp, g, G, tgeo, y_lds);   // later iterations: done by the epilogue before them
         for (; ok_pair && k < P.max_iter; ++k) {
             if (sh->rebuild == 1) {
                 const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
-                phase_cull(Dp, g, G, tile, y_lds);
+                phase_cull(Dp, g, G, tgeo, y_lds);
                 const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
-                phase_sort(Dp, g, G, tile);
+                phase_sort(Dp, g, G, tgeo);
                 ticks[6] += t_b - t_a; ticks[8] += __builtin_amdgcn_s_memrealtime() - t_b;
             } else if (sh->rebuild == 2) {
-                phase_refine(Dp, g, G, tile, y_lds);
+                phase_refine(Dp, g, G, tgeo, y_lds);
             }
             CVO_PHASE(0);
-            phase_candidates(Dp, g, G, tile, y_lds, k);
+            phase_candidates(Dp, g, G, tgeo, y_lds, k);
             cand_total += sh->cand;
             CVO_PHASE(1);
             if (sh->status != 0) break;
-            phase_linesearch(Dp, g, G, tile, y_lds, k);
+            phase_linesearch(Dp, g, G, tgeo, y_lds, k);
             CVO_PHASE(3);
             if (sh->status != 0) break;
-            phase_epilogue(Dp, g, G, tile, y_lds, k, P.max_iter);
+            phase_epilogue(Dp, g, G, tgeo, y_lds, k, P.max_iter);
             CVO_PHASE(5);
 #ifdef CVO_KTRACE   // experiment builds only: the trace row's B..E carry this iteration's phase times (100 MHz ticks) instead
             if (tid == 0 && g == 0 && Dp->trace && k < Dp->trace_cap) {
@@ -1239,19 +1273,21 @@ hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream
 
 int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
 
-// LDS: Shared | slot/row tables | sort histograms | group boxes | cull tile (3*tile floats) | resident y cloud (16 B * nm_pad, optional)
-size_t align_shared_bytes(int tile, int y_points) {
-    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)3 * ROWS_LDS * sizeof(uint16_t) + (size_t)2 * MAX_WAVES * NCLS * sizeof(int) +
-           (size_t)8 * (tile >> 5) * sizeof(float) + (size_t)3 * tile * sizeof(float) + (size_t)y_points * sizeof(float4);
+// LDS: Shared | slot/row tables (3 x rows_cap u16) | sort histograms | group boxes | cull tile (3*tile floats) | resident y cloud
+// (y_mode 1: 16 B x y_cap, y_mode 2: 12 B x y_cap, y_mode 0: none)
+size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap) {
+    const size_t ybytes = y_mode == 1 ? (size_t)y_cap * sizeof(float4) : (y_mode == 2 ? (size_t)y_cap * 3 * sizeof(float) : 0);
+    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)3 * rows_cap * sizeof(uint16_t) + (size_t)2 * MAX_WAVES * NCLS * sizeof(int) +
+           (size_t)8 * (tile >> 5) * sizeof(float) + (size_t)3 * tile * sizeof(float) + ybytes;
 }
 int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 
-hipError_t launch_align(int grid, int block, int tile, int y_points, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         unsigned launch_tag, const DevParams& P) {
-    const size_t shmem = align_shared_bytes(tile, y_points);
+    const size_t shmem = align_shared_bytes(tile, rows_cap, y_mode, y_cap);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cvo_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_points > 0 ? 1 : 0, launch_tag, P);
+    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_mode, rows_cap, y_cap, launch_tag, P);
     return hipGetLastError();
 }
 

@@ -131,6 +131,7 @@ def test_workgroup_counts_tiles_and_overflow_fallback_agree(hiplib, oracle):
                dict(wgs=1, CVO_HIP_FLAT_CAP=4), dict(wgs=5, CVO_HIP_FLAT_CAP=1, CVO_HIP_TILE=64), dict(wgs=3, CVO_HIP_FLAT_CAP=1),
                dict(wgs=2, CVO_HIP_SKIN=0.0), dict(wgs=2, CVO_HIP_SKIN=0.02), dict(wgs=4, CVO_HIP_SKIN=1.5),
                dict(wgs=1, CVO_HIP_NO_YLDS=1), dict(wgs=3, CVO_HIP_NO_YLDS=1, CVO_HIP_TILE=128),          # transformed cloud in HBM/L2, not LDS
+               dict(wgs=1, CVO_HIP_Y_MODE=2), dict(wgs=4, CVO_HIP_Y_MODE=2, CVO_HIP_TILE=256), dict(wgs=2, CVO_HIP_Y_MODE=0),   # 12-byte LDS layout / forced HBM
                dict(wgs=1, CVO_HIP_ROW_CAP=8), dict(wgs=2, CVO_HIP_ROW_CAP=16, CVO_HIP_SKIN=0.6),         # rows longer than the lists hold
                dict(wgs=1, CVO_HIP_WGS_PER_CU=2)]                                                          # two 256-thread workgroups per CU
     for cfg in configs:
