@@ -296,10 +296,10 @@ struct Engine {
     int pick_workgroups(int n_pairs, int nf_max) const {
         int G = wg_request;
         if (G <= 0) {
-            // lowest latency of this launch alone: as many workgroups per pair as the CUs allow, but not below ~768 rows per
-            // workgroup -- beyond that the partial-sum exchanges cost more than the shorter phases save (measured at 3072 points:
-            // 2.4 ms at 4, 2.5 at 8, 2.8 at 16, 3.6 at 32, 4.9 at 1)
-            int want = 1; while (want * 2 * 768 <= nf_max && want < 32) want *= 2;
+            // lowest latency of this launch alone: as many workgroups per pair as the CUs allow, but not below ~384 rows per
+            // workgroup -- a row's list is walked by one lane, so beyond one 64-row block per wave nothing gets shorter while the
+            // partial-sum exchanges keep costing (measured at 3072 points: 2.37 ms at 4, 2.33 at 8, 2.44 at 16, 2.78 at 32, 4.9 at 1)
+            int want = 1; while (want * 2 * 384 <= nf_max && want < 32) want *= 2;
             G = 1; while (G * 2 * n_pairs <= num_cus * per_cu && G < want) G *= 2;
         }
         const int g_min = (nf_max + MAX_ROWS_PER_WG - 1) / MAX_ROWS_PER_WG;     // a workgroup owns at most MAX_ROWS_PER_WG rows

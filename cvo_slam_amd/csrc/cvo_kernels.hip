@@ -180,12 +180,16 @@ __device__ __forceinline__ bool group_exchange(Shared* sh, gu64* xch, int G, int
     }
     double tot = 0;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    for (int gg = 0; gg < G; ++gg) {
+    // four workgroups' granules per poll (a wave's 64 lanes = 4 x XCH_WORDS): one L2 round trip per four members, not one each
+    static_assert(2 * K <= XCH_WORDS && 4 * XCH_WORDS == 64, "granule layout");
+    const int sub = lane >> 4, wrd = lane & 15;
+    for (int g0 = 0; g0 < G; g0 += 4) {
+        const bool mine = (g0 + sub < G) && (wrd < 2 * K);
         unsigned long long x = 0;
         for (;;) {
             bool ok = true;
-            if (lane < 2 * K) {
-                x = __hip_atomic_load(&buf[gg * XCH_WORDS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine) {
+                x = __hip_atomic_load(&buf[(g0 + sub) * XCH_WORDS + wrd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = (unsigned)(x >> 32) == epoch;
             }
             if (__all(ok)) break;
@@ -193,8 +197,11 @@ __device__ __forceinline__ bool group_exchange(Shared* sh, gu64* xch, int G, int
             __builtin_amdgcn_s_sleep(1);
         }
         const unsigned pay = (unsigned)x;
-        const unsigned lo = __shfl(pay, (2 * lane) & 63, 64), hi = __shfl(pay, (2 * lane + 1) & 63, 64);
-        if (lane < K) tot += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                               // members in workgroup order: the sum has one fixed order everywhere
+            const unsigned lo = __shfl(pay, (16 * i + 2 * lane) & 63, 64), hi = __shfl(pay, (16 * i + 2 * lane + 1) & 63, 64);
+            if (lane < K && g0 + i < G) tot += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
     }
     if (lane < K) sh->vals[lane] = tot;
     return true;
@@ -964,7 +971,7 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
 }
 
 static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
     const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
@@ -984,7 +991,7 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
 }
 
 static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in);
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
@@ -1048,7 +1055,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 
 // ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
 static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in);
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6;
@@ -1104,7 +1111,7 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
 
 // ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
 static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in, int max_iter_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in), max_iter = uni(max_iter_in);
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in), max_iter = uni(max_iter_in);
     const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     // every lane fetches its share of the moving cloud for the NEXT iteration's transform while lane 0 does the scalar work
