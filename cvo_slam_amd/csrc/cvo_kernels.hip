@@ -223,19 +223,26 @@ struct Gates {
 // ~1 ulp like libm's exp; anything outside [-0.25, 0] takes the library routine.  The
 // value is rounded to f32 right after (cvo.cpp:172-173), where a 1-ulp double
 // difference is invisible except on ~1e-8 of inputs.
+// p*x + c as the three-address v_fma_f64 with the coefficient in an SGPR pair.  Left to itself the compiler picks the
+// two-address v_fmac_f64 for half of the Horner steps and pays a v_mov_b64 of the coefficient for each (28 moves per 4 entries).
+__device__ __forceinline__ double horner_step(double p, double x, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(x), "s"(c));
+    return d;
+}
 __device__ __forceinline__ double exp_poly13(double x) {
     double p = 1.0 / 6227020800.0;                                  // 1/13!
-    p = __builtin_fma(p, x, 1.0 / 479001600.0);
-    p = __builtin_fma(p, x, 1.0 / 39916800.0);
-    p = __builtin_fma(p, x, 1.0 / 3628800.0);
-    p = __builtin_fma(p, x, 1.0 / 362880.0);
-    p = __builtin_fma(p, x, 1.0 / 40320.0);
-    p = __builtin_fma(p, x, 1.0 / 5040.0);
-    p = __builtin_fma(p, x, 1.0 / 720.0);
-    p = __builtin_fma(p, x, 1.0 / 120.0);
-    p = __builtin_fma(p, x, 1.0 / 24.0);
-    p = __builtin_fma(p, x, 1.0 / 6.0);
-    p = __builtin_fma(p, x, 0.5);
+    p = horner_step(p, x, 1.0 / 479001600.0);
+    p = horner_step(p, x, 1.0 / 39916800.0);
+    p = horner_step(p, x, 1.0 / 3628800.0);
+    p = horner_step(p, x, 1.0 / 362880.0);
+    p = horner_step(p, x, 1.0 / 40320.0);
+    p = horner_step(p, x, 1.0 / 5040.0);
+    p = horner_step(p, x, 1.0 / 720.0);
+    p = horner_step(p, x, 1.0 / 120.0);
+    p = horner_step(p, x, 1.0 / 24.0);
+    p = horner_step(p, x, 1.0 / 6.0);
+    p = __builtin_fma(p, x, 0.5);                                   // inline constants: no register either way
     p = __builtin_fma(p, x, 1.0);
     p = __builtin_fma(p, x, 1.0);
     return p;
