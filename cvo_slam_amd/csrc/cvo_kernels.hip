@@ -802,8 +802,8 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
 // second pass.  Survivors {x_i,a},{y_j} are compacted per wave (ballot + prefix popcount) for the line-search phase.
 struct RowSums { float sw[3], sv[3]; };
 
-__device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, float a, unsigned tag /* slot << 16 | column */, RowSums& rs, const Ctx& c,
-                                           size_t sbase, int& wcount, int lane) {
+__device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, float a, unsigned tag /* slot << 16 | column */, RowSums& rs, gv2u* sp /* the wave's segment of nonzero records: wave-uniform */,
+                                           int& wcount, int lane) {
     {   // a == 0 for a non-member: it adds exact zeros, the sums keep their bits
         const float yv[3] = {y4.x, y4.y, y4.z};
         float cr[3]; cross3(xi, yv, cr);                            // cvo.cpp:216
@@ -814,7 +814,7 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
     if (a > 0.f) {
         const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         v2u rec; rec.x = __float_as_uint(a); rec.y = tag;             // 8 bytes per nonzero: the line search finds x_i, y_j in LDS
-        c.surv[sbase + (size_t)(wcount + (int)below)] = rec;
+        sp[(unsigned)wcount + below] = rec;                           // scalar base + 32-bit lane offset
     }
     wcount += __popcll(mask);
 }
@@ -823,7 +823,7 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
 template <int YM, bool FLAT>
 __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                             double (&acc8)[8]) {
-    const size_t sbase = c.fbase + sh->wbase[wave];
+    gv2u* sp = uni_ptr(c.surv + c.fbase + sh->wbase[wave]);
     const bool x_lds = sh->x_lds != 0;
     int wcount = 0;
     const int nb = sh->wnb[wave];
@@ -835,17 +835,18 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
         float xi[3]; load_x(c, L, x_lds, slot, xi);
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
-        const gv2u* ep = c.ent + slot;
-        const size_t estep = (size_t)PF * c.rows_pad;
+        const gv2u* eb = uni_ptr(c.ent + (slot - lane));             // scalar base of the block's entries + 32-bit lane offsets
+        const unsigned rp = (unsigned)c.rows_pad, estep = PF * rp;
+        unsigned eo = (unsigned)lane;
         const unsigned stag = (unsigned)slot << 16;
         v2u eq[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) eq[u] = ep[(size_t)u * c.rows_pad];
+        for (int u = 0; u < PF; ++u) eq[u] = eb[eo + (unsigned)u * rp];
         for (int n0 = 0; n0 < lw; n0 += PF) {
-            if (n0 + 2 * PF <= c.capn) ep += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
+            if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
             v2u en[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) en[u] = ep[(size_t)u * c.rows_pad];
+            for (int u = 0; u < PF; ++u) en[u] = eb[eo + (unsigned)u * rp];
             float av[PF]; float4 yv4[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {                          // independent until folded: PF exp chains in flight per lane
@@ -858,7 +859,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
             }
             if (FLAT) asm volatile("; all four kernel values before the first fold" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
 #pragma unroll
-            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, c, sbase, wcount, lane);
+            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, wcount, lane);
 #pragma unroll
             for (int u = 0; u < PF; ++u) eq[u] = en[u];
         }
@@ -875,7 +876,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
 template <int YM, bool FLAT>
 __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                            double (&acc8)[8]) {
-    const size_t sbase = c.fbase + sh->wbase[wave];
+    gv2u* sp = uni_ptr(c.surv + c.fbase + sh->wbase[wave]);
     int wcount = 0;
     const int nb = sh->wnb[wave];
     for (int bi = 0; bi < nb; ++bi) {
@@ -922,7 +923,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
                 else av[u] = act ? se_kernel_value_ck(xi, yv4[u], ck, gates) : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (unsigned)j0[u], rs, c, sbase, wcount, lane);
+            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (unsigned)j0[u], rs, sp, wcount, lane);
 #pragma unroll
             for (int u = 0; u < PF; ++u) { j0[u] = j1[u]; j1[u] = j2[u]; g0[u] = g1[u]; }
         }
