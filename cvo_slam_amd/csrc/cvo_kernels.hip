@@ -230,6 +230,27 @@ __device__ __forceinline__ double horner_step(double p, double x, double c) {
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(x), "s"(c));
     return d;
 }
+// the same polynomial for PFN arguments at once, coefficient by coefficient: the PFN Horner chains are independent, and issued
+// side by side no v_fma_f64 waits for the one before it (evaluated one after the other, every step is a dependent
+// double-precision op behind a wait state)
+template <int PFN>
+__device__ __forceinline__ void exp_poly13_n(const double (&x)[PFN], double (&p)[PFN]) {
+    const double cf[10] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0,
+                           1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0};
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) p[u] = 1.0 / 6227020800.0;                         // 1/13!
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+#pragma unroll
+        for (int u = 0; u < PFN; ++u) p[u] = horner_step(p[u], x[u], cf[k]);
+    }
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) p[u] = __builtin_fma(p[u], x[u], 0.5);
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) p[u] = __builtin_fma(p[u], x[u], 1.0);
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) p[u] = __builtin_fma(p[u], x[u], 1.0);
+}
 __device__ __forceinline__ double exp_poly13(double x) {
     double p = 1.0 / 6227020800.0;                                  // 1/13!
     p = horner_step(p, x, 1.0 / 479001600.0);
@@ -299,6 +320,26 @@ __device__ __forceinline__ float se_kernel_value_ck(const float* xi, const float
 // Branch-free form for the steady-state loop (several independent entries in flight per lane); requires Gates::poly_ok,
 // i.e. every exponent of a pair inside the radius lies in [-0.25, 0].  A rejected pair's arithmetic runs on a clamped
 // argument and is thrown away.
+// se_kernel_value_flat for PFN entries of one row at once
+template <int PFN>
+__device__ __forceinline__ void se_kernel_values_flat(const float* xi, const float4 (&yj)[PFN], const float (&ck)[PFN], const bool (&active)[PFN], const Gates& G,
+                                                      float (&a_out)[PFN]) {
+    double x[PFN], p[PFN]; bool pass[PFN];
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+        const float e0 = xi[0] - yj[u].x, e1 = xi[1] - yj[u].y, e2 = xi[2] - yj[u].z;
+        float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;              // nanoflann.hpp:403-406
+        pass[u] = active[u] & (d2 < G.d2_thres);
+        x[u] = fmax((double)(-d2) * G.inv_den_l, -0.25);
+    }
+    exp_poly13_n<PFN>(x, p);
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+        const float k = (float)((double)G.s2 * p[u]);
+        const float a = ck[u] * k;
+        a_out[u] = (pass[u] & (a > G.sp)) ? a : 0.f;
+    }
+}
 __device__ __forceinline__ float se_kernel_value_flat(const float* xi, const float4 yj, float ck, bool active, const Gates& G) {
     const float e0 = xi[0] - yj.x, e1 = xi[1] - yj.y, e2 = xi[2] - yj.z;
     float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;                  // nanoflann.hpp:403-406
@@ -847,17 +888,19 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
             v2u en[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) en[u] = eb[eo + (unsigned)u * rp];
-            float av[PF]; float4 yv4[PF];
+            float av[PF], ckv[PF]; float4 yv4[PF]; bool actv[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {                          // independent until folded: PF exp chains in flight per lane
-                const bool act = n0 + u < len;
-                const int j = act ? (int)eq[u].y : 0;               // slots past the row's end hold stale entries
+            for (int u = 0; u < PF; ++u) {
+                actv[u] = n0 + u < len;
+                const int j = actv[u] ? (int)eq[u].y : 0;           // slots past the row's end hold stale entries
                 yv4[u] = load_y<YM>(c, L, j);
-                const float ck = __uint_as_float(eq[u].x);
-                if (FLAT) av[u] = se_kernel_value_flat(xi, yv4[u], ck, act, gates);
-                else av[u] = act ? se_kernel_value_ck(xi, yv4[u], ck, gates) : 0.f;
+                ckv[u] = __uint_as_float(eq[u].x);
             }
-            if (FLAT) asm volatile("; all four kernel values before the first fold" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
+            if (FLAT) se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av);   // PF exp chains side by side
+            else {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) av[u] = actv[u] ? se_kernel_value_ck(xi, yv4[u], ckv[u], gates) : 0.f;
+            }
 #pragma unroll
             for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, wcount, lane);
 #pragma unroll
@@ -907,20 +950,32 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         for (int n0 = 0; n0 < lw; n0 += PF) {
             cols(n0 + 2 * PF, j2);
             feats(j1, g1);
-            float av[PF]; float4 yv4[PF];
+            float av[PF], ckv[PF], d2c[PF]; float4 yv4[PF]; bool actv[PF];
+            double kc[PF], rc[PF], pc[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const bool act = n0 + u < len;
+                actv[u] = n0 + u < len;
                 const int j = j0[u];
                 yv4[u] = load_y<YM>(c, L, j);
                 const float f0 = (YM == 2) ? ld4(c.moving + lo_off(j)).w : yv4[u].w;   // the first channel rides with y, except in the 12-byte LDS layout
                 const float fb[5] = {f0, g0[u].x, g0[u].y, g0[u].z, g0[u].w};
-                const float d2c = feat_d2(fi, fb);
-                const float ckv = (float)((double)gates.csig2 * exp_neg((double)(-d2c) * gates.inv_den_c));
-                const float ck = (d2c < gates.d2c_thres) ? ckv : __builtin_nanf("");
-                if (act) { v2u e; e.x = __float_as_uint(ck); e.y = (unsigned)j; ep[(size_t)(n0 + u) * c.rows_pad] = e; }
-                if (FLAT) av[u] = se_kernel_value_flat(xi, yv4[u], ck, act, gates);
-                else av[u] = act ? se_kernel_value_ck(xi, yv4[u], ck, gates) : 0.f;
+                d2c[u] = feat_d2(fi, fb);
+                // exp_neg, its PF range reductions and polynomials side by side
+                const double xc = (double)(-d2c[u]) * gates.inv_den_c;
+                kc[u] = __builtin_rint(xc * 1.44269504088896338700e+00);
+                rc[u] = __builtin_fma(kc[u], -1.90821492927058770002e-10, __builtin_fma(kc[u], -6.93147180369123816490e-01, xc));
+            }
+            exp_poly13_n<PF>(rc, pc);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const float ckx = (float)((double)gates.csig2 * __builtin_ldexp(pc[u], (int)kc[u]));
+                ckv[u] = (d2c[u] < gates.d2c_thres) ? ckx : __builtin_nanf("");
+                if (actv[u]) { v2u e; e.x = __float_as_uint(ckv[u]); e.y = (unsigned)j0[u]; ep[(size_t)(n0 + u) * c.rows_pad] = e; }
+            }
+            if (FLAT) se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av);
+            else {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) av[u] = actv[u] ? se_kernel_value_ck(xi, yv4[u], ckv[u], gates) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (unsigned)j0[u], rs, sp, wcount, lane);
