@@ -302,7 +302,7 @@ struct Engine {
             int want = 1; while (want * 2 * 384 <= nf_max && want < 32) want *= 2;
             G = 1; while (G * 2 * n_pairs <= num_cus * per_cu && G < want) G *= 2;
         }
-        const int g_min = (nf_max + MAX_ROWS_PER_WG - 1) / MAX_ROWS_PER_WG;     // a workgroup owns at most MAX_ROWS_PER_WG rows
+        const int g_min = (((nf_max + 127) / 128) + (MAX_ROWS_PER_WG / 128) - 1) / (MAX_ROWS_PER_WG / 128);   // a workgroup owns at most MAX_ROWS_PER_WG rows, dealt in blocks of 128
         G = std::max(std::max(1, g_min), std::min(G, num_cus));
         return G;
     }
@@ -330,7 +330,7 @@ struct Engine {
         // (mode 1) beside a cull tile that holds the whole cloud; else as three float planes (mode 2, 12 B/point) beside a
         // tile just large enough to keep the fixed points in slot order; else it stays in HBM/L2 (mode 0).
         const size_t lds_cap = (size_t)(160 / per_cu - 4) * 1024;
-        const int rows_per_w = (nf_max + G - 1) / G;
+        const int rows_per_w = ((((std::max(nf_max, 1) + 127) / 128) + G - 1) / G) * 128;   // rows are dealt to the workgroups in blocks of 128 (ROW_DEAL)
         const int rows_cap = round_up(std::max(rows_per_w, 1), 128) + 64;
         const int tile_full = std::min(round_up(std::max(nm_max, tgran), tgran), 4096);
         const int tile_rows = round_up(std::max(round_up(std::max(rows_per_w, 1), 64), 512), tgran);   // >= the slots: x_i by slot fits the idle tile
@@ -351,7 +351,7 @@ struct Engine {
             else if (allow_lds && align_shared_bytes(t2, rows_cap, 2, nm_pad) <= lds_cap) { y_mode = 2; tile = t2; }
             else { tile = std::min(tile_full, 2048); while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0) > lds_cap) tile -= tgran; }
         }
-        const int rows_per = (nf_max + G - 1) / G;
+        const int rows_per = rows_per_w;
         int block = rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64));
         if (per_cu > 1) block = std::min(block, 256);
         if (block_request > 0) block = std::max(64, std::min(512, round_up(block_request, 64)));
@@ -364,7 +364,7 @@ struct Engine {
         if ((rc = h_states_in.ensure(sizeof(PairState) * n))) return rc;
         if (2 * (long long)P.max_iter + 2 >= 65536) return fail(CVO_ERR_INVALID, "max_iter must be below 32767");
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
-        const size_t plane = (size_t)(nf_pad + G) * capf;
+        const size_t plane = (size_t)G * rows_per * capf;                   // workgroup g's nonzero records start at g * rows_per * capf
         const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
         int capn = 64; while (capn < nm_max / 3 && capn < 4096) capn *= 2;   // longest list a row may have: 1024 at 3 k points, 4096 at 10 k
         if (const char* e = std::getenv("CVO_HIP_ROW_CAP")) capn = std::max(1, std::atoi(e));

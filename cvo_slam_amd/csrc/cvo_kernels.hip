@@ -503,8 +503,10 @@ __device__ __forceinline__ Lds lds_layout(int tgeo) {
     return L;
 }
 
-// one pair as seen by workgroup g of its G: rows are dealt round-robin (local row li <-> fixed point g + G*li):
-// near surfaces have many more neighbours per row than far ones, bands of rows would be unbalanced
+// one pair as seen by workgroup g of its G: the fixed cloud is cut into blocks of ROW_DEAL consecutive rows (scan order:
+// a thin slab of the image, so the cull's boxes stay tight) and the blocks are dealt round-robin (near surfaces have many
+// more neighbours per row than far ones: whole bands of the image per workgroup would be unbalanced)
+constexpr int ROW_DEAL = 128;
 struct Ctx {
     const gfloat* fixed; const gfloat* moving;
     int nf, nm, nrows, rows_per, rows_pad, capn, nm_pad, flat_cap, g, G;
@@ -517,8 +519,10 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     Ctx c;
     c.g = g; c.G = G;
     c.nf = D.nf; c.nm = D.nm; c.nm_pad = D.nm_pad; c.rows_pad = D.rows_pad; c.capn = D.capn;
-    c.rows_per = (c.nf + G - 1) / G;
-    c.nrows = (g < c.nf) ? (c.nf - g + G - 1) / G : 0;
+    const int nblocks = (c.nf + ROW_DEAL - 1) / ROW_DEAL;
+    c.rows_per = ((nblocks + G - 1) / G) * ROW_DEAL;                // the most rows any workgroup of the pair owns
+    const int mine = (g < nblocks) ? (nblocks - g + G - 1) / G : 0; // blocks g, g + G, g + 2G, ...; only the cloud's last block may be short
+    c.nrows = mine * ROW_DEAL - ((mine > 0 && (nblocks - 1) % G == g) ? nblocks * ROW_DEAL - c.nf : 0);
     c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
     c.ybuf = GF4{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
     c.surv = (gv2u*)D.surv;
@@ -530,10 +534,13 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     return c;
 }
 
+// fixed-cloud row of a workgroup's local row
+__device__ __forceinline__ int global_row(const Ctx& c, int li) { return (c.g + c.G * (li / ROW_DEAL)) * ROW_DEAL + (li % ROW_DEAL); }
+
 // fixed point of a slot: from the LDS copy made after the sort, or gathered from the cloud
 __device__ __forceinline__ void load_x(const Ctx& c, const Lds& L, bool x_lds, int slot, float (&xi)[3]) {
     if (x_lds) { xi[0] = L.lx[slot]; xi[1] = L.ly[slot]; xi[2] = L.lz[slot]; }
-    else { const float4 lo = ld4(c.fixed + lo_off(c.g + c.G * (int)L.row_of[slot])); xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; }
+    else { const float4 lo = ld4(c.fixed + lo_off(global_row(c, (int)L.row_of[slot]))); xi[0] = lo.x; xi[1] = lo.y; xi[2] = lo.z; }
 }
 
 // transformed moving point j; .w = first feature channel in modes 0 and 1, not available (0) in mode 2
@@ -679,7 +686,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             for (int r = 0; r < SWEEP_R; ++r) {
                 li[r] = (b2 * SWEEP_R + r) * 64 + lane;
                 if (li[r] < nrows) {
-                    const float4 lo4 = ld4(c.fixed + lo_off(g + G * li[r]));
+                    const float4 lo4 = ld4(c.fixed + lo_off(global_row(c, li[r])));
                     x[r][0] = lo4.x; x[r][1] = lo4.y; x[r][2] = lo4.z;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) { blo[q] = fminf(blo[q], x[r][q]); bhi[q] = fmaxf(bhi[q], x[r][q]); }
@@ -828,7 +835,7 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
     const int xl = (nblk * 64 <= tile) ? 1 : 0;
     if (xl) {
         for (int sl = tid; sl < nblk * 64; sl += nthreads) {
-            const float4 lo = ld4(c.fixed + lo_off(g + G * (int)L.row_of[sl]));
+            const float4 lo = ld4(c.fixed + lo_off(global_row(c, (int)L.row_of[sl])));
             L.lx[sl] = lo.x; L.ly[sl] = lo.y; L.lz[sl] = lo.z;
         }
     }
@@ -929,7 +936,8 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         int lw = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
-        const float4 lo = ld4(c.fixed + lo_off(c.g + c.G * li)), hi = ld4(c.fixed + hi_off(c.nf, c.g + c.G * li));
+        const int gi = global_row(c, li);
+        const float4 lo = ld4(c.fixed + lo_off(gi)), hi = ld4(c.fixed + hi_off(c.nf, gi));
         const float xi[3] = {lo.x, lo.y, lo.z};
         const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
@@ -1075,7 +1083,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
         if (tid == 0) acc8[7] = (double)sh->total;
     } else {
         for (int li = tid; li < nrows; li += nthreads) {            // dense fallback: every column of the row
-            const int i = g + G * li;
+            const int i = global_row(c, li);
             const float4 lo = ld4(c.fixed + lo_off(i)), hi = ld4(c.fixed + hi_off(c.nf, i));
             const float xi[3] = {lo.x, lo.y, lo.z};
             const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -1150,7 +1158,7 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
     } else {
         const Gates gates = make_gates(sh->ell, sh->P);
         for (int li = tid; li < c.nrows; li += nthreads) {
-            const int i = g + G * li;
+            const int i = global_row(c, li);
             const float4 lo = ld4(c.fixed + lo_off(i)), hi = ld4(c.fixed + hi_off(c.nf, i));
             const float xi[3] = {lo.x, lo.y, lo.z};
             const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -1244,7 +1252,7 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
     for (int p = slot; p < n_pairs; p += slots) {
         const PairDesc* Dp = descs + p;
         const int nf = Dp->nf, nm = Dp->nm;
-        const int rows_per = (nf + G - 1) / G;
+        const int rows_per = ((((nf + ROW_DEAL - 1) / ROW_DEAL) + G - 1) / G) * ROW_DEAL;
         if (tid < 25) {                                               // R[9], T[3], ell, transform[12]: the head of PairState, one lane per word
             const float v = ((const gfloat*)Dp->state_in)[tid];
             if (tid < 9) sh->R[tid] = v; else if (tid < 12) sh->T[tid - 9] = v; else if (tid == 12) sh->ell = v; else sh->M[tid - 13] = v;
