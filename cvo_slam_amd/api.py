@@ -59,6 +59,11 @@ class LcScores(C.Structure):
                 ("cos_angle", C.c_float), ("accept", C.c_int)]
 
 
+class TrackScores(C.Structure):
+    _fields_ = [("inn_pre", InnP), ("inn_post", InnP), ("inn_fixed_pcd", InnP), ("inn_moving_pcd", InnP), ("post_hessian", C.c_double * 36),
+                ("inliers", C.c_int), ("cos_angle", C.c_float)]
+
+
 # every symbol include/cvo_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = [
     "cvo_last_error", "cvo_device_count", "cvo_default_params", "cvo_create", "cvo_destroy", "cvo_set_pcd", "cvo_align",
@@ -71,6 +76,7 @@ ABI_SYMBOLS = [
     "cvo_batch_reset_states", "cvo_batch_align_async", "cvo_batch_wait", "cvo_batch_last_launch",
     "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds", "cvo_batch_compute_innerproduct_lc",
     "cvo_set_pcd_images", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
+    "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
 ]
 
 _lib = None
@@ -138,6 +144,9 @@ def load_library():
     L.cvo_match_keyframe_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera), dp]
     L.cvo_get_cloud.argtypes = [vp, C.c_int, fp, fp, C.c_int, ip]
     L.cvo_get_selected_points.argtypes = [vp, C.c_int, vp, C.c_int, ip]
+    L.cvo_batch_enqueue_innerproduct.argtypes = [vp, C.c_int]
+    L.cvo_batch_innerproduct_results.argtypes = [vp, C.c_int, C.POINTER(TrackScores)]
+    L.cvo_batch_compute_innerproduct.argtypes = [vp, C.c_int, C.POINTER(TrackScores)]
     _lib = L
     return L
 
@@ -433,6 +442,22 @@ class CvoBatch:
                      inn_fixed_pcd=tup(o.inn_fixed_pcd), inn_moving_pcd=tup(o.inn_moving_pcd),
                      post_hessian=np.array(o.post_hessian[:]).reshape(6, 6), inliers_svd=o.inliers_svd, inliers_pnpransac=o.inliers_pnpransac,
                      cos_angle=o.cos_angle, accept=bool(o.accept)) for o in out]
+
+    # -- local_tracker.cpp:240-251 for every aligned pair, one launch queued behind the align launch
+    def enqueue_innerproduct(self, n: int):
+        _check(self.L.cvo_batch_enqueue_innerproduct(self.h, n))
+
+    def innerproduct_results(self, n: int):
+        """One dict per pair with the fields of `compute_innerproduct` (cvo.cpp:475-503), tran = the pair's own align() result."""
+        out = (TrackScores * n)()
+        _check(self.L.cvo_batch_innerproduct_results(self.h, n, out))
+        tup = lambda r: (r.value, r.num, r.num_e)
+        return [dict(inn_pre=tup(o.inn_pre), inn_post=tup(o.inn_post), inn_fixed_pcd=tup(o.inn_fixed_pcd), inn_moving_pcd=tup(o.inn_moving_pcd),
+                     post_hessian=np.array(o.post_hessian[:]).reshape(6, 6), inliers=o.inliers, cos_angle=o.cos_angle) for o in out]
+
+    def compute_innerproduct(self, n: int):
+        self.enqueue_innerproduct(n)
+        return self.innerproduct_results(n)
 
     def results_to_device(self, dst_device_ptr: int, n: int, stream: int | None = None):
         _check(self.L.cvo_batch_results_to_device(self.h, C.c_void_p(dst_device_ptr), n, C.c_void_p(stream) if stream else None))

@@ -444,9 +444,16 @@ struct Engine {
     // function_inner_product / se3_Hessian: out[0]=sum_A, out[1]=count, out[2..22]=Hessian terms
     // A score block: any number of function_inner_product / se3_Hessian evaluations in one launch.
     // out[r][0] = sum_A, out[r][1] = pair count, out[r][2..22] = Hessian terms.
-    struct ScoreReq { const Cloud* a; const float* tran; const Cloud* b; bool hessian; float ell; };
+    struct ScoreReq {
+        const Cloud* a; const float* tran; const Cloud* b; bool hessian; float ell;
+        int from = -1;                    // >= 0: ell comes from pair `from`'s device-resident state (the align() result, Q1) ...
+        bool tran_from_state = false;     // ... and so does the transform applied to cloud a
+    };
     DevBuf d_scoredescs; PinBuf h_scoredescs;
-    int score_many(const ScoreReq* rq, int n, double (*out)[24]) {
+    std::vector<unsigned char> scoredescs_uploaded;
+    hipStream_t score_stream = nullptr; int score_pending = 0;
+    // Queue the launch on stream s; the sums land in pinned memory when s has drained (score_collect).
+    int score_enqueue(const ScoreReq* rq, int n, hipStream_t s) {
         HIP_TRY(hipSetDevice(device));
         if (n <= 0) return fail(CVO_ERR_INVALID, "bad score request count");
         std::vector<ScoreDesc> descs(n);
@@ -457,8 +464,10 @@ struct Engine {
             std::memset(&D, 0, sizeof(D));
             D.a = rq[r].a->rec(); D.b = rq[r].b->rec(); D.na = rq[r].a->n; D.nb = rq[r].b->n; D.ell = rq[r].ell;
             D.want_hessian = rq[r].hessian ? 1 : 0; D.out = nullptr;
-            D.use_tran = rq[r].tran ? 1 : 0;
-            for (int i = 0; i < 12; ++i) D.tran[i] = rq[r].tran ? rq[r].tran[i] : 0.f;
+            D.from = rq[r].from >= 0 ? static_cast<const PairState*>(d_states.p) + rq[r].from : nullptr;
+            if (rq[r].tran_from_state && !D.from) return fail(CVO_ERR_INVALID, "score request: transform from a state that is not named");
+            D.use_tran = rq[r].tran_from_state ? 2 : (rq[r].tran ? 1 : 0);
+            for (int i = 0; i < 12; ++i) D.tran[i] = (rq[r].tran && !rq[r].tran_from_state) ? rq[r].tran[i] : 0.f;
             row_blocks = std::max(row_blocks, score_row_blocks(D.na));
         }
         const int nout = score_nout();
@@ -470,19 +479,37 @@ struct Engine {
         const ScoreDesc* more = nullptr;
         if (n <= SCORE_MAXREQ) { B.n = n; for (int r = 0; r < n; ++r) B.d[r] = descs[r]; }
         else {
-            if ((rc = d_scoredescs.ensure(sizeof(ScoreDesc) * (size_t)n))) return rc;
-            if ((rc = h_scoredescs.ensure(sizeof(ScoreDesc) * (size_t)n))) return rc;
-            HIP_TRY(hipStreamSynchronize(stream));
-            std::memcpy(h_scoredescs.p, descs.data(), sizeof(ScoreDesc) * (size_t)n);
-            HIP_TRY(hipMemcpyAsync(d_scoredescs.p, h_scoredescs.p, sizeof(ScoreDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
+            // like the align descriptors: uploaded only when they changed, so a steady stream of score blocks over the same pairs
+            // (transforms taken from the device-resident states) queues no copy
+            const size_t bytes = sizeof(ScoreDesc) * (size_t)n;
+            if (scoredescs_uploaded.size() != bytes || std::memcmp(scoredescs_uploaded.data(), descs.data(), bytes) != 0) {
+                if ((rc = d_scoredescs.ensure(bytes))) return rc;
+                if ((rc = h_scoredescs.ensure(bytes))) return rc;
+                HIP_TRY(hipStreamSynchronize(s));
+                std::memcpy(h_scoredescs.p, descs.data(), bytes);
+                HIP_TRY(hipMemcpyAsync(d_scoredescs.p, h_scoredescs.p, bytes, hipMemcpyHostToDevice, s));
+                scoredescs_uploaded.assign(reinterpret_cast<const unsigned char*>(descs.data()), reinterpret_cast<const unsigned char*>(descs.data()) + bytes);
+            }
             more = static_cast<const ScoreDesc*>(d_scoredescs.p);
         }
-        hipError_t e = launch_score(B, more, n, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), stream);
+        hipError_t e = launch_score(B, more, n, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), s);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("score kernel launch: ") + hipGetErrorString(e));
-        HIP_TRY(hipStreamSynchronize(stream));
+        score_stream = s; score_pending = n;
+        return CVO_OK;
+    }
+    int score_collect(int n, double (*out)[24]) {
+        HIP_TRY(hipSetDevice(device));
+        if (n <= 0 || n != score_pending) return fail(CVO_ERR_INVALID, "no queued score block of that size");
+        HIP_TRY(hipStreamSynchronize(score_stream));
+        const int nout = score_nout();
         const double* hp = static_cast<const double*>(h_partials.p);
         for (int r = 0; r < n; ++r) for (int q = 0; q < 24; ++q) out[r][q] = q < nout ? hp[(size_t)r * nout + q] : 0.0;
+        score_pending = 0;
         return CVO_OK;
+    }
+    int score_many(const ScoreReq* rq, int n, double (*out)[24]) {
+        int rc = score_enqueue(rq, n, stream); if (rc) return rc;
+        return score_collect(n, out);
     }
 };
 
@@ -1066,6 +1093,43 @@ int cvo_batch_compute_innerproduct_lc(cvo_batch b, int n, const float* prior_tra
         o.accept = reject ? 0 : 1;
     }
     return CVO_OK;
+}
+// The tracker's score block (cvo.cpp:475-503) for every pair of the last launch, each with its own align() result as `tran` and
+// the ell that align() left behind (Q1).  enqueue: one launch behind the align launch on its stream, transforms read from the
+// device-resident states, nothing waits; results: waits and finishes the sums on the host.
+int cvo_batch_enqueue_innerproduct(cvo_batch b, int n) {
+    if (!b) return fail(CVO_ERR_INVALID, "null argument");
+    if (n <= 0 || n > b->last_n || !b->eng.launched) return fail(CVO_ERR_INVALID, "more pairs than the last launch aligned");
+    std::vector<Engine::ScoreReq> rq((size_t)n * 5);
+    for (int i = 0; i < n; ++i) {
+        const Cloud* fx = b->fixed[i].get(); const Cloud* mv = b->moving[i].get();
+        if (!fx || !mv || fx->n <= 0 || mv->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "compute_innerproduct: empty cloud in the batch");
+        Engine::ScoreReq* q = &rq[(size_t)i * 5];
+        q[0] = {mv, nullptr, fx, false, 0.f, i, false};              // cvo.cpp:489
+        q[1] = {mv, nullptr, fx, false, 0.f, i, true};               // cvo.cpp:491
+        q[2] = {fx, nullptr, fx, false, 0.f, i, false};              // cvo.cpp:496
+        q[3] = {mv, nullptr, mv, false, 0.f, i, false};              // cvo.cpp:497
+        q[4] = {mv, nullptr, fx, true, 0.f, i, true};                // cvo.cpp:500
+    }
+    return b->eng.score_enqueue(rq.data(), n * 5, b->eng.last_stream);
+}
+int cvo_batch_innerproduct_results(cvo_batch b, int n, cvo_track_scores* out) {
+    if (!b || !out) return fail(CVO_ERR_INVALID, "null argument");
+    std::vector<double> r((size_t)std::max(n, 1) * 5 * 24);
+    int rc = b->eng.score_collect(n * 5, reinterpret_cast<double (*)[24]>(r.data())); if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        const double (*ri)[24] = reinterpret_cast<const double (*)[24]>(r.data() + (size_t)i * 5 * 24);
+        cvo_track_scores& o = out[i];
+        finish_inn_p(ri[0], &o.inn_pre); finish_inn_p(ri[1], &o.inn_post); finish_inn_p(ri[2], &o.inn_fixed_pcd); finish_inn_p(ri[3], &o.inn_moving_pcd);
+        o.cos_angle = o.inn_post.value / (sqrtf(o.inn_fixed_pcd.value) * sqrtf(o.inn_moving_pcd.value));           // cvo.cpp:498
+        o.inliers = (int)ri[4][1];                                   // cvo.cpp:708 with the caller's counter starting at 0 (local_tracker.cpp:240)
+        finish_hessian(ri[4] + 2, o.inliers, o.post_hessian);
+    }
+    return CVO_OK;
+}
+int cvo_batch_compute_innerproduct(cvo_batch b, int n, cvo_track_scores* out) {
+    int rc = cvo_batch_enqueue_innerproduct(b, n); if (rc) return rc;
+    return cvo_batch_innerproduct_results(b, n, out);
 }
 int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stream) {
     if (!b || !dst_device || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad argument");

@@ -84,8 +84,10 @@ struct ScoreDesc {
     const float* b;          // two planes of nb float4: searched cloud
     int na, nb;
     float tran[12];
-    int use_tran;
+    int use_tran;            // 0: a as stored, 1: a transformed by tran, 2: a transformed by from->transform (the pair's own align() result)
     float ell;
+    const PairState* from;   // non-null: ell (and the transform when use_tran == 2) come from this device-resident state, so a score block can be
+                             // queued behind the align launch that produces it without a host round trip
     int want_hessian;        // 0: inner product only, 1: Hessian terms too
     double* out;
 };

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, co
     __shared__ __attribute__((aligned(16))) float lz[SCORE_TILE];
 
     const int tid = threadIdx.x, i = blockIdx.x * SCORE_BLOCK + tid;
-    const float ell = D.ell, sigma = P.sigma;
+    const float ell = D.from ? D.from->ell : D.ell, sigma = P.sigma;
     const float d2_thres = gate_d2_score(ell, P.sp_thres, sigma);                // cvo.cpp:395 / 626
     const float d2c_thres = gate_d2c(P.c_ell, P.sp_thres, P.c_sigma);            // cvo.cpp:396 / 627
     const float thr_cull = d2_thres * (1.0f + 1e-6f);
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, co
     const bool valid = i < D.na;
     if (valid) {
         const float4 lo = ld4s(D.a + lo_off(i)), hi = ld4s(D.a + hi_off(D.na, i));
-        if (D.use_tran) apply_transform(D.tran, lo.x, lo.y, lo.z, pa[0], pa[1], pa[2]);
+        if (D.use_tran) apply_transform(D.use_tran == 2 ? D.from->transform : D.tran, lo.x, lo.y, lo.z, pa[0], pa[1], pa[2]);
         else { pa[0] = lo.x; pa[1] = lo.y; pa[2] = lo.z; }
         fa[0] = lo.w; fa[1] = hi.x; fa[2] = hi.y; fa[3] = hi.z; fa[4] = hi.w;
     }

@@ -230,6 +230,21 @@ typedef struct cvo_lc_scores {
 int cvo_batch_compute_innerproduct_lc(cvo_batch b, int n, const float* prior_tran, const float* lc_prior_tran,
                                       const float* lc_prior_tran_2, cvo_lc_scores* out);
 
+/* The tracker's score block (cvo::compute_innerproduct, cvo.cpp:475-503; caller local_tracker.cpp:240-251) for the
+ * first n pairs of the last align launch: tran = each pair's own align() result, ell = what that align() left
+ * behind (Q1), inliers counted from 0.  enqueue queues ONE launch behind the align launch on its stream (the
+ * transforms are read from the device-resident states, the host does not wait); results waits for it and finishes
+ * the sums (inn_p count rule, Hessian scaling and eigenvalue shift) on the host.  compute = both. */
+typedef struct cvo_track_scores {
+    cvo_inn_p inn_pre, inn_post, inn_fixed_pcd, inn_moving_pcd;    /* cvo.cpp:489-497 */
+    double post_hessian[36];           /* cvo.cpp:500 */
+    int    inliers;                    /* cvo.cpp:708 */
+    float  cos_angle;                  /* cvo.cpp:498 */
+} cvo_track_scores;
+int cvo_batch_enqueue_innerproduct(cvo_batch b, int n);
+int cvo_batch_innerproduct_results(cvo_batch b, int n, cvo_track_scores* out);
+int cvo_batch_compute_innerproduct(cvo_batch b, int n, cvo_track_scores* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -484,6 +484,43 @@ def test_batch_loop_closure_verification_block(hiplib, oracle):
     B.close()
 
 
+def test_batch_tracker_score_block_queued_behind_align(hiplib, oracle):
+    """local_tracker.cpp:228-251 for a batch: align, then compute_innerproduct with tran = the alignment's own result and the
+    ell it left behind (Q1), inliers counted from 0.  The score launch is queued behind the align launch (transforms read from
+    the device-resident states) and collected afterwards; a second round over the same batch object (descriptor cache hit,
+    warm-started states, carried ell) must match the oracle objects driven twice as well."""
+    from cvo_slam_amd import synth
+    sizes = (300, 520, 64, 900, 410, 777, 333, 640, 250, 1000, 1500)           # 55 requests: descriptors travel through HBM
+    pairs = [synth.make_small_pair(900 + i, n=n) for i, n in enumerate(sizes)]
+    n = len(pairs)
+    B = hiplib.CvoBatch(n)
+    single = []
+    for i, p in enumerate(pairs):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+        o = oracle.OracleCvo(); o.set_pcd(p.fixed.xyz, p.fixed.feat); o.set_pcd(p.moving.xyz, p.moving.feat)
+        single.append(o)
+    for rnd in range(2):
+        B.align_async(n)
+        B.enqueue_innerproduct(n)                                               # no host wait in between
+        res = B.wait(n)
+        got = B.innerproduct_results(n)
+        assert len(got) == n
+        for i, (o, r, g) in enumerate(zip(single, res, got)):
+            rc, _ = o.align(); assert rc == 0
+            st = o.get_state()
+            assert_pose_close(r["transform"], st["transform"])
+            rc, want = o.compute_innerproduct(st["transform"]); assert rc == 0
+            for key in ("inn_pre", "inn_post", "inn_fixed_pcd", "inn_moving_pcd"):
+                assert g[key][1] == want[key][1], (rnd, i, key)
+                assert g[key][0] == pytest.approx(want[key][0], rel=1e-5), (rnd, i, key)
+            assert g["inliers"] == want["inliers"], (rnd, i)
+            assert g["cos_angle"] == pytest.approx(want["cos_angle"], rel=1e-5)
+            np.testing.assert_allclose(g["post_hessian"], want["post_hessian"], rtol=1e-3, atol=1e-3 * np.abs(want["post_hessian"]).max())
+    with pytest.raises(hiplib.CvoError):
+        B.innerproduct_results(n)                                               # nothing queued any more
+    B.close()
+
+
 def test_handles_are_independent_across_host_threads(hiplib, oracle):
     """keyframe_graph.cpp:212-240: the optional back-end thread owns its own cvo objects while the tracker thread uses its.
     Handles share nothing (own stream, own buffers, thread-local error text): four host threads, each with its own object and
