@@ -301,6 +301,41 @@ def main():
 
     results = batch.wait(n)
     info = batch.last_launch()
+
+    # Secondary figure ("alignments incl. the post-align score block"): every step also queues the tracker's score
+    # block (4 inner products + 1 Hessian per pair, cvo.cpp:475-503) behind its align launch and collects it with the results.
+    with_scores = None
+    if world == 1 and not args.no_latency_probe:
+        k2 = max(depth, min(args.steps, 32))
+        scored = []
+
+        def step_scored(i):
+            bi = i % depth
+            if bi in scored:
+                scored.remove(bi); batches[bi].wait(); batches[bi].innerproduct_results(n)
+            b = batches[bi]
+            b.reset_states(); b.align_async(n); b.enqueue_innerproduct(n)
+            scored.append(bi)
+
+        def drain_scored():
+            last = None
+            while scored:
+                bi = scored.pop(0); batches[bi].wait(); last = batches[bi].innerproduct_results(n)
+            return last
+
+        for i in range(depth):
+            step_scored(i)
+        drain_scored(); torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(k2):
+            step_scored(i)
+        last_scores = drain_scored(); torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        with_scores = {"value": n * k2 / el2, "unit": "alignments/s", "steps": k2, "ms_per_step": 1e3 * el2 / k2,
+                       "score_block": "compute_innerproduct per pair (4 inner products + 1 Hessian, dense all-pairs sweeps at the ell align() left behind), "
+                                      "one launch per step queued behind the align launch",
+                       "mean_cos_angle": float(np.mean([r["cos_angle"] for r in last_scores]))}
+        batch.reset_states(); batch.align_async(n); batch.wait()       # leave batch 0 as the timed region left it
     if rank == 0 and os.environ.get("CVO_BENCH_PHASES"):
         ph = batch.last_phase_seconds(); its_all = sum(r["iterations_run"] for r in results)
         print("[bench] phase us/iteration under load (workgroup 0 of every pair of the last launch): " +
@@ -347,6 +382,7 @@ def main():
                          "note": "achieved = algorithmic bytes of ONE launch / its own HIP-event duration; a launch holds 64 of 256 CUs and "
                                  "launches_side_by_side of them run at once, achieved_all_launches is the whole GPU's rate.  The path is "
                                  "latency/VALU bound, not HBM bound (SURVEY 8d): see valu and DESIGN.md"},
+            "with_score_block": with_scores,
             "valu": {"dense_pair_tests_per_s": flops_launch / 8.0 / (step_ms_rank * 1e-3),
                      "executed_wave_instructions_per_launch": valu_instr,
                      "issue_slots_used": (valu_instr * 4.0 / (256 * 4 * 2.4e9 * step_ms_rank * 1e-3)) if valu_instr else None,

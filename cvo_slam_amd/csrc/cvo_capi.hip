@@ -39,6 +39,9 @@ hipError_t pcd_launch_cloud(const uint8_t* map, const uint16_t* depth, const uin
 hipError_t pcd_launch_unpack(const float* cloud, int n, float* xyz, float* feat, hipStream_t s);
 int score_nout();
 int score_row_blocks(int na);
+int score_groups(int n);
+size_t score_box_bytes(int n);
+hipError_t launch_cloud_boxes(const float* rec, int n, float* gbox, hipStream_t stream);
 hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
                         double* out_pinned, hipStream_t stream);
 }  // namespace cvohip
@@ -88,8 +91,10 @@ struct PinBuf {
 struct Cloud {
     DevBuf buf; int n = 0;
     DevBuf px; int n_px = 0;        // selected pixel (x, y) per point, when the cloud was generated from images
+    // boxes of the 32-point groups for the score kernels, made on first use after the points were written
+    mutable DevBuf boxes; mutable bool boxes_valid = false; mutable hipStream_t boxes_stream = nullptr;
     float* rec() const { return static_cast<float*>(buf.p); }
-    ~Cloud() { buf.release(); px.release(); }
+    ~Cloud() { buf.release(); px.release(); boxes.release(); }
 };
 
 DevParams to_dev(const cvo_params& p) {
@@ -165,7 +170,7 @@ struct Engine {
         HIP_TRY(hipSetDevice(device));
         if (n < 0) return fail(CVO_ERR_INVALID, "negative point count");
         if (n > 65535) return fail(CVO_ERR_INVALID, "more than 65535 points per cloud is not supported (16-bit column indices)");
-        c.n = n;
+        c.n = n; c.boxes_valid = false; uploads_pending = true;
         if (n == 0) return CVO_OK;
         if (!xyz || !feat) return fail(CVO_ERR_INVALID, "null cloud pointer");
         const size_t bytes = (size_t)n * REC * sizeof(float);
@@ -280,7 +285,7 @@ struct Engine {
         int npts = 0;
         for (int t = 0; t < nt; ++t) npts += hc[nt + t];                 // kept pixels with a valid depth = points (pcd_generator.cpp:471)
         if (npts > 65535) return fail(CVO_ERR_INVALID, "more than 65535 points per cloud is not supported (16-bit column indices)");
-        c.n = npts; c.n_px = npts;
+        c.n = npts; c.n_px = npts; c.boxes_valid = false;
         if (npts == 0) return CVO_OK;
         if ((rc = c.buf.ensure((size_t)npts * REC * sizeof(float)))) return rc;
         if ((rc = c.px.ensure((size_t)npts * 2 * sizeof(uint16_t)))) return rc;
@@ -315,6 +320,7 @@ struct Engine {
         const int n = (int)pairs.size();
         if (n <= 0) return fail(CVO_ERR_INVALID, "no pairs to align");
         hipStream_t s = on_stream ? on_stream : stream;
+        { int rcs = settle_uploads(s); if (rcs) return rcs; }
         int nf_max = 0, nm_max = 0;
         for (const PairIn& p : pairs) { nf_max = std::max(nf_max, p.fixed ? p.fixed->n : 0); nm_max = std::max(nm_max, p.moving ? p.moving->n : 0); }
         const int G = pick_workgroups(n, nf_max);
@@ -452,17 +458,38 @@ struct Engine {
     DevBuf d_scoredescs; PinBuf h_scoredescs;
     std::vector<unsigned char> scoredescs_uploaded;
     hipStream_t score_stream = nullptr; int score_pending = 0;
+    bool uploads_pending = false;     // clouds were written on `stream`: a launch on another stream waits for them once
+    int settle_uploads(hipStream_t s) {
+        if (uploads_pending && s != stream) HIP_TRY(hipStreamSynchronize(stream));
+        uploads_pending = false;
+        return CVO_OK;
+    }
+    int ensure_boxes(const Cloud& c, hipStream_t s) {
+        if (!c.boxes_valid) {
+            int rc = c.boxes.ensure(score_box_bytes(c.n)); if (rc) return rc;
+            hipError_t e = launch_cloud_boxes(c.rec(), c.n, static_cast<float*>(c.boxes.p), s);
+            if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("cloud box kernel launch: ") + hipGetErrorString(e));
+            c.boxes_valid = true; c.boxes_stream = s;
+        } else if (c.boxes_stream != s) {
+            HIP_TRY(hipStreamSynchronize(c.boxes_stream));           // made on another stream of this engine: complete before use here
+            c.boxes_stream = s;
+        }
+        return CVO_OK;
+    }
     // Queue the launch on stream s; the sums land in pinned memory when s has drained (score_collect).
     int score_enqueue(const ScoreReq* rq, int n, hipStream_t s) {
         HIP_TRY(hipSetDevice(device));
         if (n <= 0) return fail(CVO_ERR_INVALID, "bad score request count");
+        { int rcs = settle_uploads(s); if (rcs) return rcs; }
         std::vector<ScoreDesc> descs(n);
         int row_blocks = 1;
         for (int r = 0; r < n; ++r) {
             if (!rq[r].a || !rq[r].b || rq[r].a->n <= 0 || rq[r].b->n <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "empty cloud");
             ScoreDesc& D = descs[r];
             std::memset(&D, 0, sizeof(D));
+            int rcb = ensure_boxes(*rq[r].b, s); if (rcb) return rcb;
             D.a = rq[r].a->rec(); D.b = rq[r].b->rec(); D.na = rq[r].a->n; D.nb = rq[r].b->n; D.ell = rq[r].ell;
+            D.bbox = static_cast<const float*>(rq[r].b->boxes.p); D.nbox = score_groups(D.nb);
             D.want_hessian = rq[r].hessian ? 1 : 0; D.out = nullptr;
             D.from = rq[r].from >= 0 ? static_cast<const PairState*>(d_states.p) + rq[r].from : nullptr;
             if (rq[r].tran_from_state && !D.from) return fail(CVO_ERR_INVALID, "score request: transform from a state that is not named");

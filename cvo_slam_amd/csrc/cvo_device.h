@@ -82,6 +82,8 @@ struct PairDesc {
 struct ScoreDesc {
     const float* a;          // two planes of na float4: queried cloud (positions optionally transformed by tran)
     const float* b;          // two planes of nb float4: searched cloud
+    const float* bbox;       // its 32-point group boxes: planes lo x, y, z, y/z then hi x, y, z, y/z of nbox floats each
+    int nbox;
     int na, nb;
     float tran[12];
     int use_tran;            // 0: a as stored, 1: a transformed by tran, 2: a transformed by from->transform (the pair's own align() result)
