@@ -336,6 +336,40 @@ def main():
                                       "one launch per step queued behind the align launch",
                        "mean_cos_angle": float(np.mean([r["cos_angle"] for r in last_scores]))}
         batch.reset_states(); batch.align_async(n); batch.wait()       # leave batch 0 as the timed region left it
+
+    # PCIe-inclusive rate, for the record (never `value`): every step first hands its 64 pairs over as host buffers in the
+    # reference layout (cvo_batch_set_pair: packing + host-to-device copies), then aligns them.
+    with_upload = None
+    if world == 1 and not args.no_latency_probe:
+        k3 = max(depth, min(args.steps, 32))
+        busy = []
+
+        def step_upload(i):
+            bi = i % depth
+            if bi in busy:
+                busy.remove(bi); batches[bi].wait()
+            b = batches[bi]
+            for q, (_, fx, ff, mx, mf) in enumerate(pairs):
+                b.set_pair(q, fx, ff, mx, mf)
+            b.align_async(n)
+            busy.append(bi)
+
+        for i in range(depth):
+            step_upload(i)
+        while busy:
+            batches[busy.pop(0)].wait()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for i in range(k3):
+            step_upload(i)
+        while busy:
+            batches[busy.pop(0)].wait()
+        torch.cuda.synchronize()
+        el3 = time.perf_counter() - t3
+        mb = sum(fx.nbytes + ff.nbytes + mx.nbytes + mf.nbytes for (_, fx, ff, mx, mf) in pairs) / 1e6
+        with_upload = {"value": n * k3 / el3, "unit": "alignments/s", "steps": k3, "ms_per_step": 1e3 * el3 / k3, "host_MB_per_step": mb,
+                       "note": "clouds cross the boundary as host buffers every step (one host thread packs and copies them)"}
+        batch.reset_states(); batch.align_async(n); batch.wait()
     if rank == 0 and os.environ.get("CVO_BENCH_PHASES"):
         ph = batch.last_phase_seconds(); its_all = sum(r["iterations_run"] for r in results)
         print("[bench] phase us/iteration under load (workgroup 0 of every pair of the last launch): " +
@@ -383,6 +417,7 @@ def main():
                                  "launches_side_by_side of them run at once, achieved_all_launches is the whole GPU's rate.  The path is "
                                  "latency/VALU bound, not HBM bound (SURVEY 8d): see valu and DESIGN.md"},
             "with_score_block": with_scores,
+            "with_host_upload": with_upload,
             "valu": {"dense_pair_tests_per_s": flops_launch / 8.0 / (step_ms_rank * 1e-3),
                      "executed_wave_instructions_per_launch": valu_instr,
                      "issue_slots_used": (valu_instr * 4.0 / (256 * 4 * 2.4e9 * step_ms_rank * 1e-3)) if valu_instr else None,
