@@ -222,10 +222,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    backend = os.environ.get("CVO_BENCH_BACKEND", "nccl")          # "gloo" + CVO_BENCH_SHARE_GPU=1: rehearsal of the N>1 code path on a one-GPU box
+    if os.environ.get("CVO_BENCH_SHARE_GPU"):
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # `depth` batch objects, each on its own HIP stream, hold the same pairs; consecutive steps go to
     # alternating objects so that the next step's persistent kernel fills the CUs the previous step's
@@ -295,7 +301,7 @@ def main():
     elapsed = time.perf_counter() - t0
     assert len(kernel_ms) == args.steps
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -408,7 +414,7 @@ def main():
                        "pairs_per_gpu": n, "points_fixed_mean": float(np.mean(nfs)), "points_moving_mean": float(np.mean(nms)),
                        "iterations_mean": float(np.mean(its)), "iterations_max": int(np.max(its)),
                        "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth,
-                       "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": "RCCL all_gather of 64-byte result records" if world > 1 else "none (1 GPU)"},
+                       "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": (("RCCL" if backend == "nccl" else backend) + " all_gather of 64-byte result records") if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "cvo_align_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "launches_side_by_side": overlap, "achieved_all_launches": achieved_gbs * overlap,

@@ -33,6 +33,8 @@ def gather_results(local: torch.Tensor, n_pairs: int, world: int | None = None) 
     if world == 1:
         assert local.shape[0] == n_pairs
         return local.clone()
+    if local.is_cuda and dist.get_backend() != "nccl":        # rehearsal on a backend without device collectives: stage through the host
+        return gather_results(local.cpu(), n_pairs, world).to(local.device)
     rank = dist.get_rank()
     mine = shard_range(n_pairs, rank, world)
     assert local.shape == (len(mine), RESULT_FLOATS), (local.shape, len(mine))
