@@ -276,6 +276,49 @@ def test_score_block_vs_oracle(hiplib, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("case", ["shuffled", "behind_camera", "tiny", "ragged_33", "wide_ell"])
+def test_score_box_cull_edge_cases(hiplib, oracle, case):
+    """The score kernels skip 32-point groups by bounding box (x, y, z, ray slope).  Point order, points at or behind the camera
+    plane (no slope bound), clouds smaller than a group, a ragged last group and the widest radius (fresh object, ell = 0.15)
+    must not change a single pair: counts equal the oracle's, sums agree to f32 rounding."""
+    from cvo_slam_amd import synth
+    rng = np.random.default_rng(5)
+    p = synth.make_small_pair(31, n=700)
+    fx, ff, mx, mf = p.fixed.xyz.copy(), p.fixed.feat.copy(), p.moving.xyz.copy(), p.moving.feat.copy()
+    ell = 0.03
+    if case == "shuffled":                                           # no scan order: boxes are loose, nothing else changes
+        a, b = rng.permutation(fx.shape[0]), rng.permutation(mx.shape[0])
+        fx, ff, mx, mf = fx[a], ff[:, a], mx[b], mf[:, b]
+    elif case == "behind_camera":                                    # the whole scene pushed through z = 0
+        fx[:, 2] -= 1.2; mx[:, 2] -= 1.2
+        assert (fx[:, 2] < 0).any() and (fx[:, 2] > 0).any()
+    elif case == "tiny":
+        fx, ff, mx, mf = fx[:7], ff[:, :7], mx[:5], mf[:, :5]
+        mx[:] = fx[:5] + 0.002
+    elif case == "ragged_33":
+        fx, ff, mx, mf = fx[:97], ff[:, :97], mx[:33], mf[:, :33]
+        mx[:] = fx[:33] + np.float32(0.003)
+    elif case == "wide_ell":
+        ell = 0.15
+    tf = make_tf([0.2, 1, 0.1], 0.01, [0.004, -0.002, 0.003])
+    g = hiplib.Cvo(); g.set_pcd(fx, ff); g.set_pcd(mx, mf); g.set_state(np.eye(3), np.zeros(3), ell)
+    o = oracle.OracleCvo(); o.set_pcd(fx, ff); o.set_pcd(mx, mf); o.set_state(np.eye(3), np.zeros(3), ell)
+    for (sa, t, sb) in ((1, None, 0), (1, tf, 0), (0, None, 0), (1, None, 1), (0, tf, 1)):
+        rc, want = o.function_inner_product(sa, t, sb); assert rc == 0
+        got = g.function_inner_product(sa, t, sb)
+        assert got[1] == want[1], (case, sa, sb)
+        assert got[0] == pytest.approx(want[0], rel=2e-6), (case, sa, sb)
+        rc, Ho, inl_o, _ = o.se3_hessian(sa, t, sb); assert rc == 0
+        Hg, inl_g = g.se3_hessian(sa, t, sb)
+        assert inl_g == inl_o, (case, sa, sb)
+        np.testing.assert_allclose(Hg, Ho, rtol=1e-3, atol=1e-3 * max(np.abs(Ho).max(), 1e-30))
+    rc, so = o.compute_innerproduct(tf); assert rc == 0
+    sg = g.compute_innerproduct(tf)
+    assert [sg[k][1] for k in ("inn_pre", "inn_post", "inn_fixed_pcd", "inn_moving_pcd")] == [so[k][1] for k in ("inn_pre", "inn_post", "inn_fixed_pcd", "inn_moving_pcd")]
+    assert sg["inliers"] == so["inliers"]
+    g.close()
+
+
 def test_empty_overlap_scores(hiplib, oracle):
     # no pair within the radius: value 0, num forced to 1 (cvo.cpp:455-456), Hessian = identity (cvo.cpp:755)
     gd = load("small_pair_11.npz")
