@@ -163,6 +163,46 @@ def test_full_size_pair_fresh_vs_oracle(hiplib, oracle):
     g.close()
 
 
+def test_full_size_batch_properties_without_the_oracle(hiplib):
+    """BASELINE-size pairs (640x480, ~3 k points) through size-independent properties of the path: the known camera motion
+    is recovered, the result is frame-covariant (both clouds moved by S => S T S^-1), repeated launches and different
+    workgroup counts give the same bits."""
+    from cvo_slam_amd import synth
+    n = 8
+    pairs = [synth.make_pair(100 + i) for i in range(n)]
+    B = hiplib.CvoBatch(n)
+    for i, p in enumerate(pairs):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+    res = B.align(n)
+    for p, r in zip(pairs, res):
+        assert r["status"] == 0
+        re, te = rot_trans_err(r["transform"], p.true_transform)
+        re0, te0 = rot_trans_err(np.eye(3, 4), p.true_transform)
+        assert re < 2e-3 and te < 3e-3, (re, te)                                # ~0.05 deg, ~1 mm on these scenes
+        assert re < re0 / 5 and te < te0 / 5
+    # determinism: the same launch again, and with 2 and 4 cooperating workgroups per pair
+    for wgs in (1, 2, 4):
+        B.set_workgroups(wgs); B.reset_states()
+        again = B.align(n)
+        for r, r2 in zip(res, again):
+            np.testing.assert_array_equal(r["transform"], r2["transform"])
+            assert (r["iterations_run"], r["A_nonzero"]) == (r2["iterations_run"], r2["A_nonzero"])
+    B.close()
+    # covariance: a rigid change of the common frame
+    S = np.eye(4); S[:3] = make_tf([0.3, 1, 0.2], 0.2, [0.1, -0.05, 0.2])
+    B2 = hiplib.CvoBatch(n)
+    for i, p in enumerate(pairs):
+        fx = (p.fixed.xyz.astype(np.float64) @ S[:3, :3].T + S[:3, 3]).astype(np.float32)
+        mx = (p.moving.xyz.astype(np.float64) @ S[:3, :3].T + S[:3, 3]).astype(np.float32)
+        B2.set_pair(i, fx, p.fixed.feat, mx, p.moving.feat)
+    res2 = B2.align(n)
+    for r, r2 in zip(res, res2):
+        T = np.eye(4); T[:3] = r["transform"]
+        re, te = rot_trans_err(r2["transform"], (S @ T @ np.linalg.inv(S))[:3])
+        assert re < 5e-4 and te < 5e-4, (re, te)
+    B2.close()
+
+
 @pytest.mark.parametrize("changes", [
     dict(sp_thres=1.0e-3),                                   # wide radius: exponents beyond the range-reduction-free polynomial (general exp path)
     dict(sp_thres=9.0e-3, sigma=0.12),
