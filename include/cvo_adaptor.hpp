@@ -22,7 +22,7 @@
 
 #include <Eigen/Core>
 #include <Eigen/Geometry>
-#include <opencv2/core/mat.hpp>
+#include <opencv2/core.hpp>       // cv::Mat, cv::Point2f, cv::FileStorage
 
 #include "data_type.h"        // reference: cvo::frame, cvo::point_cloud, cvo::camera_info
 #ifdef CVO_ADAPTOR_CPU_PCD
@@ -91,7 +91,7 @@ public:
                     accum_transform = Eigen::Affine3f::Identity();   // cvo.hpp:142-144
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 
-    cvo(const std::string& calib_file) : ptr_fixed_fr(new frame) {     // cvo.cpp:18-71
+    cvo(const std::string& calib_file) : ptr_fixed_fr(new frame()) {   // value-initialised: frame::~frame() delete[]s its pyramid pointers (data_type.h:62-68)     // cvo.cpp:18-71
         cv::FileStorage fSettings(calib_file, cv::FileStorage::READ);
         cam_info.fx = fSettings["Camera.fx"]; cam_info.fy = fSettings["Camera.fy"];
         cam_info.cx = fSettings["Camera.cx"]; cam_info.cy = fSettings["Camera.cy"];
@@ -102,7 +102,7 @@ public:
 
     void set_pcd(const cv::Mat& RGB_img, const cv::Mat& dep_img) {      // cvo.cpp:345-386
         if (!init) { generate_and_upload(RGB_img, dep_img, ptr_fixed_fr.get(), CVO_SLOT_FIXED); sync(); return; }
-        ptr_moving_fr.reset(new frame);
+        ptr_moving_fr.reset(new frame());
         generate_and_upload(RGB_img, dep_img, ptr_moving_fr.get(), CVO_SLOT_MOVING);
     }
     void align() { if (cvo_align(h_) != CVO_OK) std::cerr << "cvo align: " << cvo_last_error() << "\n"; sync(); }   // cvo.cpp:763-821
