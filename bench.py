@@ -425,11 +425,15 @@ def main():
             "with_score_block": with_scores,
             "with_host_upload": with_upload,
             "valu": {"dense_pair_tests_per_s": flops_launch / 8.0 / (step_ms_rank * 1e-3),
+                     "algorithmic_flops_fraction": flops_launch / (step_ms_rank * 1e-3) / 157.3e12,
+                     "hbm_fraction_of_achievable": bytes_launch / (step_ms_rank * 1e-3) / 6.3e12,
                      "executed_wave_instructions_per_launch": valu_instr,
                      "issue_slots_used": (valu_instr * 4.0 / (256 * 4 * 2.4e9 * step_ms_rank * 1e-3)) if valu_instr else None,
                      "note": "issue_slots_used = VALU wave-instructions of one launch (SQ_INSTS_VALU, profiles/) x 4 cycles / (256 CUs x 4 SIMDs x 2.4 GHz x "
                              "time per step): the share of the chip's plain-f32 issue slots the job keeps busy.  dense_pair_tests_per_s counts the "
-                             "N*M tests per iteration the reference's radius search stands for; the kernel skips most of them (lists + box cull)"},
+                             "N*M tests per iteration the reference's radius search stands for; the kernel skips most of them (lists + box cull), so "
+                             "algorithmic_flops_fraction (SURVEY 8d: 8 flop per dense pair test / 157.3 TF) exceeds 1 -- it prices work that is not executed; "
+                             "hbm_fraction_of_achievable = algorithmic bytes per step / 6.3 TB/s (SURVEY 8d), whole GPU"},
         }
         if world == 1 and not args.no_latency_probe:
             out["latency"] = latency_probe(ca, pairs, local_rank)
