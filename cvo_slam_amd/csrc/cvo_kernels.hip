@@ -233,14 +233,16 @@ __device__ __forceinline__ double horner_step(double p, double x, double c) {
 // the same polynomial for PFN arguments at once, coefficient by coefficient: the PFN Horner chains are independent, and issued
 // side by side no v_fma_f64 waits for the one before it (evaluated one after the other, every step is a dependent
 // double-precision op behind a wait state)
-template <int PFN>
+template <int PFN, int DEG = 13>
 __device__ __forceinline__ void exp_poly13_n(const double (&x)[PFN], double (&p)[PFN]) {
-    const double cf[10] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0,
-                           1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0};
+    // 1/13!, 1/12!, ..., 1/3!; a DEG-term chain starts at 1/DEG!
+    const double cf[11] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
+                           1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0};
+    static_assert(DEG >= 4 && DEG <= 13, "degree");
 #pragma unroll
-    for (int u = 0; u < PFN; ++u) p[u] = 1.0 / 6227020800.0;                         // 1/13!
+    for (int u = 0; u < PFN; ++u) p[u] = cf[13 - DEG];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
+    for (int k = 14 - DEG; k < 11; ++k) {
 #pragma unroll
         for (int u = 0; u < PFN; ++u) p[u] = horner_step(p[u], x[u], cf[k]);
     }
@@ -323,16 +325,19 @@ __device__ __forceinline__ float se_kernel_value_ck(const float* xi, const float
 // se_kernel_value_flat for PFN entries of one row at once
 template <int PFN>
 __device__ __forceinline__ void se_kernel_values_flat(const float* xi, const float4 (&yj)[PFN], const float (&ck)[PFN], const bool (&active)[PFN], const Gates& G,
-                                                      float (&a_out)[PFN]) {
+                                                      float (&a_out)[PFN], float (&e_out)[PFN][3]) {
     double x[PFN], p[PFN]; bool pass[PFN];
 #pragma unroll
     for (int u = 0; u < PFN; ++u) {
         const float e0 = xi[0] - yj[u].x, e1 = xi[1] - yj[u].y, e2 = xi[2] - yj[u].z;
         float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;              // nanoflann.hpp:403-406
         pass[u] = active[u] & (d2 < G.d2_thres);
-        x[u] = fmax((double)(-d2) * G.inv_den_l, -0.25);
+        // inside the radius the exponent is in [-0.25, 0] (Gates::poly_ok): twelve terms leave 2.4e-18 of exp there.  Outside it
+        // the polynomial returns some finite or infinite number that `pass` throws away; no clamp needed
+        x[u] = (double)(-d2) * G.inv_den_l;
+        e_out[u][0] = e0; e_out[u][1] = e1; e_out[u][2] = e2;
     }
-    exp_poly13_n<PFN>(x, p);
+    exp_poly13_n<PFN, 12>(x, p);
 #pragma unroll
     for (int u = 0; u < PFN; ++u) {
         const float k = (float)((double)G.s2 * p[u]);
@@ -867,6 +872,24 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
     wcount += __popcll(mask);
 }
 
+// the same with e = x_i - y_j already at hand (the flat evaluation computed it for d2): y_j - x_i = -e exactly, so
+// sv - a*e has the bits of sv + a*(y_j - x_i)
+__device__ __forceinline__ void fold_entry_e(const float* xi, const float4 y4, const float (&e)[3], float a, unsigned tag, RowSums& rs, gv2u* sp, int& wcount, int lane) {
+    {
+        const float yv[3] = {y4.x, y4.y, y4.z};
+        float cr[3]; cross3(xi, yv, cr);                            // cvo.cpp:216
+        rs.sw[0] += a * cr[0]; rs.sw[1] += a * cr[1]; rs.sw[2] += a * cr[2];
+        rs.sv[0] -= a * e[0]; rs.sv[1] -= a * e[1]; rs.sv[2] -= a * e[2];     // cvo.cpp:217
+    }
+    const unsigned long long mask = __ballot(a > 0.f);
+    if (a > 0.f) {
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        v2u rec; rec.x = __float_as_uint(a); rec.y = tag;
+        sp[(unsigned)wcount + below] = rec;
+    }
+    wcount += __popcll(mask);
+}
+
 // every iteration but the first after a rebuild: entries {ck, j} stream in, PF per lane per step, the next step's in flight
 template <int YM, bool FLAT>
 __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
@@ -903,13 +926,17 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
                 yv4[u] = load_y<YM>(c, L, j);
                 ckv[u] = __uint_as_float(eq[u].x);
             }
-            if (FLAT) se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av);   // PF exp chains side by side
-            else {
+            if (FLAT) {
+                float ev[PF][3];
+                se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av, ev);   // PF exp chains side by side
+#pragma unroll
+                for (int u = 0; u < PF; ++u) fold_entry_e(xi, yv4[u], ev[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, wcount, lane);
+            } else {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) av[u] = actv[u] ? se_kernel_value_ck(xi, yv4[u], ckv[u], gates) : 0.f;
-            }
 #pragma unroll
-            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, wcount, lane);
+                for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, wcount, lane);
+            }
 #pragma unroll
             for (int u = 0; u < PF; ++u) eq[u] = en[u];
         }
@@ -980,13 +1007,17 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
                 ckv[u] = (d2c[u] < gates.d2c_thres) ? ckx : __builtin_nanf("");
                 if (actv[u]) { v2u e; e.x = __float_as_uint(ckv[u]); e.y = (unsigned)j0[u]; ep[(size_t)(n0 + u) * c.rows_pad] = e; }
             }
-            if (FLAT) se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av);
-            else {
+            if (FLAT) {
+                float ev[PF][3];
+                se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av, ev);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) fold_entry_e(xi, yv4[u], ev[u], av[u], stag | (unsigned)j0[u], rs, sp, wcount, lane);
+            } else {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) av[u] = actv[u] ? se_kernel_value_ck(xi, yv4[u], ckv[u], gates) : 0.f;
-            }
 #pragma unroll
-            for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (unsigned)j0[u], rs, sp, wcount, lane);
+                for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (unsigned)j0[u], rs, sp, wcount, lane);
+            }
 #pragma unroll
             for (int u = 0; u < PF; ++u) { j0[u] = j1[u]; j1[u] = j2[u]; g0[u] = g1[u]; }
         }
