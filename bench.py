@@ -192,8 +192,8 @@ def latency_probe(ca, pairs, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="frame pairs per GPU per step")
     ap.add_argument("--workgroups", type=int, default=1, help="workgroups per pair (0 = auto: lowest latency of one batch alone; 1 = highest throughput)")
     ap.add_argument("--streams", type=int, default=8, help="steps in flight (batch objects on separate HIP streams)")
