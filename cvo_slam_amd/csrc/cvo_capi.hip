@@ -728,7 +728,7 @@ int cvo_create(const cvo_params* p, int device, cvo_handle* out) {
     *out = nullptr;
     std::unique_ptr<cvo_handle_s> h(new cvo_handle_s());
     if (p) h->prm = *p; else cvo_default_params(&h->prm);
-    int rc = h->eng.init(device, h->prm); if (rc) return rc;
+    int rc = h->eng.init(device, h->prm); if (rc) { h->eng.destroy(); return rc; }   // whatever init had created before it failed
     h->fixed.reset(new Cloud());                                     // ptr_fixed_pcd(new point_cloud), cvo.cpp:30
     h->ell = h->prm.ell;
     const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -993,7 +993,7 @@ int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* 
     *out = nullptr;
     std::unique_ptr<cvo_batch_s> b(new cvo_batch_s());
     if (p) b->prm = *p; else cvo_default_params(&b->prm);
-    int rc = b->eng.init(device, b->prm); if (rc) return rc;
+    int rc = b->eng.init(device, b->prm); if (rc) { b->eng.destroy(); return rc; }
     b->max_pairs = max_pairs;
     b->fixed.resize(max_pairs); b->moving.resize(max_pairs);
     b->init_states.resize(max_pairs);
