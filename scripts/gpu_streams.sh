@@ -1,5 +1,7 @@
-for cfg in "8 8" "8 12" "16 12" "16 16" "24 24"; do
+#!/bin/bash
+# streams in flight x hardware queues (development aid)
+for rep in 1 2; do for cfg in "8 8" "16 8" "16 10" "16 12" "12 12"; do
   set -- $cfg
-  v=$(GPU_MAX_HW_QUEUES=$1 timeout -k 10 200 python bench.py --streams $2 --steps 128 --warmup 32 --no-cpu-baseline --no-latency-probe 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']), round(d['roofline']['kernel_ms'],2), round(d['roofline']['launches_side_by_side'],2))")
+  v=$(GPU_MAX_HW_QUEUES=$1 timeout -k 10 200 python bench.py --streams $2 --steps 256 --warmup 32 --no-cpu-baseline --no-latency-probe 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']), round(d['roofline']['kernel_ms'],2), round(d['roofline']['launches_side_by_side'],2))")
   echo "queues $1 streams $2: $v"
-done
+done; done

@@ -43,3 +43,47 @@ def test_replay_synthetic_sequence_from_disk(hiplib, tmp_path):
     poses_mem, _ = replay.replay_odometry(frames, synth.camera_tuple(cam))
     for a, b in zip(poses, poses_mem):
         np.testing.assert_array_equal(a, b)
+
+
+def test_full_size_tracker_sequence_from_images_vs_oracle(hiplib, oracle):
+    """SURVEY 8d's second scenario at full size, from the images: the LocalTracker call sequence (local_tracker.cpp:228-251,
+    356-431, 506) on 640x480 frames -- point clouds from the GPU generator, odometry object with warm start and carried ell
+    (Q1, Q2), keyframe object warm-started by reset_initial -- against the oracle fed with the oracle generator's clouds of
+    the same frames.  Every transform within the tolerance, every iteration count equal."""
+    from cvo_slam_amd import synth
+    frames, _ = synth.make_sequence(2, n_frames=5)
+    cam = synth.camera_tuple(synth.TUM1)
+
+    odo, kf = hiplib.Cvo(), hiplib.Cvo()
+    got = []
+    odo.set_pcd_images(*frames[0], cam); kf.set_pcd_images(*frames[0], cam)          # :228, :231
+    t = odo.match_odometry_images(*frames[1], cam); got.append((t, odo.get_iteration_number()))   # :233
+    odo.update_fixed_pcd()                                                           # :277
+    kf.first_frame = False; kf.reset_transform(np.asarray(t, np.float32))            # :330-333
+    for f in frames[2:]:
+        t = odo.match_odometry_images(*f, cam); got.append((t, odo.get_iteration_number()))       # :356
+        odo.update_fixed_pcd()                                                       # :403
+        kf.reset_initial(np.asarray(t, np.float32))                                  # :407
+        tk = kf.match_keyframe_images(*f, cam); got.append((tk, kf.get_iteration_number()))       # :415
+        kf.update_previous_pcd()                                                     # :506
+    n_pts = odo.get_fixed_and_moving_number()
+    odo.close(); kf.close()
+
+    clouds = [oracle.pcd_generate(b, d, cam) for (b, d) in frames]
+    assert (clouds[-2]["n"], clouds[-1]["n"]) == tuple(n_pts) and min(n_pts) > 2000   # counts as of the last set_pcd (cvo.cpp:370-371)
+    oo, ok = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8), oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8)
+    want = []
+    c = clouds[0]; oo.set_pcd(c["xyz"], c["feat"]); ok.set_pcd(c["xyz"], c["feat"])
+    c = clouds[1]; rc, t = oo.match(c["xyz"], c["feat"]); assert rc == 0; want.append((t, oo.get_state()["iter"]))
+    oo.update_fixed_pcd(); ok.reset_transform(t.astype(np.float32))
+    for c in clouds[2:]:
+        rc, t = oo.match(c["xyz"], c["feat"]); assert rc == 0; want.append((t, oo.get_state()["iter"]))
+        oo.update_fixed_pcd()
+        ok.reset_initial(t.astype(np.float32))
+        rc, tk = ok.match(c["xyz"], c["feat"]); assert rc == 0; want.append((tk, ok.get_state()["iter"]))
+        ok.update_previous_pcd()
+    assert len(got) == len(want) == 7
+    for k, ((tg, ig), (tw, iw)) in enumerate(zip(got, want)):
+        re, te = rot_trans_err(tg, tw)
+        assert re <= 1e-4 and te <= 1e-4, (k, re, te)
+        assert ig == iw, (k, ig, iw)
