@@ -87,3 +87,49 @@ def test_full_size_tracker_sequence_from_images_vs_oracle(hiplib, oracle):
         re, te = rot_trans_err(tg, tw)
         assert re <= 1e-4 and te <= 1e-4, (k, re, te)
         assert ig == iw, (k, ig, iw)
+
+
+def test_full_size_loop_closure_candidates_vs_oracle(hiplib, oracle):
+    """SURVEY 8d's loop-closure-like set at full size: motions up to 10 degrees / 15 cm, every candidate warm-started within
+    ~2 degrees / 3 cm of the truth through reset_initial (keyframe_graph.cpp:693-705), all aligned by one batch launch and
+    scored by one launch; poses, iteration counts, pair counts and the accept decision against single oracle objects."""
+    from cvo_slam_amd import synth
+    from helpers import make_tf
+    rng = np.random.default_rng(12)
+    n = 6
+    pairs = [synth.make_pair(300 + i, max_deg=10.0, max_trans=0.15) for i in range(n)]
+    lc_priors = []
+    for p in pairs:                                                  # prior = truth perturbed by <= 2 deg / 3 cm
+        d = np.eye(4); d[:3] = make_tf(rng.normal(size=3), np.deg2rad(rng.uniform(0.5, 2.0)), rng.normal(size=3) * 0.012)
+        T = np.eye(4); T[:3] = p.true_transform
+        lc_priors.append((T @ d)[:3].astype(np.float32))
+    lc_priors = np.stack(lc_priors)
+    priors = np.stack([np.eye(3, 4, dtype=np.float32)] * n)
+    B = hiplib.CvoBatch(n)
+    single = []
+    for i, p in enumerate(pairs):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+        o = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8)
+        o.reset_initial(lc_priors[i])
+        o.set_pcd(p.fixed.xyz, p.fixed.feat); o.set_pcd(p.moving.xyz, p.moving.feat)
+        st0 = o.get_state(); B.set_state(i, st0["R"], st0["T"], st0["ell"])
+        single.append(o)
+    res = B.align(n)
+    got = B.compute_innerproduct_lc(priors, lc_priors, lc_priors)
+    accepted = 0
+    for i, (o, r, g, p) in enumerate(zip(single, res, got, pairs)):
+        rc, _ = o.align(); assert rc == 0
+        st = o.get_state()
+        re, te = rot_trans_err(r["transform"], st["transform"])
+        assert re <= 1e-4 and te <= 1e-4, (i, re, te)
+        assert r["iter"] == st["iter"], (i, r["iter"], st["iter"])
+        rc, want = o.compute_innerproduct_lc(priors[i], lc_priors[i], lc_priors[i], st["transform"]); assert rc == 0
+        for key in ("inn_prior", "inn_lc_prior", "inn_lc_pre", "inn_lc_post", "inn_fixed_pcd", "inn_moving_pcd"):
+            assert g[key][1] == want[key][1], (i, key)
+            assert g[key][0] == pytest.approx(want[key][0], rel=1e-5), (i, key)
+        assert (g["inliers_svd"], g["inliers_pnpransac"]) == (want["inliers_svd"], want["inliers_pnpransac"])
+        re_t, te_t = rot_trans_err(r["transform"], p.true_transform)
+        assert re_t < 5e-3 and te_t < 1e-2, (i, re_t, te_t)           # the large motion is recovered from the prior
+        accepted += int(g["accept"])
+    assert accepted >= n - 1                                         # verified candidates pass the reference's rule (keyframe_graph.cpp:711-712)
+    B.close()
