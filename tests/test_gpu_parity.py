@@ -525,6 +525,30 @@ def test_batch_matches_single_objects_and_warm_start(hiplib, oracle):
     B.close()
 
 
+@pytest.mark.parametrize("wgs", [1, 2])
+def test_batch_larger_than_the_gpu(hiplib, oracle, wgs):
+    """More pairs than resident workgroup slots (256 CUs / workgroups per pair): every persistent workgroup (group) aligns
+    several pairs one after the other and must start each from a clean state.  300 small pairs of varying size, each against
+    its own oracle object."""
+    from cvo_slam_amd import synth
+    n = 300
+    sizes = [64 + (37 * i) % 90 for i in range(n)]
+    pairs = [synth.make_small_pair(5000 + i, n=sizes[i]) for i in range(n)]
+    B = hiplib.CvoBatch(n); B.set_workgroups(wgs)
+    for i, p in enumerate(pairs):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+    res = B.align(n)
+    for i, (p, r) in enumerate(zip(pairs, res)):
+        assert r["status"] == 0, i
+        o = oracle.OracleCvo(); o.set_pcd(p.fixed.xyz, p.fixed.feat); o.set_pcd(p.moving.xyz, p.moving.feat)
+        rc, _ = o.align(); assert rc == 0
+        st = o.get_state()
+        re, te = rot_trans_err(r["transform"], st["transform"])
+        assert re <= 1e-6 and te <= 1e-6, (i, re, te)
+        assert (r["iter"], r["A_nonzero"]) == (st["iter"], st["A_nonzero"]), i
+    B.close()
+
+
 def test_batch_loop_closure_verification_block(hiplib, oracle):
     """keyframe_graph.cpp:693-717 for a batch of candidates: fresh objects warm-started by reset_initial(lc_prior), aligned in
     one launch, then every pair's compute_innerproduct_lc block (6 inner products + 2 Hessians) in ONE score launch, with the
