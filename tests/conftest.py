@@ -27,5 +27,8 @@ def oracle():
 def hiplib():
     """The product library; built in-tree, loaded through the C ABI.  GPU tests fail loudly if it is absent."""
     import cvo_slam_amd as ca
+    if not os.path.exists(ca.lib_path()):          # fresh checkout: compile it (hipcc cross-compiles gfx950 without a GPU)
+        from cvo_slam_amd import build
+        build.build()
     ca.load_library()
     return ca
