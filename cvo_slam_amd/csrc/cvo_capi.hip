@@ -175,9 +175,17 @@ struct Engine {
         if (!xyz || !feat) return fail(CVO_ERR_INVALID, "null cloud pointer");
         const size_t bytes = (size_t)n * REC * sizeof(float);
         int rc = c.buf.ensure(bytes); if (rc) return rc;
-        rc = h_stage.ensure(bytes); if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(stream));                       // staging buffer may still feed an earlier copy
-        float* s = static_cast<float*>(h_stage.p);
+        // pinned staging ring: clouds are packed one behind the other and the stream is only waited for when the ring wraps,
+        // so handing over a whole batch (64 pairs = 12.6 MB) costs one wait, not one per cloud
+        const size_t want = std::max(bytes, (size_t)16 << 20);
+        if (h_stage.bytes < want) {
+            HIP_TRY(hipStreamSynchronize(stream));                   // the old buffer may still feed a copy
+            rc = h_stage.ensure(want); if (rc) return rc;
+            stage_used = 0;
+        }
+        if (stage_used + bytes > h_stage.bytes) { HIP_TRY(hipStreamSynchronize(stream)); stage_used = 0; }
+        float* s = reinterpret_cast<float*>(static_cast<unsigned char*>(h_stage.p) + stage_used);
+        stage_used += (bytes + 255) & ~(size_t)255;
         for (int i = 0; i < n; ++i) {                                // plane 0: {x, y, z, f0}; plane 1: {f1..f4}
             float* lo = s + lo_off(i); float* hi = s + hi_off(n, i);
             lo[0] = xyz[(size_t)i * 3 + 0]; lo[1] = xyz[(size_t)i * 3 + 1]; lo[2] = xyz[(size_t)i * 3 + 2];
@@ -225,8 +233,9 @@ struct Engine {
         if ((rc = d_map.ensure(n))) return rc;
         if ((rc = d_counts.ensure(sizeof(int) * 8))) return rc;
         if ((rc = h_counts.ensure(sizeof(int) * 8))) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));                          // nothing reads the staging ring any more
         if ((rc = h_stage.ensure(5 * n))) return rc;
-        HIP_TRY(hipStreamSynchronize(stream));
+        stage_used = (5 * n + 255) & ~(size_t)255;                      // the images are staged at the start of the ring
         if (pattern_len != (int)n) {                                    // the byte pattern only depends on w*h: made once
             if ((rc = d_pattern.ensure(n))) return rc;
             std::vector<unsigned char> pat(n);
@@ -458,6 +467,7 @@ struct Engine {
     DevBuf d_scoredescs; PinBuf h_scoredescs;
     std::vector<unsigned char> scoredescs_uploaded;
     hipStream_t score_stream = nullptr; int score_pending = 0;
+    size_t stage_used = 0;            // bytes of the pinned staging ring handed to copies that may still be in flight
     bool uploads_pending = false;     // clouds were written on `stream`: a launch on another stream waits for them once
     int settle_uploads(hipStream_t s) {
         if (uploads_pending && s != stream) HIP_TRY(hipStreamSynchronize(stream));
