@@ -898,6 +898,15 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
     const bool x_lds = sh->x_lds != 0;
     int wcount = 0;
     const int nb = sh->wnb[wave];
+    const unsigned rp = (unsigned)c.rows_pad, estep = PF * rp;
+    // the first entries of a block are fetched while the block before it is walked: in the late iterations a row holds only a
+    // handful of entries, and a block would otherwise start with an exposed memory round trip
+    v2u ehead[PF];
+    if (nb > 0) {
+        const gv2u* eb0 = uni_ptr(c.ent + wave_block(0, wave, nwaves) * 64);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) ehead[u] = eb0[(unsigned)lane + (unsigned)u * rp];
+    }
     for (int bi = 0; bi < nb; ++bi) {
         const int slot = wave_block(bi, wave, nwaves) * 64 + lane;
         const int len = L.lenS[slot];
@@ -907,12 +916,16 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         float xi[3]; load_x(c, L, x_lds, slot, xi);
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
         const gv2u* eb = uni_ptr(c.ent + (slot - lane));             // scalar base of the block's entries + 32-bit lane offsets
-        const unsigned rp = (unsigned)c.rows_pad, estep = PF * rp;
         unsigned eo = (unsigned)lane;
         const unsigned stag = (unsigned)slot << 16;
         v2u eq[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) eq[u] = eb[eo + (unsigned)u * rp];
+        for (int u = 0; u < PF; ++u) eq[u] = ehead[u];
+        if (bi + 1 < nb) {
+            const gv2u* eb1 = uni_ptr(c.ent + wave_block(bi + 1, wave, nwaves) * 64);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) ehead[u] = eb1[(unsigned)lane + (unsigned)u * rp];
+        }
         for (int n0 = 0; n0 < lw; n0 += PF) {
             if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
             v2u en[PF];
