@@ -13,9 +13,10 @@ for rep in range(2):
     h.set_pcd(fx, ff); h.set_pcd(mx, mf)
     out = h.align(trace_cap=128)
 rows = out
-print("k ell cand nnz | cull cand ls epi (us)")
+print("k ell cand nnz | lists cand ls epi | cand: prologue rows reduce | ls: walk reduce | epi: scalar transform (us)")
 tot = np.zeros(4)
 for k, r in enumerate(rows):
     t = r["BCDE"] / 100.0; tot += t
-    print(k, round(float(r["ell"]), 2), r["candidates"], r["nnz"], "|", *(round(float(x), 1) for x in t))
+    sub = [float(x) / 100.0 for x in list(r["omega"]) + list(r["v"]) + [r["step"]]]
+    print(k, round(float(r["ell"]), 2), r["candidates"], r["nnz"], "|", *(round(float(x), 1) for x in t), "|", *(round(x, 1) for x in sub[:3]), "|", *(round(x, 1) for x in sub[3:5]), "|", *(round(x, 1) for x in sub[5:]))
 print("totals us", tot.round(0), "sum", tot.sum().round(0))
