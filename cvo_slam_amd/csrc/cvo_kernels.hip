@@ -85,6 +85,9 @@ struct __attribute__((aligned(16))) Shared {
     int x_lds;             // the fixed points, by slot, sit in the (otherwise idle) cull tile: lx/ly/lz[slot]
     unsigned launch_tag;   // high 16 bits of every exchange tag: this launch's sequence number (granules of earlier launches never match)
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
+#ifdef CVO_KTRACE
+    unsigned long long ksub[4];  // experiment builds: line-search walk, line-search reduction, epilogue scalar part, epilogue transform (ticks, this iteration)
+#endif
     float omega[3];        // this iteration's twist (f32, cvo.cpp:234-235)
     float v[3];
     float dist;
@@ -1179,6 +1182,9 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
     for (int q = 0; q < 3; ++q) { omega[q] = sh->omega[q]; v[q] = sh->v[q]; }
     const LsConsts ls = make_ls(omega, v, sh->ell);
     double acc4[4] = {0, 0, 0, 0};
+#ifdef CVO_KTRACE
+    const unsigned long long kt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (!sh->dense_mode) {
         // every wave walks the nonzeros it compacted itself: the candidate phase deals the rows so that the waves' shares are
         // near equal, and a wave's segment is one contiguous run
@@ -1216,8 +1222,14 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
             acc4[0] += Bi; acc4[1] += Ci; acc4[2] += Di; acc4[3] += Ei;
         }
     }
+#ifdef CVO_KTRACE
+    const unsigned long long kt1 = __builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();
     block_reduce<4>(acc4, sh, tid, nwaves);
+#ifdef CVO_KTRACE
+    if (tid == 0) { sh->ksub[0] = kt1 - kt0; sh->ksub[1] = __builtin_amdgcn_s_memrealtime() - kt1; }
+#endif
     if (G > 1) {
         if (tid < 64) { if (!group_exchange<4>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 2u), lane)) sh->status = 6; }
         __syncthreads();
@@ -1236,6 +1248,9 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 #pragma unroll
         for (int u = 0; u < PRE_T; ++u) { pre[u] = (j < c.nm) ? ld4(c.moving + lo_off(j)) : make_float4(0.f, 0.f, 0.f, 0.f); j += blockDim.x; }
     }
+#ifdef CVO_KTRACE
+    const unsigned long long ke0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) {
         const DevParams& P = sh->P;
         const double B = sh->vals[0], C = sh->vals[1], Dd = sh->vals[2], E = sh->vals[3];
@@ -1279,9 +1294,15 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         }
     }
     __syncthreads();
+#ifdef CVO_KTRACE
+    const unsigned long long ke1 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (!sh->stop && k + 1 < max_iter) {                             // T of iteration k+1 (cvo.cpp:770-771)
         if (y_lds == 1) transform_body_t<1>(c, L, sh, pre, true); else transform_large(Dp, g, G, tgeo, y_lds);
     }
+#ifdef CVO_KTRACE
+    if (threadIdx.x == 0) { sh->ksub[2] = ke1 - ke0; sh->ksub[3] = __builtin_amdgcn_s_memrealtime() - ke1; }
+#endif
 }
 
 __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
@@ -1314,7 +1335,7 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
         unsigned long long ticks[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
 #ifdef CVO_KTRACE
-        unsigned long long kt_prev[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long kt_prev[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ksub_prev[4] = {0, 0, 0, 0};
 #endif
         const unsigned long long clk_t0 = t_prev, clk_c0 = __builtin_amdgcn_s_memtime();
 #define CVO_PHASE(idx) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); ticks[idx] += t_now - t_prev; t_prev = t_now; } while (0)
@@ -1346,6 +1367,10 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
             if (tid == 0 && g == 0 && Dp->trace && k < Dp->trace_cap) {
                 TraceRow& tr = Dp->trace[k];
                 tr.B = (double)(ticks[0] - kt_prev[0]); tr.C = (double)(ticks[1] - kt_prev[1]); tr.D = (double)(ticks[3] - kt_prev[3]); tr.E = (double)(ticks[5] - kt_prev[5]);
+                // omega = candidate phase (prologue, row walk, wait + reduction), v = line-search walk, its reduction, epilogue scalar part; step = fused transform
+                tr.omega[0] = (float)(sh->sub[0] - ksub_prev[0]); tr.omega[1] = (float)(sh->sub[1] - ksub_prev[1]); tr.omega[2] = (float)(sh->sub[2] - ksub_prev[2]);
+                tr.v[0] = (float)sh->ksub[0]; tr.v[1] = (float)sh->ksub[1]; tr.v[2] = (float)sh->ksub[2]; tr.step = (float)sh->ksub[3];
+                for (int q = 0; q < 4; ++q) ksub_prev[q] = sh->sub[q];
                 for (int q = 0; q < 10; ++q) kt_prev[q] = ticks[q];
             }
 #endif
