@@ -31,6 +31,11 @@ for case in range(N):
         g = ca.Cvo(); g.set_workgroups(wgs); g.set_pcd(*fixed); g.set_pcd(*moving); gtr = g.align(trace_cap=3000)
         re, te = rot_trans_err(g.transform, ost["transform"])
         ok = re <= 1e-6 and te <= 1e-6 and g.get_iteration_number() == ost["iter"] and g.get_A_nonzero() == ost["A_nonzero"] and [r["nnz"] for r in gtr] == [r["nnz"] for r in otr]
+        # the score block at the ell the alignment left behind (Q1): pair counts exact, sums to f32 rounding
+        rc2, so = o.compute_innerproduct(ost["transform"]); sg = g.compute_innerproduct(ost["transform"])
+        for key in ("inn_pre", "inn_post", "inn_fixed_pcd", "inn_moving_pcd"):
+            ok = ok and sg[key][1] == so[key][1] and abs(sg[key][0] - so[key][0]) <= 3e-6 * abs(so[key][0]) + 1e-12
+        ok = ok and sg["inliers"] == so["inliers"]
         g.close()
     except Exception as e:   # noqa: BLE001
         ok = False; re = te = float("nan"); print("EXC", repr(e))
