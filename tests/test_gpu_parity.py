@@ -678,3 +678,16 @@ def test_batch_results_to_device_records(hiplib):
     table = shard.gather_results(out, 3, 1)
     assert table.shape == (3, shard.RESULT_FLOATS)
     B.close()
+
+
+def test_randomized_sweep_against_the_oracle(hiplib):
+    """scripts/gpu_stress.py: random small clouds (64 ... 3072 points, ragged sizes), workgroup counts 1 ... 32, cull tiles,
+    LDS layouts, list skins and capacities -- pose, iteration count, nonzeros of every iteration and the score block of each
+    case against the oracle.  40 cases here; the round ran ~1000 with other seeds."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CASES="40", SEED="77")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_stress.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "40 / 40 cases identical to the oracle" in r.stdout
