@@ -83,6 +83,7 @@ struct __attribute__((aligned(16))) Shared {
     int rows_cap;          // entries of the three row/slot tables in LDS (the workgroup's rows, padded)
     int y_cap;             // points the LDS-resident moving cloud has room for (stride of the SoA planes)
     int x_lds;             // the fixed points, by slot, sit in the (otherwise idle) cull tile: lx/ly/lz[slot]
+    int ctx_rows_per, ctx_nrows;   // this workgroup's share of the current pair's rows (pair_rows)
     unsigned launch_tag;   // high 16 bits of every exchange tag: this launch's sequence number (granules of earlier launches never match)
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
 #ifdef CVO_KTRACE
@@ -522,15 +523,21 @@ struct Ctx {
     gu16* jT; gv2u* ent; gu64* xch;
     size_t fbase;
 };
+__device__ __forceinline__ void pair_rows(int nf, int g, int G, int& rows_per, int& nrows) {
+    const int nblocks = (nf + ROW_DEAL - 1) / ROW_DEAL;
+    rows_per = ((nblocks + G - 1) / G) * ROW_DEAL;                  // the most rows any workgroup of the pair owns
+    const int mine = (g < nblocks) ? (nblocks - g + G - 1) / G : 0; // blocks g, g + G, g + 2G, ...; only the cloud's last block may be short
+    nrows = mine * ROW_DEAL - ((mine > 0 && (nblocks - 1) % G == g) ? nblocks * ROW_DEAL - nf : 0);
+}
 __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     const PairDesc& D = *Dp;
     Ctx c;
     c.g = g; c.G = G;
     c.nf = D.nf; c.nm = D.nm; c.nm_pad = D.nm_pad; c.rows_pad = D.rows_pad; c.capn = D.capn;
-    const int nblocks = (c.nf + ROW_DEAL - 1) / ROW_DEAL;
-    c.rows_per = ((nblocks + G - 1) / G) * ROW_DEAL;                // the most rows any workgroup of the pair owns
-    const int mine = (g < nblocks) ? (nblocks - g + G - 1) / G : 0; // blocks g, g + G, g + 2G, ...; only the cloud's last block may be short
-    c.nrows = mine * ROW_DEAL - ((mine > 0 && (nblocks - 1) % G == g) ? nblocks * ROW_DEAL - c.nf : 0);
+    // rows_per / nrows of this workgroup: worked out once per pair (pair_rows: three divisions by G) and kept in Shared -- every
+    // phase builds its own Ctx
+    const Shared* shc = reinterpret_cast<const Shared*>(cvo_smem);
+    c.rows_per = shc->ctx_rows_per; c.nrows = shc->ctx_nrows;
     c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
     c.ybuf = GF4{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
     c.surv = (gv2u*)D.surv;
@@ -1324,6 +1331,7 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
         }
         if (tid == 32) {
             const PairState* st = Dp->state_in;
+            int rp, nr; pair_rows(nf, g, G, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
             sh->stop = 0; sh->status = 0; sh->iter_at_break = st->iter; sh->nnz = 0; sh->cand = 0;
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
             sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
