@@ -419,6 +419,8 @@ def main():
                          "traffic": traffic, "kernel": "cvo_align_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "launches_side_by_side": overlap, "achieved_all_launches": achieved_gbs * overlap,
                          "frac_all_launches": achieved_gbs * overlap / HBM_PEAK_GBS,
+                         "profile": "profiles/r01_j_kernel_stats.csv: rocprofv3 --kernel-trace --stats of this command with --no-latency-probe (only "
+                                    "launches of the timed regime): 11.90 ms average over 297 launches; profiles/README.md indexes the rest",
                          "note": "achieved = algorithmic bytes of ONE launch / its own HIP-event duration; a launch holds 64 of 256 CUs and "
                                  "launches_side_by_side of them run at once, achieved_all_launches is the whole GPU's rate.  The path is "
                                  "latency/VALU bound, not HBM bound (SURVEY 8d): see valu and DESIGN.md"},
