@@ -6,9 +6,10 @@
  * (thirdparty/cvo/include/cvo.hpp:82-282) IS the boundary that local_tracker /
  * keyframe_graph link against.  Each entry point below replaces one member of
  * that class (cited per function); a header-only `cvo::cvo` adaptor with the
- * reference's exact signatures forwards to them.  Images never
- * cross this ABI: the reference's pcd_generator stays on the host side of the
- * adaptor and hands the selected cloud over as plain arrays.
+ * reference's exact signatures forwards to them.  A point cloud
+ * enters either as plain arrays (cvo_set_pcd: the reference's pcd_generator stays
+ * on the host side of the adaptor) or as the RGB and depth images themselves
+ * (cvo_set_pcd_images: the generator runs on the GPU, the cloud never leaves HBM).
  *
  * Conventions
  *   - plain pointers and sizes only; all pointers are HOST pointers unless the
