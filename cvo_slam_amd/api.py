@@ -77,13 +77,15 @@ ABI_SYMBOLS = [
     "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds", "cvo_batch_compute_innerproduct_lc",
     "cvo_set_pcd_images", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
+    "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
 ]
 
 _lib = None
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, "libcvo_hip.so")
+    # CVO_HIP_LIB: experiment builds of the same ABI (scripts/gpu_*.sh); products leave it unset
+    return os.environ.get("CVO_HIP_LIB") or os.path.join(HERE, "libcvo_hip.so")
 
 
 def load_library():
@@ -147,8 +149,34 @@ def load_library():
     L.cvo_batch_enqueue_innerproduct.argtypes = [vp, C.c_int]
     L.cvo_batch_innerproduct_results.argtypes = [vp, C.c_int, C.POINTER(TrackScores)]
     L.cvo_batch_compute_innerproduct.argtypes = [vp, C.c_int, C.POINTER(TrackScores)]
+    for name in ("cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3"):
+        getattr(L, name).argtypes = [C.c_int, C.c_int, fp, fp]
     _lib = L
     return L
+
+
+def selftest_cubic_step(coef_minstep, device: int = 0):
+    """cubic_step on the device for n x {c3, c2, c1, c0, min_step} (cvo.cpp:76-92,317-333)."""
+    a = np.ascontiguousarray(coef_minstep, np.float32).reshape(-1, 5); out = np.zeros(a.shape[0], np.float32)
+    fp = C.POINTER(C.c_float)
+    _check(load_library().cvo_selftest_cubic_step(device, a.shape[0], a.ctypes.data_as(fp), out.ctypes.data_as(fp)))
+    return out
+
+
+def selftest_exp_sek3(omega_v_dt, device: int = 0):
+    """Exp_SEK3 on the device for n x {omega, v, dt} (LieGroup.cpp:159-186): (n,3,3) dR and (n,3) dT."""
+    a = np.ascontiguousarray(omega_v_dt, np.float32).reshape(-1, 7); out = np.zeros((a.shape[0], 12), np.float32)
+    fp = C.POINTER(C.c_float)
+    _check(load_library().cvo_selftest_exp_sek3(device, a.shape[0], a.ctypes.data_as(fp), out.ctypes.data_as(fp)))
+    return out[:, :9].reshape(-1, 3, 3), out[:, 9:]
+
+
+def selftest_dist_se3(dR_dT, device: int = 0):
+    """dist_se3 on the device for n x {dR row-major, dT} (cvo.cpp:94-104)."""
+    a = np.ascontiguousarray(dR_dT, np.float32).reshape(-1, 12); out = np.zeros(a.shape[0], np.float32)
+    fp = C.POINTER(C.c_float)
+    _check(load_library().cvo_selftest_dist_se3(device, a.shape[0], a.ctypes.data_as(fp), out.ctypes.data_as(fp)))
+    return out
 
 
 def _check(rc: int):

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["cvo_kernels.hip", "cvo_score_kernels.hip", "cvo_pcd_kernels.hip", "cvo_capi.hip", "cvo_hip.hpp"]
+SOURCES = ["cvo_kernels.hip", "cvo_score_kernels.hip", "cvo_pcd_kernels.hip", "cvo_selftest.hip", "cvo_capi.hip", "cvo_hip.hpp"]
 HEADERS = ["cvo_device.h", "cvo_math.hpp", os.path.join("..", "..", "include", "cvo_hip.h")]
 
 

@@ -42,6 +42,7 @@ int score_row_blocks(int na);
 int score_groups(int n);
 size_t score_box_bytes(int n);
 hipError_t launch_cloud_boxes(const float* rec, int n, float* gbox, hipStream_t stream);
+hipError_t launch_selftest(int kind, const float* in, float* out, int n, hipStream_t s);
 hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
                         double* out_pinned, hipStream_t stream);
 }  // namespace cvohip
@@ -998,6 +999,26 @@ int cvo_set_workgroups(cvo_handle h, int workgroups_per_pair) {
 }
 
 // ------------------------------------------------------------------ batches
+namespace {
+int selftest(int device, int kind, int n, const float* in, int in_w, float* out, int out_w) {
+    int rc = check_device(device, nullptr); if (rc) return rc;
+    if (n <= 0 || !in || !out) return fail(CVO_ERR_INVALID, "bad self-test arguments");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf din, dout;
+    if ((rc = din.ensure(sizeof(float) * (size_t)n * in_w)) || (rc = dout.ensure(sizeof(float) * (size_t)n * out_w))) { din.release(); dout.release(); return rc; }
+    hipError_t e = hipMemcpy(din.p, in, sizeof(float) * (size_t)n * in_w, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_selftest(kind, static_cast<const float*>(din.p), static_cast<float*>(dout.p), n, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, sizeof(float) * (size_t)n * out_w, hipMemcpyDeviceToHost);
+    din.release(); dout.release();
+    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("self-test: ") + hipGetErrorString(e));
+    return CVO_OK;
+}
+}  // namespace
+int cvo_selftest_cubic_step(int device, int n, const float* coef_minstep, float* step_out) { return selftest(device, 0, n, coef_minstep, 5, step_out, 1); }
+int cvo_selftest_exp_sek3(int device, int n, const float* omega_v_dt, float* dR_dT_out) { return selftest(device, 1, n, omega_v_dt, 7, dR_dT_out, 12); }
+int cvo_selftest_dist_se3(int device, int n, const float* dR_dT, float* dist_out) { return selftest(device, 2, n, dR_dT, 12, dist_out, 1); }
+
 int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* out) {
     if (!out || max_pairs <= 0) return fail(CVO_ERR_INVALID, "bad argument");
     *out = nullptr;

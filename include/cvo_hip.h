@@ -168,6 +168,17 @@ int cvo_set_state(cvo_handle h, const float R[9], const float T[3], float ell);
 /* number of workgroups that cooperate on this handle's alignment (latency knob; 0 = auto) */
 int cvo_set_workgroups(cvo_handle h, int workgroups_per_pair);
 
+/* ---- device self-test of the scalar closed forms the align kernel's epilogue runs once per iteration.  Each call
+ * evaluates n cases on the device, one lane per case, with the very device functions the kernel calls:
+ *   cubic_step: poly_solver + root selection + clamp, cvo.cpp:76-92,317-333   in: n x {c3, c2, c1, c0, min_step}  out: n steps
+ *   exp_sek3:   Exp_SEK3 (K = 1) incl. the theta < 1e-6 branch, LieGroup.cpp:159-186   in: n x {omega[3], v[3], dt}
+ *               out: n x {dR[9] row-major, dT[3]}
+ *   dist_se3:   || logm([dR dT; 0 1]) ||_F, cvo.cpp:94-104   in: n x {dR[9], dT[3]}   out: n distances
+ * Host pointers.  For known-answer tests that do not involve the CPU oracle (tests/test_gpu_closed_forms.py). */
+int cvo_selftest_cubic_step(int device, int n, const float* coef_minstep, float* step_out);
+int cvo_selftest_exp_sek3(int device, int n, const float* omega_v_dt, float* dR_dT_out);
+int cvo_selftest_dist_se3(int device, int n, const float* dR_dT, float* dist_out);
+
 /* ======================= batched alignment (independent frame pairs) ===========
  * keyframe<->keyframe loop-closure candidates (keyframe_graph.cpp:622-731) and
  * offline batches are independent cvo::cvo objects; a batch runs all of them in

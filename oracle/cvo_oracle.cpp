@@ -28,6 +28,7 @@
  * Build: -O2 -ffp-contract=off (no FMA contraction), see oracle/Makefile.
  * ========================================================================== */
 #include "cvo_oracle.h"
+#include "ref_noise.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -36,6 +37,7 @@
 #include <limits>
 #include <memory>
 #include <numeric>
+#include <random>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -254,6 +256,8 @@ struct orc_cvo {
     std::vector<int> A_rowptr, A_col; std::vector<float> A_val;   // Eigen::SparseMatrix<float,RowMajor>
     double last_BCDE[4] = {0, 0, 0, 0};
     int search_mode = ORC_SEARCH_BRUTE, threads = 1;
+    int variant = 0;                               // ORC_VAR_* (reference-noise variants, cvo_oracle.h)
+    unsigned long long shuffle_seed = 0, shuffle_calls = 0;
 };
 
 namespace {
@@ -325,6 +329,29 @@ void compute_flow(orc_cvo* o) {
     const float inv_c = 1 / o->p.c, inv_d = 1 / o->p.d;                           // `1/c`, `1/d` are float
     double dw[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
     long nnz = 0;
+    if (o->variant & ORC_VAR_SHUFFLE) {
+        // the same per-row f32 sums, added across rows in a seeded random order (cvo.cpp:226-230 runs under a spin
+        // mutex in whatever order the TBB workers arrive)
+        std::vector<float> rw((size_t)N * 3), rv((size_t)N * 3);
+        for (int i = 0; i < N; ++i) {
+            const float* xi = &X.xyz[(size_t)i * 3];
+            float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
+            for (int e = o->A_rowptr[i]; e < o->A_rowptr[i + 1]; ++e) {
+                const float* yj = &o->cloud_y[(size_t)o->A_col[e] * 3];
+                const float a = o->A_val[e];
+                float cr[3]; cross3(xi, yj, cr);
+                for (int k = 0; k < 3; ++k) { sw[k] += a * cr[k]; sv[k] += a * (yj[k] - xi[k]); }
+            }
+            for (int k = 0; k < 3; ++k) { rw[(size_t)i * 3 + k] = inv_c * sw[k]; rv[(size_t)i * 3 + k] = inv_d * sv[k]; }
+        }
+        std::vector<int> perm(N); std::iota(perm.begin(), perm.end(), 0);
+        std::mt19937_64 rng(o->shuffle_seed + 0x9E3779B97F4A7C15ull * (++o->shuffle_calls));
+        std::shuffle(perm.begin(), perm.end(), rng);
+        for (int i : perm) for (int k = 0; k < 3; ++k) { dw[k] += (double)rw[(size_t)i * 3 + k]; dv[k] += (double)rv[(size_t)i * 3 + k]; }
+        for (int k = 0; k < 3; ++k) { o->omega[k] = (float)dw[k]; o->v[k] = (float)dv[k]; }
+        o->A_nonzero = o->A_rowptr[N];
+        return;
+    }
 #pragma omp parallel num_threads(o->threads)
     {
         double lw[3] = {0, 0, 0}, lv[3] = {0, 0, 0}; long ln = 0;
@@ -461,7 +488,9 @@ void compute_step_size(orc_cvo* o) {
     const float s_gamma = -temp_coef;
     const float s_delta = (float)(2.0 * temp_coef);
     double B = 0, C = 0, D = 0, E = 0;
-#pragma omp parallel num_threads(o->threads)
+    const bool shuffled = (o->variant & ORC_VAR_SHUFFLE) != 0;
+    std::vector<double> rowBCDE(shuffled ? (size_t)N * 4 : 0);
+#pragma omp parallel num_threads(shuffled ? 1 : o->threads)
     {
         double lB = 0, lC = 0, lD = 0, lE = 0;
 #pragma omp for schedule(static)
@@ -486,15 +515,22 @@ void compute_step_size(orc_cvo* o) {
                 Ei += double(A_ij * (epsil + beta * delta + 1 / 2.0 * beta * beta * gamma                                  // cvo.cpp:304-305
                                      + 1 / 2.0 * gamma * gamma + 1 / 24.0 * beta * beta * beta * beta));
             }
-            lB += Bi; lC += Ci; lD += Di; lE += Ei;
+            if (shuffled) { rowBCDE[(size_t)i * 4 + 0] = Bi; rowBCDE[(size_t)i * 4 + 1] = Ci; rowBCDE[(size_t)i * 4 + 2] = Di; rowBCDE[(size_t)i * 4 + 3] = Ei; }
+            else { lB += Bi; lC += Ci; lD += Di; lE += Ei; }
         }
 #pragma omp critical
         { B += lB; C += lC; D += lD; E += lE; }
     }
+    if (shuffled) {                                                               // cvo.cpp:309-314 in a seeded random row order
+        std::vector<int> perm(N); std::iota(perm.begin(), perm.end(), 0);
+        std::mt19937_64 rng(o->shuffle_seed + 0xD1B54A32D192ED03ull * (++o->shuffle_calls));
+        std::shuffle(perm.begin(), perm.end(), rng);
+        for (int i : perm) { B += rowBCDE[(size_t)i * 4 + 0]; C += rowBCDE[(size_t)i * 4 + 1]; D += rowBCDE[(size_t)i * 4 + 2]; E += rowBCDE[(size_t)i * 4 + 3]; }
+    }
     o->last_BCDE[0] = B; o->last_BCDE[1] = C; o->last_BCDE[2] = D; o->last_BCDE[3] = E;
     // p_coef << 4.0*float(E), 3.0*float(D), 2.0*float(C), float(B);   cvo.cpp:318
     const float c3 = (float)(4.0 * float(E)), c2 = (float)(3.0 * float(D)), c1 = (float)(2.0 * float(C)), c0 = float(B);
-    o->step = orc_cubic_step(c3, c2, c1, c0, o->p.min_step);
+    o->step = (o->variant & ORC_VAR_F32_ROOTS) ? orc_cubic_step_f32eig(c3, c2, c1, c0, o->p.min_step) : orc_cubic_step(c3, c2, c1, c0, o->p.min_step);
 }
 
 }  // namespace
@@ -548,6 +584,56 @@ extern "C" float orc_dist_se3(const float dR[9], const float dT[3]) {
     return (float)std::sqrt(2.0 * theta * theta + u2);
 }
 
+// ---- reference-noise variants (cvo_oracle.h) -------------------------------------------------
+// poly_solver + root selection as the reference runs them: f32 companion matrix, f32 eigenvalues, imag()==0 (cvo.cpp:76-92,324-330)
+extern "C" float orc_cubic_step_f32eig(float c3, float c2, float c1, float c0, float min_step) {
+    refnoise::Mat<float, 4> M;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) M.a[i][j] = 0.f;
+    M.a[1][0] = 1.f; M.a[2][1] = 1.f;                                             // bottomLeftCorner = Identity, cvo.cpp:82-83
+    M.a[0][0] = -(c2 / c3); M.a[0][1] = -(c1 / c3); M.a[0][2] = -(c0 / c3);       // M.row(0) = -(coef/coef(0)).segment(1,order), cvo.cpp:86
+    float re[3], im[3];
+    float best = std::numeric_limits<float>::max();
+    if (refnoise::eigenvalues<float, 4>(M, 3, re, im)) {
+        for (int k = 0; k < 3; ++k) if (re[k] > 0 && re[k] < best && im[k] == 0) best = re[k];   // cvo.cpp:325-327
+    }
+    float step = (best == std::numeric_limits<float>::max()) ? min_step : best;   // cvo.cpp:330
+    step = step > 0.8 ? (float)0.8 : step;                                        // cvo.cpp:333
+    return step;
+}
+// dist_se3 as the reference runs it: Matrix4f::log().norm() in f32 (cvo.cpp:94-104)
+extern "C" float orc_dist_se3_f32logm(const float dR[9], const float dT[3]) {
+    refnoise::Mat<float, 4> M = refnoise::Mat<float, 4>::identity(), Lg;
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) M.a[r][c] = dR[r * 3 + c]; M.a[r][3] = dT[r]; }
+    if (!refnoise::logm<float, 4>(M, 4, Lg)) return std::numeric_limits<float>::quiet_NaN();
+    float s = 0.f;
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) s += Lg.a[r][c] * Lg.a[r][c];
+    return std::sqrt(s);
+}
+extern "C" void orc_set_variant(orc_cvo* o, int flags, unsigned long long shuffle_seed) { o->variant = flags; o->shuffle_seed = shuffle_seed; o->shuffle_calls = 0; }
+template <class S> static int test_eig(int n, const double* A, double* re, double* im) {
+    refnoise::Mat<S, 4> M = refnoise::Mat<S, 4>::identity();
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) M.a[i][j] = (S)A[i * n + j];
+    S r[4], q[4];
+    if (!refnoise::eigenvalues<S, 4>(M, n, r, q)) return 1;
+    for (int i = 0; i < n; ++i) { re[i] = (double)r[i]; im[i] = (double)q[i]; }
+    return 0;
+}
+template <class S> static int test_logm(int n, const double* A, double* out) {
+    refnoise::Mat<S, 4> M = refnoise::Mat<S, 4>::identity(), Lg;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) M.a[i][j] = (S)A[i * n + j];
+    if (!refnoise::logm<S, 4>(M, n, Lg)) return 1;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) out[i * n + j] = (double)Lg.a[i][j];
+    return 0;
+}
+extern "C" int orc_test_eigenvalues(int n, const double* A, double* re, double* im, int use_f32) {
+    if (n < 1 || n > 4) return 2;
+    return use_f32 ? test_eig<float>(n, A, re, im) : test_eig<double>(n, A, re, im);
+}
+extern "C" int orc_test_logm(int n, const double* A, double* out, int use_f32) {
+    if (n < 1 || n > 4) return 2;
+    return use_f32 ? test_logm<float>(n, A, out) : test_logm<double>(n, A, out);
+}
+
 // align, cvo.cpp:763-821
 extern "C" int orc_align(orc_cvo* o, orc_trace_row* trace, int trace_cap, int* trace_len) {
     if (trace_len) *trace_len = 0;
@@ -572,7 +658,7 @@ extern "C" int orc_align(orc_cvo* o, orc_trace_row* trace, int trace_cap, int* t
         float RdT[3]; mat3_vec(o->R, dT, RdT);
         for (int q = 0; q < 3; ++q) o->T[q] = RdT[q] + o->T[q];                    // cvo.cpp:800
         float Rn[9]; mat3_mul(o->R, dR, Rn); std::memcpy(o->R, Rn, sizeof(Rn));   // cvo.cpp:801
-        const float dist = orc_dist_se3(dR, dT);
+        const float dist = (o->variant & ORC_VAR_F32_LOGM) ? orc_dist_se3_f32logm(dR, dT) : orc_dist_se3(dR, dT);
         if (tr) tr->dist = dist;
         if (dist < o->p.eps_2) { o->iter = k; break; }                            // cvo.cpp:804-808
         o->ell = (k > 2) ? (float)0.10 : o->ell;                                  // cvo.cpp:810-812

@@ -102,6 +102,27 @@ void orc_set_state(orc_cvo* o, const float R[9], const float T[3], float ell);
 void orc_get_accum(const orc_cvo* o, float prev_transform[12], float accum_transform[12]);
 int  orc_get_init(const orc_cvo* o);
 
+/* ---- reference-noise variants (tests/golden/noise_envelope.json, scripts/make_noise_envelope.py).
+ * The reference is not bit-reproducible and computes three things differently from the base oracle;
+ * each flag switches one of them to a restatement of what the reference does, so that the spread of
+ * the final pose over the variants bounds how far the real reference may sit from the base oracle:
+ *   ORC_VAR_SHUFFLE  cross-row f64 sums of omega, v (cvo.cpp:226-230) and B..E (cvo.cpp:309-314) added in
+ *                    a seeded random row order (the reference: TBB workers under a spin mutex, any order)
+ *   ORC_VAR_F32_ROOTS  step = smallest positive eigenvalue with imag()==0 of the f32 companion matrix
+ *                    (cvo.cpp:76-92, 324-330: MatrixXf::eigenvalues()), Francis QR in f32 (ref_noise.hpp)
+ *   ORC_VAR_F32_LOGM   dist_se3 = Frobenius norm of an f32 Schur + Pade matrix logarithm of the f32 4x4
+ *                    (cvo.cpp:94-104: Matrix4f::log().norm()), ref_noise.hpp
+ * A fourth source, FMA contraction / re-association by an optimising compiler (the reference is built
+ * -O3 -march=native with icpc, CMakeLists.txt:13), is a second BUILD of this same source
+ * (oracle/Makefile: libcvo_oracle_fast.so, -O3 -march=native -ffp-contract=fast). */
+enum { ORC_VAR_SHUFFLE = 1, ORC_VAR_F32_ROOTS = 2, ORC_VAR_F32_LOGM = 4 };
+void  orc_set_variant(orc_cvo* o, int flags, unsigned long long shuffle_seed);
+float orc_cubic_step_f32eig(float c3, float c2, float c1, float c0, float min_step);
+float orc_dist_se3_f32logm(const float dR[9], const float dT[3]);
+/* ref_noise.hpp instantiated in double (use_f32 = 0) or float: checked against numpy/scipy */
+int   orc_test_eigenvalues(int n, const double* A /* n x n row-major */, double* re, double* im, int use_f32);
+int   orc_test_logm(int n, const double* A, double* out, int use_f32);
+
 /* one iteration's pieces, exposed for kernel-level parity */
 int  orc_flow_once(orc_cvo* o, float omega[3], float v[3], int* nnz, double BCDE[4], float* step,
                    int* csr_rowptr /* nf+1 or NULL */, int* csr_col /* cap or NULL */,

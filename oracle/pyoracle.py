@@ -12,14 +12,40 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcvo_oracle.so")
 REF_LIB_PATH = os.path.join(HERE, "_ref", "libref_nanoflann.so")
+_SRCS = [os.path.join(HERE, f) for f in ("cvo_oracle.cpp", "pcd_oracle.cpp", "cvo_oracle.h", "ref_noise.hpp", "Makefile")]
 
 
-def build(force: bool = False) -> None:
-    """Compile the oracle (and oracle/_ref when /root/reference exists)."""
-    srcs = [os.path.join(HERE, f) for f in ("cvo_oracle.cpp", "pcd_oracle.cpp", "cvo_oracle.h")]
-    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-C", HERE, "-s", os.path.join(HERE, "libcvo_oracle.so")])
+def _cpu_tag() -> str:
+    """-march=native binds the fast build to the host's CPU: the file name carries a hash of the CPU's flag list, so a
+    library built on another machine (this repository travels between boxes with its built .so files) is never loaded."""
+    import hashlib
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = line; break
+    except OSError:
+        pass
+    return hashlib.sha1(flags.encode()).hexdigest()[:10]
+
+
+def fast_lib_path() -> str:
+    return os.path.join(HERE, f"libcvo_oracle_fast_{_cpu_tag()}.so")
+
+
+def _stale(path: str) -> bool:
+    return (not os.path.exists(path)) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in _SRCS)
+
+
+def build(force: bool = False, fast: bool = True) -> None:
+    """Compile the oracle: the parity build (-O2 -ffp-contract=off), the fast build of the same source
+    (-O3 -march=native -ffp-contract=fast: the FMA member of the noise envelope and the timed CPU baseline),
+    and oracle/_ref when /root/reference exists."""
+    if force or _stale(LIB_PATH):
+        subprocess.check_call(["make", "-C", HERE, "-s", LIB_PATH])
+    if fast and (force or _stale(fast_lib_path())):
+        subprocess.check_call(["make", "-C", HERE, "-s", "fast", f"FAST_TAG={_cpu_tag()}"])
     if os.path.exists("/root/reference/thirdparty/cvo/thirdparty/nanoflann.hpp") and (force or not os.path.exists(REF_LIB_PATH)):
         subprocess.check_call(["make", "-C", HERE, "-s", "ref"])
 
@@ -41,16 +67,18 @@ class TraceRow(C.Structure):
 
 SEARCH_BRUTE, SEARCH_KDTREE = 0, 1
 SLOT_FIXED, SLOT_MOVING, SLOT_PREVIOUS = 0, 1, 2
+VAR_SHUFFLE, VAR_F32_ROOTS, VAR_F32_LOGM = 1, 2, 4      # cvo_oracle.h: reference-noise variants
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            build()
-        L = C.CDLL(LIB_PATH)
+def lib(flavor: str = "parity"):
+    """flavor "parity": the un-fused -O2 build every parity test compares with; "fast": the optimising build."""
+    if flavor not in _libs:
+        path = LIB_PATH if flavor == "parity" else fast_lib_path()
+        if _stale(path):
+            build(fast=(flavor != "parity"))
+        L = C.CDLL(path)
         fp = C.POINTER(C.c_float); dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int)
         L.orc_default_params.argtypes = [C.POINTER(Params)]
         L.orc_create.argtypes = [C.POINTER(Params)]; L.orc_create.restype = C.c_void_p
@@ -80,8 +108,13 @@ def lib():
         L.orc_dist_se3.argtypes = [fp, fp]; L.orc_dist_se3.restype = C.c_float
         L.orc_hessian_regularize.argtypes = [fp, C.c_int, dp]
         L.orc_radius_search.argtypes = [fp, C.c_int, fp, C.c_float, ip, fp, C.c_int, C.c_int]
-        _lib = L
-    return _lib
+        L.orc_set_variant.argtypes = [C.c_void_p, C.c_int, C.c_ulonglong]
+        L.orc_cubic_step_f32eig.argtypes = [C.c_float] * 5; L.orc_cubic_step_f32eig.restype = C.c_float
+        L.orc_dist_se3_f32logm.argtypes = [fp, fp]; L.orc_dist_se3_f32logm.restype = C.c_float
+        L.orc_test_eigenvalues.argtypes = [C.c_int, dp, dp, dp, C.c_int]
+        L.orc_test_logm.argtypes = [C.c_int, dp, dp, C.c_int]
+        _libs[flavor] = L
+    return _libs[flavor]
 
 
 def ref_lib():
@@ -106,11 +139,13 @@ def default_params() -> Params:
 class OracleCvo:
     """The reference's `cvo::cvo` (cvo.hpp:82-282) with pcd_generator output handed in."""
 
-    def __init__(self, params: Params | None = None, search=SEARCH_BRUTE, threads=1):
-        self.L = lib()
+    def __init__(self, params: Params | None = None, search=SEARCH_BRUTE, threads=1, flavor="parity", variant=0, shuffle_seed=0):
+        self.L = lib(flavor)
         self.params = params or default_params()
         self.h = C.c_void_p(self.L.orc_create(C.byref(self.params)))
         self.L.orc_set_exec(self.h, search, threads)
+        if variant:
+            self.L.orc_set_variant(self.h, int(variant), int(shuffle_seed))
 
     def __del__(self):
         try:
@@ -237,6 +272,29 @@ def exp_sek3(omega, v, dt):
 def dist_se3(dR, dT):
     r, rp = _f(np.asarray(dR).reshape(9)); t, tp = _f(dT)
     return float(lib().orc_dist_se3(rp, tp))
+
+
+def cubic_step_f32eig(c3, c2, c1, c0, min_step=0.2):
+    return float(lib().orc_cubic_step_f32eig(c3, c2, c1, c0, min_step))
+
+
+def dist_se3_f32logm(dR, dT):
+    r, rp = _f(np.asarray(dR).reshape(9)); t, tp = _f(dT)
+    return float(lib().orc_dist_se3_f32logm(rp, tp))
+
+
+def test_eigenvalues(A, use_f32=False):
+    A = np.ascontiguousarray(A, np.float64); n = A.shape[0]
+    re = np.zeros(n); im = np.zeros(n); dp = C.POINTER(C.c_double)
+    rc = lib().orc_test_eigenvalues(n, A.ctypes.data_as(dp), re.ctypes.data_as(dp), im.ctypes.data_as(dp), int(use_f32))
+    return rc, re + 1j * im
+
+
+def test_logm(A, use_f32=False):
+    A = np.ascontiguousarray(A, np.float64); n = A.shape[0]
+    out = np.zeros((n, n)); dp = C.POINTER(C.c_double)
+    rc = lib().orc_test_logm(n, A.ctypes.data_as(dp), out.ctypes.data_as(dp), int(use_f32))
+    return rc, out
 
 
 def hessian_regularize(H, inliers):

@@ -1,0 +1,39 @@
+"""The HIP path against the reference-noise envelope (tests/golden/noise_envelope.json): its distance from the base
+oracle must not exceed what the reference's own sources of noise (FMA contraction, reduction order, f32 companion-matrix
+roots, f32 matrix logarithm) produce on the same pair -- and the north-star tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import rot_trans_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_result_lies_inside_the_reference_noise_envelope(hiplib, oracle):
+    ca = hiplib
+    from cvo_slam_amd import synth
+    with open(os.path.join(GOLDEN, "noise_envelope.json")) as f:
+        env = json.load(f)
+    cases = [("small", row, synth.make_small_pair(row["pair"], n=600)) for row in env["small"]["per_pair"]]
+    cases += [("tum64", row, synth.make_pair(row["pair"])) for row in env["tum64"]["per_pair"][:12]]
+    B = ca.CvoBatch(len(cases), device=0)
+    for i, (_, _, p) in enumerate(cases):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+    B.align_async(len(cases))
+    res = B.wait(len(cases))
+    B.close()
+    for (kind, row, p), r in zip(cases, res):
+        o = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=4)
+        o.set_pcd(p.fixed.xyz, p.fixed.feat); o.set_pcd(p.moving.xyz, p.moving.feat)
+        assert o.align()[0] == 0
+        st = o.get_state()
+        assert st["iter"] == row["base_iter"]
+        rot, tr = rot_trans_err(r["transform"], st["transform"])
+        assert r["status"] == 0 and r["iter"] == st["iter"]
+        # inside the envelope of this very pair (with a floor of 1e-7: an f32 pose has ~6e-8 of resolution) and inside the tolerance
+        assert rot <= max(row["max_rot_rad"], 1e-7) and tr <= max(row["max_trans_m"], 1e-7), (kind, row["pair"], rot, tr)
+        assert rot <= 1e-4 and tr <= 1e-4

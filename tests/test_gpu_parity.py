@@ -487,6 +487,43 @@ def test_reset_keyframe_slot_moves(hiplib):
     g.close()
 
 
+def test_reset_keyframe_matches_the_oracle_state_machine(hiplib, oracle):
+    """cvo.cpp:591-604 against orc_reset_keyframe, both branches: before any update_previous_pcd (FIXED <- MOVING) and after
+    one (FIXED <- PREVIOUS, MOVING -> PREVIOUS); the slots are identified by what an alignment and the inner products on
+    them return afterwards."""
+    S = hiplib.api
+    from cvo_slam_amd import synth
+    clouds = [synth.make_small_pair(300 + i, n=350 + 40 * i) for i in range(2)]
+    A = (clouds[0].fixed.xyz, clouds[0].fixed.feat); B = (clouds[0].moving.xyz, clouds[0].moving.feat)
+    Cc = (clouds[1].moving.xyz, clouds[1].moving.feat); D = (clouds[1].fixed.xyz, clouds[1].fixed.feat)
+    odom = make_tf([0.2, 0.1, 1], 0.012, [0.01, -0.004, 0.006])
+
+    def drive(obj, fip, is_gpu):
+        out = []
+        obj.set_pcd(*A); obj.set_pcd(*B)
+        obj.reset_keyframe(odom)                                  # no PREVIOUS yet: FIXED <- MOVING (cvo.cpp:593-595)
+        out.append(np.array(obj.transform if is_gpu else obj.get_state()["transform"], np.float64))
+        obj.set_pcd(*Cc)                                          # new MOVING against the moved FIXED (= B)
+        out.append(fip(obj, S.SLOT_MOVING, S.SLOT_FIXED))
+        obj.update_previous_pcd()                                 # MOVING -> PREVIOUS (cvo.cpp:584-589)
+        obj.set_pcd(*D)
+        obj.reset_keyframe(odom)                                  # FIXED <- PREVIOUS (= Cc), MOVING (= D) -> PREVIOUS (cvo.cpp:596-601)
+        out.append(fip(obj, S.SLOT_FIXED, S.SLOT_PREVIOUS))
+        obj.set_pcd(*A)
+        out.append(fip(obj, S.SLOT_MOVING, S.SLOT_PREVIOUS))
+        out.append(fip(obj, S.SLOT_MOVING, S.SLOT_FIXED))
+        return out
+
+    g = hiplib.Cvo()
+    got = drive(g, lambda o, a, b: o.function_inner_product(a, None, b), True)
+    o = oracle.OracleCvo()
+    want = drive(o, lambda q, a, b: q.function_inner_product(a, None, b)[1], False)
+    np.testing.assert_array_equal(got[0], np.float64(odom)); np.testing.assert_array_equal(want[0], np.float64(odom))
+    for gv, wv in zip(got[1:], want[1:]):
+        assert gv[1] == wv[1] and gv[0] == pytest.approx(wv[0], rel=1e-6), (gv, wv)      # pair counts exact, sums to f64-order noise
+    g.close()
+
+
 # ----------------------------------------------------------------------------- batches
 def test_batch_matches_single_objects_and_warm_start(hiplib, oracle):
     from cvo_slam_amd import synth
