@@ -45,10 +45,18 @@ def _gen_pair(idx):
     return idx, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat
 
 
+def under_profiler() -> bool:
+    """rocprofv3 preloads its tool library into the program it starts; with counter collection that library has
+    initialised the GPU before main() runs, and a fork() after that point hangs now and then."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return ("rocprof" in pre) or any(k.startswith(("ROCPROF", "ROCPROFILER_", "ROCP_")) for k in os.environ)
+
+
 def generate_pairs(first: int, count: int, workers: int = 0):
-    """Seeded synthetic pairs first..first+count-1, rendered on host worker processes
-    (forked before anything touches the GPU).  workers = 1: in this process (under rocprofv3 --pmc the profiler has
-    initialised the GPU before the program starts, and forking after that hangs now and then)."""
+    """Seeded synthetic pairs first..first+count-1, rendered on host worker processes (forked before anything touches
+    the GPU) -- or in this process when a profiler has been preloaded (no fork then: see under_profiler) or workers = 1."""
+    if workers <= 0 and under_profiler():
+        workers = 1
     workers = max(1, min(workers or host_threads(), count))
     if workers == 1:
         return [_gen_pair(first + i) for i in range(count)]
@@ -87,42 +95,59 @@ def host_threads() -> int:
 
 
 def cpu_baseline(pairs, threads, budget_s=20.0):
-    """Oracle (CPU restatement with the reference's structure: KD-tree rebuilt every
-    iteration, row-parallel loops) on the host cores.  Pass 1 aligns as many of the batch's
-    pairs as fit in ~budget_s seconds once each (their transforms are the parity check);
-    the first 16 pairs are then repeated four more times (rate = median of the five passes over
-    those 16) and the first 3 pairs once on a single thread."""
+    """The oracle (CPU restatement with the reference's structure: KD-tree rebuilt every iteration, two sparse sweeps) on
+    the host cores, three ways:
+      parity pass   the un-fused -O2 build (the checker), every pair of the batch once: transforms for the parity block
+      pair_parallel the -O3 -march=native -ffp-contract=fast build, one alignment per host thread,
+                    `threads` of them at once: the strongest CPU configuration for a batch of independent pairs = `value`
+      row_parallel  the same build with the reference's own structure: one alignment at a time, its row loops spread over
+                    `threads` OpenMP threads (the TBB parallel_for stand-in); the KD-tree build and the CSR assembly of
+                    every iteration stay serial, as in the reference (cvo.cpp:135-136, 182-183)
+    plus one thread alone.  All on a bounded sample (about budget_s seconds in all)."""
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     po.build()
 
-    def run(sel, nthreads):
-        tfs, iters = [], []
-        t0 = time.perf_counter()
-        for (_, fx, ff, mx, mf) in sel:
-            o = po.OracleCvo(search=po.SEARCH_KDTREE, threads=nthreads)
-            o.set_pcd(fx, ff); o.set_pcd(mx, mf)
-            o.align()
-            st = o.get_state()
-            tfs.append(st["transform"].copy()); iters.append(st["iter"] + 1)
-            if time.perf_counter() - t0 > budget_s:
-                break
-        return tfs, iters, time.perf_counter() - t0
+    def one(args):
+        (_, fx, ff, mx, mf), nthreads, flavor = args
+        o = po.OracleCvo(search=po.SEARCH_KDTREE, threads=nthreads, flavor=flavor)
+        o.set_pcd(fx, ff); o.set_pcd(mx, mf)
+        o.align()
+        st = o.get_state()
+        return st["transform"].copy(), st["iter"] + 1, o.get_timing()
 
-    sub = pairs[: min(16, len(pairs))]
     t_all0 = time.perf_counter()
-    tfs_s, it_s, dt_s = run(sub, threads)                               # pass 1, first 16
-    tfs_r, it_r, dt_r = run(pairs[len(sub):], threads) if len(pairs) > len(sub) else ([], [], 0.0)
-    rates = [len(tfs_s) / dt_s]
-    for _ in range(4):
-        if time.perf_counter() - t_all0 > 1.5 * budget_s:
-            break
-        r_tfs, _, r_dt = run(sub, threads)
-        rates.append(len(r_tfs) / r_dt)
-    one = pairs[: min(3, len(pairs))]
-    o_tfs, _, o_dt = run(one, 1)
-    return dict(rate=float(np.median(rates)), rates=rates, first_pass_rate=(len(tfs_s) + len(tfs_r)) / (dt_s + dt_r), seconds=time.perf_counter() - t_all0,
-                tfs=tfs_s + tfs_r, iters=it_s + it_r, single_thread_rate=len(o_tfs) / o_dt, single_thread_pairs=len(o_tfs))
+    with ThreadPoolExecutor(threads) as ex:                        # ctypes drops the GIL inside the oracle
+        t0 = time.perf_counter()
+        par = list(ex.map(one, [(p, 1, "parity") for p in pairs]))
+        dt_parity = time.perf_counter() - t0
+        rates_pp = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fast = list(ex.map(one, [(p, 1, "fast") for p in pairs]))
+            rates_pp.append(len(pairs) / (time.perf_counter() - t0))
+            if time.perf_counter() - t_all0 > budget_s:
+                break
+    sub = pairs[: min(8, len(pairs))]
+    rates_rp, serial = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rr = [one((p, threads, "fast")) for p in sub]
+        dt = time.perf_counter() - t0
+        rates_rp.append(len(sub) / dt)
+        serial.append(sum(r[2]["kdtree_build"] + r[2]["csr_assembly"] for r in rr) / dt)
+    t0 = time.perf_counter()
+    single = [one((p, 1, "fast")) for p in pairs[:3]]
+    rate_1 = len(single) / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    single_par = [one((p, 1, "parity")) for p in pairs[:3]]
+    rate_1_parity = len(single_par) / (time.perf_counter() - t0)
+    return dict(rate=float(np.median(rates_pp)), rates=rates_pp, parity_build_rate=len(pairs) / dt_parity,
+                row_parallel_rate=float(np.median(rates_rp)), row_parallel_serial_fraction=float(np.median(serial)),
+                single_thread_rate=rate_1, single_thread_rate_parity_build=rate_1_parity, seconds=time.perf_counter() - t_all0,
+                tfs=[r[0] for r in par], iters=[r[1] for r in par],
+                fast_vs_parity_build=max((rot_trans_err(a[0], b[0]) for a, b in zip(fast, par)), key=lambda e: max(e)))
 
 
 def latency_probe(ca, pairs, device):
@@ -395,47 +420,68 @@ def main():
         value = world * n * args.steps / elapsed
         step_ms_rank = 1e3 * elapsed / args.steps          # one launch retires every step_ms_rank on this GPU
         overlap = k_ms / step_ms_rank                      # launches running side by side, on average
-        traffic = None                                  # HBM bytes per launch from separate rocprofv3 --pmc passes (scripts/pmc_run.sh)
-        valu_instr = None                               # VALU wave-instructions one launch executes (same passes)
+        # Counter figures come from separate rocprofv3 --pmc passes over this kernel (scripts/pmc_run.sh -> profiles/pmc_traffic.json,
+        # taken at the commit named inside it): HBM bytes and VALU wave-instructions ONE launch of this workload executes.  Both are
+        # properties of the work, not of the timing; the rates below divide them by times measured live in this run.
+        traffic = valu_instr = pmc_src = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            traffic = float(pmc["hbm_bytes_per_launch"]); valu_instr = float(pmc.get("valu_wave_instructions_per_launch", 0)) or None
+            if pmc.get("shape", "tum") == args.shape and int(pmc.get("pairs", n)) == n:
+                traffic = float(pmc["hbm_bytes_per_launch"]); valu_instr = float(pmc.get("valu_wave_instructions_per_launch", 0)) or None
+                pmc_src = pmc.get("source")
         except Exception:
-            traffic = None
+            pass
+        prof_ms = prof_file = None                       # rocprofv3 --kernel-trace --stats of this command, committed: its average must agree with kernel_ms
+        try:
+            import csv
+            prof_file = "profiles/r02_kernel_stats.csv" if args.shape == "tum" else "profiles/r02_eth3d_kernel_stats.csv"
+            with open(os.path.join(ROOT, prof_file), newline="") as f:
+                for row in csv.DictReader(f):
+                    if "cvo_align_kernel" in row.get("Name", ""):
+                        prof_ms = float(row["AverageNs"]) * 1e-6
+        except Exception:
+            prof_file = None
+        # The kernel is bound by VALU issue, not by HBM: the roofline object prices the issue slots.
+        # One wave64 VALU instruction occupies its SIMD for 4 cycles (plain f32, f64 FMA alike on gfx950), so the chip issues at most
+        # 256 CUs x 4 SIMDs x 2.4 GHz / 4 wave-instructions per second.
+        step_s = step_ms_rank * 1e-3
+        valu_peak = 256 * 4 * 2.4e9 / 4.0
+        valu_rate = (valu_instr / step_s) if valu_instr else None
+        pair_tests = float(info.get("candidates_total", 0))          # list candidates the last launch evaluated (every launch of the region does the same work)
         out = {
             "metric": "CVO frame-pair alignments/sec (640x480, ~3k pts/cloud)",
             "value": value, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} independent synthetic {'640x480 TUM' if args.shape == 'tum' else '736x456 ETH3D'}-shape RGB-D pairs per GPU per step "
-                                   f"(BASELINE config 3; {world * n} pairs per step at {world} GPU(s); config 4 = 512 pairs at 8 GPUs), "
+                                   f"(BASELINE config {'3' if args.shape == 'tum' else '5'}; {world * n} pairs per step at {world} GPU(s); config 4 = 512 pairs at 8 GPUs), "
                                    f"full align() from R=I,T=0,ell=0.15 to convergence",
                        "pairs_per_gpu": n, "points_fixed_mean": float(np.mean(nfs)), "points_moving_mean": float(np.mean(nms)),
                        "iterations_mean": float(np.mean(its)), "iterations_max": int(np.max(its)),
                        "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth,
                        "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": (("RCCL" if backend == "nccl" else backend) + " all_gather of 64-byte result records") if world > 1 else "none (1 GPU)"},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "cvo_align_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "launches_side_by_side": overlap, "achieved_all_launches": achieved_gbs * overlap,
-                         "frac_all_launches": achieved_gbs * overlap / HBM_PEAK_GBS,
-                         "profile": "profiles/r01_j_kernel_stats.csv: rocprofv3 --kernel-trace --stats of this command with --no-latency-probe (only "
-                                    "launches of the timed regime): 11.90 ms average over 297 launches; profiles/README.md indexes the rest",
-                         "note": "achieved = algorithmic bytes of ONE launch / its own HIP-event duration; a launch holds 64 of 256 CUs and "
-                                 "launches_side_by_side of them run at once, achieved_all_launches is the whole GPU's rate.  The path is "
-                                 "latency/VALU bound, not HBM bound (SURVEY 8d): see valu and DESIGN.md"},
+            "roofline": {"bound": "valu_issue", "achieved": valu_rate, "peak": valu_peak, "unit": "wave-instructions/s",
+                         "frac": (valu_rate / valu_peak) if valu_rate else None,
+                         "traffic": traffic, "kernel": "cvo_align_kernel", "kernel_ms": k_ms,
+                         "valu_wave_instructions_per_launch": valu_instr, "counters": pmc_src,
+                         "launches_side_by_side": overlap, "profile": prof_file, "profile_kernel_ms": prof_ms,
+                         "note": "achieved = VALU wave-instructions one launch executes (SQ_INSTS_VALU, rocprofv3 --pmc at the commit named in `counters`) / "
+                                 "time per step measured live (one launch retires per step); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 "
+                                 "instruction.  kernel_ms = mean HIP-event duration of a launch on its own stream with launches_side_by_side of them "
+                                 "sharing the CUs (so it contains queueing; the rocprofv3 --kernel-trace average of the same command is `profile_kernel_ms`)"},
+            "hbm": {"bound": "hbm", "achieved": bytes_launch / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / step_s / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": bytes_launch, "traffic": traffic, "traffic_rate_GBs": (traffic / step_s / 1e9) if traffic else None,
+                    "per_launch_achieved_GBs": achieved_gbs,
+                    "note": "secondary: chip-level rate = algorithmic bytes of one step (SURVEY 8d: 2(32N+32M)+24M per iteration x executed iterations) / time "
+                            "per step; traffic = FETCH_SIZE (doubled: gfx950 wide-read under-count) + WRITE_SIZE per launch from the PMC passes; "
+                            "per_launch_achieved_GBs divides by one launch's own duration instead"},
             "with_score_block": with_scores,
             "with_host_upload": with_upload,
-            "valu": {"dense_pair_tests_per_s": flops_launch / 8.0 / (step_ms_rank * 1e-3),
-                     "algorithmic_flops_fraction": flops_launch / (step_ms_rank * 1e-3) / 157.3e12,
-                     "hbm_fraction_of_achievable": bytes_launch / (step_ms_rank * 1e-3) / 6.3e12,
-                     "executed_wave_instructions_per_launch": valu_instr,
-                     "issue_slots_used": (valu_instr * 4.0 / (256 * 4 * 2.4e9 * step_ms_rank * 1e-3)) if valu_instr else None,
-                     "note": "issue_slots_used = VALU wave-instructions of one launch (SQ_INSTS_VALU, profiles/) x 4 cycles / (256 CUs x 4 SIMDs x 2.4 GHz x "
-                             "time per step): the share of the chip's plain-f32 issue slots the job keeps busy.  dense_pair_tests_per_s counts the "
-                             "N*M tests per iteration the reference's radius search stands for; the kernel skips most of them (lists + box cull), so "
-                             "algorithmic_flops_fraction (SURVEY 8d: 8 flop per dense pair test / 157.3 TF) exceeds 1 -- it prices work that is not executed; "
-                             "hbm_fraction_of_achievable = algorithmic bytes per step / 6.3 TB/s (SURVEY 8d), whole GPU"},
+            "work": {"executed_pair_tests_per_s": pair_tests / step_s if pair_tests else None,
+                     "dense_pair_tests_per_s_equivalent": flops_launch / 8.0 / step_s,
+                     "note": "executed_pair_tests = list candidates the kernel evaluated with the reference's exact expression (all iterations of one step); the "
+                             "dense equivalent counts the N*M tests per iteration the reference's radius search stands for (most are skipped by lists + box cull)"},
         }
         if world == 1 and not args.no_latency_probe:
             out["latency"] = latency_probe(ca, pairs, local_rank)
@@ -446,13 +492,30 @@ def main():
             cpu_rate, cpu_tfs, cpu_its = cb["rate"], cb["tfs"], cb["iters"]
             errs = [rot_trans_err(results[i]["transform"], cpu_tfs[i]) for i in range(len(cpu_tfs))]
             out["cpu_baseline"] = {"value": cpu_rate, "unit": "alignments/s", "cores": cores, "kind": "port",
-                                   "sample": f"oracle (CPU restatement of the reference: KD-tree rebuilt per iteration, OpenMP rows; not the icpc binary) on "
-                                             f"{cores} host threads: {len(cpu_tfs)} pairs of the timed batch once each (parity check, {cb['first_pass_rate']:.1f}/s), "
-                                             f"value = median of {len(cb['rates'])} passes over the first 16 pairs; {cb['seconds']:.1f} s in all",
-                                   "passes": cb["rates"], "single_thread_value": cb["single_thread_rate"], "single_thread_pairs": cb["single_thread_pairs"],
+                                   "sample": f"oracle (CPU restatement of the reference: KD-tree rebuilt per iteration, two sparse sweeps; not the icpc binary), "
+                                             f"-O3 -march=native -ffp-contract=fast build, the {len(pairs)} pairs of the timed batch, one alignment per host thread, "
+                                             f"{cores} at once; value = median of {len(cb['rates'])} passes; {cb['seconds']:.1f} s for all CPU legs",
+                                   "passes": cb["rates"],
+                                   "row_parallel_value": cb["row_parallel_rate"], "row_parallel_serial_fraction": cb["row_parallel_serial_fraction"],
+                                   "row_parallel_note": f"the reference's own structure: one alignment at a time, row loops on {cores} threads; the KD-tree build and CSR assembly "
+                                                        "of every iteration are serial (cvo.cpp:135-136, 182-183) and take the stated share of the wall time",
+                                   "single_thread_value": cb["single_thread_rate"], "single_thread_value_parity_build": cb["single_thread_rate_parity_build"],
+                                   "parity_build_value": cb["parity_build_rate"],
+                                   "fast_build_vs_parity_build_max_err": {"rot_rad": cb["fast_vs_parity_build"][0], "trans_m": cb["fast_vs_parity_build"][1]},
                                    "iterations_mean": float(np.mean(cpu_its))}
-            out["parity"] = {"pairs_checked": len(errs), "max_rot_err_rad": max(e[0] for e in errs), "max_trans_err_m": max(e[1] for e in errs),
-                             "iterations_equal": bool(all(a == b for a, b in zip(its, cpu_its))), "tolerance": "1e-4 rad / 1e-4 m"}
+            env = None
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", "noise_envelope.json")) as f:
+                    ej = json.load(f)["tum64"]
+                env = {"max_rot_rad": ej["max_rot_rad"], "max_trans_m": ej["max_trans_m"], "pairs_beyond_1e-4": ej["pairs_beyond_1e-4"],
+                       "per_variant": {k: [v["max_rot_rad"], v["max_trans_m"]] for k, v in ej["per_variant"].items()},
+                       "source": "tests/golden/noise_envelope.json (scripts/make_noise_envelope.py): distance of the oracle's reference-noise variants from the base oracle on these 64 pairs"}
+            except Exception:
+                pass
+            out["parity"] = {"pairs_checked": len(errs), "against": "oracle, un-fused parity build (every pair of the timed batch)",
+                             "max_rot_err_rad": max(e[0] for e in errs), "max_trans_err_m": max(e[1] for e in errs),
+                             "iterations_equal": bool(all(a == b for a, b in zip(its, cpu_its))), "tolerance": "1e-4 rad / 1e-4 m",
+                             "reference_noise_envelope": env if args.shape == "tum" else None}
             out["speedup_vs_cpu_baseline"] = value / cpu_rate
         print(json.dumps(out), flush=True)
 

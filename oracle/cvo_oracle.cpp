@@ -31,6 +31,7 @@
 #include "ref_noise.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -256,6 +257,7 @@ struct orc_cvo {
     std::vector<int> A_rowptr, A_col; std::vector<float> A_val;   // Eigen::SparseMatrix<float,RowMajor>
     double last_BCDE[4] = {0, 0, 0, 0};
     int search_mode = ORC_SEARCH_BRUTE, threads = 1;
+    double t_sec[4] = {0, 0, 0, 0};                // where align() spent its time: KD-tree build | radius searches + kernel values (row-parallel) | CSR assembly (serial) | flow + step-size sweeps
     int variant = 0;                               // ORC_VAR_* (reference-noise variants, cvo_oracle.h)
     unsigned long long shuffle_seed = 0, shuffle_calls = 0;
 };
@@ -287,8 +289,10 @@ void se_kernel(orc_cvo* o, float l, float s2) {
     // float d2_c_thres = -2.0*c_ell*c_ell*log(sp_thres/c_sigma/c_sigma);   cvo.cpp:126
     const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)std::log(P.sp_thres / P.c_sigma / P.c_sigma));
 
+    const auto tk0 = std::chrono::steady_clock::now();
     KdTree tree; const KdTree* tp = nullptr;
     if (o->search_mode == ORC_SEARCH_KDTREE) { tree.build(o->cloud_y.data(), M); tp = &tree; }   // rebuilt every call, cvo.cpp:135-136
+    const auto tk1 = std::chrono::steady_clock::now();
 
     std::vector<std::vector<int>> cols(N); std::vector<std::vector<float>> vals(N);
 #pragma omp parallel num_threads(o->threads)
@@ -311,6 +315,7 @@ void se_kernel(orc_cvo* o, float l, float s2) {
             }
         }
     }
+    const auto tk2 = std::chrono::steady_clock::now();
     // A.setFromTriplets + makeCompressed (cvo.cpp:182-183): CSR, columns ascending
     o->A_rowptr.assign(N + 1, 0);
     for (int i = 0; i < N; ++i) o->A_rowptr[i + 1] = o->A_rowptr[i] + (int)cols[i].size();
@@ -319,11 +324,20 @@ void se_kernel(orc_cvo* o, float l, float s2) {
         std::copy(cols[i].begin(), cols[i].end(), o->A_col.begin() + o->A_rowptr[i]);
         std::copy(vals[i].begin(), vals[i].end(), o->A_val.begin() + o->A_rowptr[i]);
     }
+    const auto tk3 = std::chrono::steady_clock::now();
+    o->t_sec[0] += std::chrono::duration<double>(tk1 - tk0).count(); o->t_sec[1] += std::chrono::duration<double>(tk2 - tk1).count();
+    o->t_sec[2] += std::chrono::duration<double>(tk3 - tk2).count();
 }
 
 // compute_flow, cvo.cpp:187-236
+struct SweepTimer {   // the two sparse sweeps (compute_flow after se_kernel, compute_step_size)
+    orc_cvo* o; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit SweepTimer(orc_cvo* p) : o(p) {}
+    ~SweepTimer() { o->t_sec[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 void compute_flow(orc_cvo* o) {
     se_kernel(o, o->ell, o->p.sigma * o->p.sigma);                                // cvo.cpp:189
+    SweepTimer sweep_timer(o);
     const Cloud& X = *o->fixed;
     const int N = X.n;
     const float inv_c = 1 / o->p.c, inv_d = 1 / o->p.d;                           // `1/c`, `1/d` are float
@@ -461,6 +475,7 @@ namespace {
 
 // compute_step_size, cvo.cpp:239-334
 void compute_step_size(orc_cvo* o) {
+    SweepTimer sweep_timer(o);
     const Cloud& X = *o->fixed;
     const int N = X.n, M = o->moving->n;
     float Oh[9]; skew3(o->omega, Oh);                                             // cvo.cpp:241
@@ -949,6 +964,7 @@ void orc_get_accum(const orc_cvo* o, float prev_transform[12], float accum_trans
     if (accum_transform) std::memcpy(accum_transform, o->accum_transform.m, sizeof(float) * 12);
 }
 int orc_get_init(const orc_cvo* o) { return o->init ? 1 : 0; }
+void orc_get_timing(const orc_cvo* o, double seconds[4]) { for (int i = 0; i < 4; ++i) seconds[i] = o->t_sec[i]; }
 
 int orc_flow_once(orc_cvo* o, float omega[3], float v[3], int* nnz, double BCDE[4], float* step,
                   int* csr_rowptr, int* csr_col, float* csr_val, int csr_cap) {

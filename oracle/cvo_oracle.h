@@ -101,6 +101,9 @@ void orc_get_state(const orc_cvo* o, float R[9], float T[3], float* ell, float t
 void orc_set_state(orc_cvo* o, const float R[9], const float T[3], float ell);
 void orc_get_accum(const orc_cvo* o, float prev_transform[12], float accum_transform[12]);
 int  orc_get_init(const orc_cvo* o);
+/* seconds this object's align() calls spent in: [0] KD-tree build (serial, cvo.cpp:135-136)  [1] radius searches + kernel values
+ * (row-parallel, cvo.cpp:139-180)  [2] CSR assembly (serial: setFromTriplets, cvo.cpp:182-183)  [3] the two sparse sweeps */
+void orc_get_timing(const orc_cvo* o, double seconds[4]);
 
 /* ---- reference-noise variants (tests/golden/noise_envelope.json, scripts/make_noise_envelope.py).
  * The reference is not bit-reproducible and computes three things differently from the base oracle;

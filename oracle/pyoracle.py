@@ -102,6 +102,7 @@ def lib(flavor: str = "parity"):
         L.orc_set_state.argtypes = [C.c_void_p, fp, fp, C.c_float]
         L.orc_get_accum.argtypes = [C.c_void_p, fp, fp]
         L.orc_get_init.argtypes = [C.c_void_p]
+        L.orc_get_timing.argtypes = [C.c_void_p, dp]
         L.orc_flow_once.argtypes = [C.c_void_p, fp, fp, ip, dp, fp, ip, ip, fp, C.c_int]
         L.orc_cubic_step.argtypes = [C.c_float] * 5; L.orc_cubic_step.restype = C.c_float
         L.orc_exp_sek3.argtypes = [fp, fp, C.c_float, fp, fp]
@@ -238,6 +239,10 @@ class OracleCvo:
                              C.byref(it), C.byref(nnz), C.byref(nf), C.byref(nm))
         return dict(R=R.reshape(3, 3), T=T, ell=ell.value, transform=tf.reshape(3, 4), iter=it.value, A_nonzero=nnz.value,
                     num_fixed=nf.value, num_moving=nm.value)
+
+    def get_timing(self):
+        t = np.zeros(4); self.L.orc_get_timing(self.h, t.ctypes.data_as(C.POINTER(C.c_double)))
+        return dict(kdtree_build=t[0], search_and_kernel=t[1], csr_assembly=t[2], sparse_sweeps=t[3])
 
     def set_state(self, R, T, ell):
         r, rp = _f(np.asarray(R).reshape(9)); t, tp = _f(np.asarray(T).reshape(3))
