@@ -271,12 +271,36 @@ def main():
         batches.append(b)
     batch = batches[0]
 
-    from cvo_slam_amd import shard
+    from cvo_slam_amd import shard, api
     n = args.pairs
-    assert list(shard.shard_range(world * n, rank, world)) == list(range(rank * n, rank * n + n))
+    assert list(api.shard_range(world * n, rank, world)) == list(range(rank * n, rank * n + n))      # cvo_shard_range: contiguous blocks
     sends = [torch.zeros((n, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda") for _ in range(depth)]
+    recvs = [torch.zeros((world * n, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda") for _ in range(depth)] if world > 1 else []
     gathered = None
     inflight = []                                  # batch objects with a launch not yet waited for
+    # The gather: ONE RCCL all-gather of the 64-byte records per step, enqueued by the C ABI behind the align launch on its
+    # stream (cvo_batch_gather_results: pack kernel + ncclAllGather, no host sync in between).  The communicator's unique id
+    # travels through torch.distributed once.  CVO_BENCH_GATHER=torch (or a non-RCCL backend) gathers with torch.distributed
+    # after the wait instead.
+    comm = None
+    gather_mode = "none"
+    if world > 1:
+        gather_mode = "torch"
+        if backend == "nccl" and os.environ.get("CVO_BENCH_GATHER", "abi") == "abi":
+            try:                                   # does RCCL load on this rank at all?  (decided by all ranks together before anything collective)
+                my_id = api.comm_unique_id(); can = 1
+            except Exception as e:
+                print(f"[bench] rank {rank}: RCCL not loadable through the C ABI ({e})", file=sys.stderr, flush=True)
+                my_id = bytes(api.COMM_ID_BYTES); can = 0
+            ok = torch.tensor([can], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                idt = torch.frombuffer(bytearray(my_id), dtype=torch.uint8).to("cuda")
+                dist.broadcast(idt, 0)                                 # rank 0's id, everywhere
+                comm = ca.CvoComm(bytes(idt.cpu().numpy().tobytes()), world, rank, device=local_rank)   # ncclCommInitRank (collective)
+                gather_mode = "abi"
+            elif rank == 0:
+                print("[bench] gathering with torch.distributed instead", file=sys.stderr, flush=True)
 
     kernel_ms = []                                 # HIP-event duration of every launch, on the stream it ran on
 
@@ -285,7 +309,10 @@ def main():
         batches[bi].wait()
         kernel_ms.append(batches[bi].last_launch()["kernel_ms"])
         if world > 1:
-            gathered = shard.gather_results(sends[bi], world * n, world)   # RCCL: the SE(3) results of every rank, everywhere
+            if comm is not None:
+                gathered = recvs[bi]                                           # already there: the all-gather ran behind the kernel
+            else:
+                gathered = shard.gather_results(sends[bi], world * n, world)   # the SE(3) results of every rank, everywhere
 
     def step(i):
         bi = i % depth
@@ -294,7 +321,10 @@ def main():
         b = batches[bi]
         b.reset_states()                           # every step starts from R=I, T=0, ell=0.15
         b.align_async(n)
-        b.results_to_device(sends[bi].data_ptr(), n)   # same stream, behind the kernel
+        if comm is not None:
+            b.gather_results(comm, n, recvs[bi].data_ptr())   # pack + ncclAllGather on the launch's stream
+        else:
+            b.results_to_device(sends[bi].data_ptr(), n)      # same stream, behind the kernel
         inflight.append(bi)
 
     def drain():
@@ -460,7 +490,7 @@ def main():
                        "pairs_per_gpu": n, "points_fixed_mean": float(np.mean(nfs)), "points_moving_mean": float(np.mean(nms)),
                        "iterations_mean": float(np.mean(its)), "iterations_max": int(np.max(its)),
                        "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth,
-                       "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": (("RCCL" if backend == "nccl" else backend) + " all_gather of 64-byte result records") if world > 1 else "none (1 GPU)"},
+                       "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": ((("RCCL ncclAllGather enqueued by the C ABI behind each align launch" if gather_mode == "abi" else ("RCCL" if backend == "nccl" else backend) + " all_gather via torch.distributed after the wait") + ", 64-byte result records") if world > 1 else "none (1 GPU)")},
             "roofline": {"bound": "valu_issue", "achieved": valu_rate, "peak": valu_peak, "unit": "wave-instructions/s",
                          "frac": (valu_rate / valu_peak) if valu_rate else None,
                          "traffic": traffic, "kernel": "cvo_align_kernel", "kernel_ms": k_ms,
@@ -520,6 +550,11 @@ def main():
         print(json.dumps(out), flush=True)
 
     if world > 1:
+        if gathered is not None and rank == 0:
+            g = gathered.cpu().numpy()
+            assert g.shape == (world * n, shard.RESULT_FLOATS) and np.all(g[:, 15] == 0), "gathered records incomplete or a rank reported an error"
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -11,4 +11,4 @@ Layout
 The product path never imports oracle/ and has no CPU fallback: if libcvo_hip.so is
 missing or no gfx950 device is visible, calls raise.
 """
-from .api import Cvo, CvoBatch, CvoError, default_params, device_count, lib_path, load_library  # noqa: F401
+from .api import Cvo, CvoBatch, CvoComm, CvoMulti, CvoError, default_params, device_count, lib_path, load_library  # noqa: F401

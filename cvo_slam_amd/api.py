@@ -78,6 +78,8 @@ ABI_SYMBOLS = [
     "cvo_set_pcd_images", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
+    "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
+    "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
 ]
 
 _lib = None
@@ -151,6 +153,18 @@ def load_library():
     L.cvo_batch_compute_innerproduct.argtypes = [vp, C.c_int, C.POINTER(TrackScores)]
     for name in ("cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3"):
         getattr(L, name).argtypes = [C.c_int, C.c_int, fp, fp]
+    L.cvo_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
+    L.cvo_comm_unique_id.argtypes = [C.c_char_p]
+    L.cvo_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.cvo_comm_create_all.argtypes = [ip, C.c_int, C.POINTER(vp)]
+    L.cvo_comm_destroy.argtypes = [vp]
+    L.cvo_batch_gather_results.argtypes = [vp, vp, C.c_int, vp]
+    L.cvo_gather_results.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]
+    L.cvo_multi_create.argtypes = [C.POINTER(Params), ip, C.c_int, C.c_int, C.POINTER(vp)]
+    L.cvo_multi_destroy.argtypes = [vp]
+    L.cvo_multi_batch.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.cvo_multi_align_async.argtypes = [vp, C.c_int]
+    L.cvo_multi_wait.argtypes = [vp, C.c_int, fp]
     _lib = L
     return L
 
@@ -395,6 +409,76 @@ class Cvo:
         _check(self.L.cvo_set_workgroups(self.h, int(g)))
 
 
+RESULT_FLOATS = 16      # CVO_RESULT_FLOATS
+COMM_ID_BYTES = 128     # CVO_COMM_ID_BYTES
+
+
+def shard_range(n_pairs: int, rank: int, world: int) -> range:
+    """cvo_shard_range: the contiguous block of global pair indices `rank` owns."""
+    first = C.c_int(0); count = C.c_int(0)
+    _check(load_library().cvo_shard_range(n_pairs, rank, world, C.byref(first), C.byref(count)))
+    return range(first.value, first.value + count.value)
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().cvo_comm_unique_id(buf))
+    return buf.raw
+
+
+class CvoComm:
+    """One rank's RCCL communicator (one process per GPU): rank 0 makes the id, the launcher broadcasts it."""
+
+    def __init__(self, unique_id: bytes, n_ranks: int, rank: int, device: int = 0):
+        self.L = load_library(); self.h = C.c_void_p(); self.n_ranks = n_ranks; self.rank = rank
+        assert len(unique_id) == COMM_ID_BYTES
+        _check(self.L.cvo_comm_create(unique_id, n_ranks, rank, device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.cvo_comm_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CvoMulti:
+    """Single process, several GPUs: one batch per device, contiguous block sharding, one RCCL all-gather of the result records
+    enqueued behind every device's align launch (cvo_multi_*)."""
+
+    def __init__(self, devices, max_pairs_per_device: int, params: Params | None = None):
+        self.L = load_library(); self.params = params or default_params()
+        self.devices = list(devices); self.max_pairs = max_pairs_per_device
+        dev = (C.c_int * len(self.devices))(*self.devices)
+        self.h = C.c_void_p()
+        _check(self.L.cvo_multi_create(C.byref(self.params), dev, len(self.devices), max_pairs_per_device, C.byref(self.h)))
+
+    def batch(self, i: int) -> "CvoBatch":
+        h = C.c_void_p(); _check(self.L.cvo_multi_batch(self.h, i, C.byref(h)))
+        return CvoBatch._borrow(h, self.max_pairs, self.params)
+
+    def align_async(self, n: int):
+        _check(self.L.cvo_multi_align_async(self.h, n)); self._n = n
+
+    def wait(self, from_device: int = 0):
+        out = np.zeros((len(self.devices) * self._n, RESULT_FLOATS), np.float32)
+        _check(self.L.cvo_multi_wait(self.h, from_device, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.cvo_multi_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CvoBatch:
     """Independent frame pairs aligned in one persistent launch (the
     keyframe<->keyframe batch of keyframe_graph.cpp:622-731; BASELINE configs 3-4)."""
@@ -404,11 +488,24 @@ class CvoBatch:
         self.params = params or default_params()
         self.max_pairs = max_pairs
         self.h = C.c_void_p()
+        self.owned = True
         _check(self.L.cvo_batch_create(C.byref(self.params), device, max_pairs, C.byref(self.h)))
 
+    @classmethod
+    def _borrow(cls, handle, max_pairs, params):
+        """A batch owned by a CvoMulti: same methods, never destroyed from here."""
+        b = cls.__new__(cls)
+        b.L = load_library(); b.params = params; b.max_pairs = max_pairs; b.h = handle; b.owned = False
+        return b
+
+    def gather_results(self, comm: "CvoComm", n: int, recv_device_ptr: int):
+        """pack + ONE ncclAllGather of the first n result records, enqueued behind the last launch on its stream."""
+        _check(self.L.cvo_batch_gather_results(self.h, comm.h, n, C.c_void_p(recv_device_ptr)))
+
     def close(self):
-        if getattr(self, "h", None) and self.h.value:
-            self.L.cvo_batch_destroy(self.h); self.h = C.c_void_p()
+        if getattr(self, "h", None) and self.h.value and getattr(self, "owned", True):
+            self.L.cvo_batch_destroy(self.h)
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:

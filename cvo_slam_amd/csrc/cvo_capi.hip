@@ -7,6 +7,8 @@
 // CVO_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -1195,6 +1197,177 @@ int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stre
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->eng.last_stream;
     hipError_t e = launch_pack_results(static_cast<const PairState*>(b->eng.d_states.p), static_cast<float*>(dst_device), n, s);
     if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pack kernel launch: ") + hipGetErrorString(e));
+    return CVO_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU: RCCL all-gather of the result records
+}  // extern "C"
+
+namespace {
+// RCCL is bound at run time (dlopen) so that single-GPU users of the library do not need it at load time.
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, /* ncclUniqueId by value: 128 bytes */ struct Id128, int) = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+struct Id128 { char b[CVO_COMM_ID_BYTES]; };
+Rccl g_rccl;
+int rccl_load() {
+    if (g_rccl.lib) return CVO_OK;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) return fail(CVO_ERR_HIP, std::string("RCCL not found (librccl.so.1): ") + (dlerror() ? dlerror() : ""));
+#define CVO_RCCL_SYM(field, sym) do { *reinterpret_cast<void**>(&g_rccl.field) = dlsym(h, sym); if (!g_rccl.field) return fail(CVO_ERR_HIP, std::string("RCCL symbol missing: ") + sym); } while (0)
+    CVO_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); CVO_RCCL_SYM(CommInitRank, "ncclCommInitRank"); CVO_RCCL_SYM(CommInitAll, "ncclCommInitAll");
+    CVO_RCCL_SYM(CommDestroy, "ncclCommDestroy"); CVO_RCCL_SYM(AllGather, "ncclAllGather"); CVO_RCCL_SYM(GroupStart, "ncclGroupStart");
+    CVO_RCCL_SYM(GroupEnd, "ncclGroupEnd"); CVO_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef CVO_RCCL_SYM
+    g_rccl.lib = h;
+    return CVO_OK;
+}
+#define RCCL_TRY(expr) do { int r__ = (expr); if (r__ != 0) return fail(CVO_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r__)); } while (0)
+constexpr int RCCL_FLOAT = 7;     // ncclFloat32 (rccl.h)
+}  // namespace
+
+struct cvo_comm_s { void* comm = nullptr; int n_ranks = 1, rank = 0, device = 0; DevBuf send; };
+
+struct cvo_multi_s {
+    int n_devices = 0, max_pairs = 0, last_n = 0;
+    std::vector<int> devices;
+    std::vector<cvo_batch> batches;
+    std::vector<cvo_comm> comms;
+    std::vector<DevBuf> recv;
+};
+
+extern "C" {
+
+int cvo_shard_range(int n_pairs_total, int rank, int n_ranks, int* first, int* count) {
+    if (n_pairs_total < 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks || !first || !count) return fail(CVO_ERR_INVALID, "bad shard arguments");
+    const int base = n_pairs_total / n_ranks, rem = n_pairs_total % n_ranks;      // block sizes differ by at most one
+    *first = rank * base + std::min(rank, rem); *count = base + (rank < rem ? 1 : 0);
+    return CVO_OK;
+}
+int cvo_comm_unique_id(char id[CVO_COMM_ID_BYTES]) {
+    if (!id) return fail(CVO_ERR_INVALID, "null id");
+    int rc = rccl_load(); if (rc) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(id));
+    return CVO_OK;
+}
+int cvo_comm_create(const char id[CVO_COMM_ID_BYTES], int n_ranks, int rank, int device, cvo_comm* out) {
+    if (!id || !out || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(CVO_ERR_INVALID, "bad communicator arguments");
+    int rc = check_device(device, nullptr); if (rc) return rc;
+    rc = rccl_load(); if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    Id128 uid; std::memcpy(uid.b, id, CVO_COMM_ID_BYTES);
+    void* comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, n_ranks, uid, rank));
+    cvo_comm_s* c = new cvo_comm_s(); c->comm = comm; c->n_ranks = n_ranks; c->rank = rank; c->device = device;
+    *out = c;
+    return CVO_OK;
+}
+int cvo_comm_create_all(const int* devices, int n_devices, cvo_comm* out) {
+    if (!devices || !out || n_devices <= 0) return fail(CVO_ERR_INVALID, "bad communicator arguments");
+    for (int i = 0; i < n_devices; ++i) { int rc = check_device(devices[i], nullptr); if (rc) return rc; }
+    int rc = rccl_load(); if (rc) return rc;
+    std::vector<void*> comms(n_devices, nullptr);
+    RCCL_TRY(g_rccl.CommInitAll(comms.data(), n_devices, devices));
+    for (int i = 0; i < n_devices; ++i) {
+        cvo_comm_s* c = new cvo_comm_s(); c->comm = comms[i]; c->n_ranks = n_devices; c->rank = i; c->device = devices[i];
+        out[i] = c;
+    }
+    return CVO_OK;
+}
+int cvo_comm_destroy(cvo_comm c) {
+    if (!c) return fail(CVO_ERR_INVALID, "null communicator");
+    (void)hipSetDevice(c->device);
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    c->send.release();
+    delete c;
+    return CVO_OK;
+}
+namespace {
+// pack kernel + all-gather of batch b's first n records, both on the stream of its last launch
+int enqueue_gather(cvo_batch b, cvo_comm c, int n, void* recv_device) {
+    if (!b || !c || !recv_device || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad gather arguments");
+    if (c->device != b->eng.device) return fail(CVO_ERR_INVALID, "communicator and batch live on different devices");
+    HIP_TRY(hipSetDevice(b->eng.device));
+    int rc = c->send.ensure(sizeof(float) * (size_t)n * CVO_RESULT_FLOATS); if (rc) return rc;
+    hipStream_t s = b->eng.last_stream;
+    hipError_t e = launch_pack_results(static_cast<const PairState*>(b->eng.d_states.p), static_cast<float*>(c->send.p), n, s);
+    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pack kernel launch: ") + hipGetErrorString(e));
+    RCCL_TRY(g_rccl.AllGather(c->send.p, recv_device, (size_t)n * CVO_RESULT_FLOATS, RCCL_FLOAT, c->comm, s));
+    return CVO_OK;
+}
+}  // namespace
+int cvo_batch_gather_results(cvo_batch b, cvo_comm c, int n, void* recv_device) {
+    int rc = rccl_load(); if (rc) return rc;
+    return enqueue_gather(b, c, n, recv_device);
+}
+int cvo_gather_results(cvo_batch* batches, cvo_comm* comms, int n_devices, int n, void* const* recv_device) {
+    if (!batches || !comms || !recv_device || n_devices <= 0) return fail(CVO_ERR_INVALID, "bad gather arguments");
+    int rc = rccl_load(); if (rc) return rc;
+    RCCL_TRY(g_rccl.GroupStart());                                  // one process drives several ranks: their calls must be grouped
+    int first_err = CVO_OK;
+    for (int i = 0; i < n_devices && first_err == CVO_OK; ++i) first_err = enqueue_gather(batches[i], comms[i], n, recv_device[i]);
+    const int ge = g_rccl.GroupEnd();
+    if (first_err) return first_err;
+    if (ge != 0) return fail(CVO_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+    return CVO_OK;
+}
+
+int cvo_multi_create(const cvo_params* p, const int* devices, int n_devices, int max_pairs_per_device, cvo_multi* out) {
+    if (!devices || !out || n_devices <= 0 || max_pairs_per_device <= 0) return fail(CVO_ERR_INVALID, "bad multi arguments");
+    std::unique_ptr<cvo_multi_s> m(new cvo_multi_s());
+    m->n_devices = n_devices; m->max_pairs = max_pairs_per_device; m->devices.assign(devices, devices + n_devices);
+    m->batches.assign(n_devices, nullptr); m->comms.assign(n_devices, nullptr); m->recv.resize(n_devices);
+    int rc = cvo_comm_create_all(devices, n_devices, m->comms.data());
+    for (int i = 0; i < n_devices && !rc; ++i) rc = cvo_batch_create(p, devices[i], max_pairs_per_device, &m->batches[i]);
+    for (int i = 0; i < n_devices && !rc; ++i) {
+        rc = (hipSetDevice(devices[i]) == hipSuccess) ? m->recv[i].ensure(sizeof(float) * (size_t)n_devices * max_pairs_per_device * CVO_RESULT_FLOATS)
+                                                      : fail(CVO_ERR_HIP, "hipSetDevice failed");
+    }
+    if (rc) { const std::string msg = g_err; cvo_multi_destroy(m.release()); g_err = msg; return rc; }
+    *out = m.release();
+    return CVO_OK;
+}
+int cvo_multi_destroy(cvo_multi m) {
+    if (!m) return fail(CVO_ERR_INVALID, "null multi");
+    for (int i = 0; i < m->n_devices; ++i) {
+        if (m->batches[i]) (void)cvo_batch_destroy(m->batches[i]);
+        if (m->comms[i]) (void)cvo_comm_destroy(m->comms[i]);
+        (void)hipSetDevice(m->devices[i]); m->recv[i].release();
+    }
+    delete m;
+    return CVO_OK;
+}
+int cvo_multi_batch(cvo_multi m, int i, cvo_batch* out) {
+    if (!m || !out || i < 0 || i >= m->n_devices) return fail(CVO_ERR_INVALID, "bad device index");
+    *out = m->batches[i];
+    return CVO_OK;
+}
+int cvo_multi_align_async(cvo_multi m, int n) {
+    if (!m || n <= 0 || n > m->max_pairs) return fail(CVO_ERR_INVALID, "bad pair count");
+    for (int i = 0; i < m->n_devices; ++i) { int rc = cvo_batch_align_async(m->batches[i], n, nullptr); if (rc) return rc; }
+    std::vector<void*> recv(m->n_devices);
+    for (int i = 0; i < m->n_devices; ++i) recv[i] = m->recv[i].p;
+    int rc = cvo_gather_results(m->batches.data(), m->comms.data(), m->n_devices, n, recv.data()); if (rc) return rc;
+    m->last_n = n;
+    return CVO_OK;
+}
+int cvo_multi_wait(cvo_multi m, int from_device, float* records_out) {
+    if (!m || from_device < 0 || from_device >= m->n_devices) return fail(CVO_ERR_INVALID, "bad argument");
+    if (m->last_n <= 0) return fail(CVO_ERR_INVALID, "no launch to wait for");
+    for (int i = 0; i < m->n_devices; ++i) { int rc = cvo_batch_wait(m->batches[i], nullptr, 0); if (rc) return rc; }
+    if (records_out) {
+        HIP_TRY(hipSetDevice(m->devices[from_device]));
+        HIP_TRY(hipMemcpy(records_out, m->recv[from_device].p, sizeof(float) * (size_t)m->n_devices * m->last_n * CVO_RESULT_FLOATS, hipMemcpyDeviceToHost));
+    }
     return CVO_OK;
 }
 

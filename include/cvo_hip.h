@@ -226,6 +226,41 @@ int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]);
 #define CVO_RESULT_FLOATS 16
 int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stream);
 
+/* ======================= multi-GPU: shard the pairs, gather the SE(3) records ===========
+ * Frame pairs are independent (loop-closure candidates keyframe_graph.cpp:622-731, offline batches): pair p of P goes to
+ * a contiguous block per rank (block sizes differ by at most one: cvo_shard_range), its clouds live only on the owning GPU, and the ONLY exchange is one RCCL
+ * all-gather of the CVO_RESULT_FLOATS-float result records over xGMI.  RCCL (librccl.so.1) is loaded when the first
+ * communicator is made; a process that never shards does not need it.
+ *
+ * One process per GPU (torch.distributed / MPI launchers): rank 0 calls cvo_comm_unique_id, the host framework
+ * broadcasts the CVO_COMM_ID_BYTES bytes, every rank calls cvo_comm_create (ncclCommInitRank).  One process, several
+ * GPUs: cvo_comm_create_all (ncclCommInitAll).  cvo_batch_gather_results packs the first n records of the batch's last
+ * launch on the device and enqueues ONE ncclAllGather of n*CVO_RESULT_FLOATS floats behind the pack kernel on the
+ * launch's stream: no host synchronisation between align and gather; recv_device (nranks*n records, rank-major) is
+ * valid when that stream has drained (cvo_batch_wait). */
+#define CVO_COMM_ID_BYTES 128
+typedef struct cvo_comm_s* cvo_comm;
+int cvo_shard_range(int n_pairs_total, int rank, int n_ranks, int* first, int* count);    /* contiguous block of rank */
+int cvo_comm_unique_id(char id[CVO_COMM_ID_BYTES]);
+int cvo_comm_create(const char id[CVO_COMM_ID_BYTES], int n_ranks, int rank, int device, cvo_comm* out);
+int cvo_comm_create_all(const int* devices, int n_devices, cvo_comm* out /* n_devices handles */);
+int cvo_comm_destroy(cvo_comm c);
+int cvo_batch_gather_results(cvo_batch b, cvo_comm c, int n, void* recv_device);
+/* single-process form: one batch per device, all n_devices all-gathers inside one RCCL group */
+int cvo_gather_results(cvo_batch* batches, cvo_comm* comms, int n_devices, int n, void* const* recv_device);
+
+/* Convenience object for the single-process case: n_devices batches (one per GPU, max_pairs_per_device each), their
+ * communicators and gather buffers.  cvo_multi_batch hands out device i's batch for cvo_batch_set_pair & co;
+ * cvo_multi_align_async launches every device's batch (n pairs each) and enqueues the gather behind it;
+ * cvo_multi_wait drains the streams and copies the gathered records (n_devices*n, device-major) to the host from
+ * device `from_device`'s copy (every device holds all of them). */
+typedef struct cvo_multi_s* cvo_multi;
+int cvo_multi_create(const cvo_params* p, const int* devices, int n_devices, int max_pairs_per_device, cvo_multi* out);
+int cvo_multi_destroy(cvo_multi m);
+int cvo_multi_batch(cvo_multi m, int i, cvo_batch* out);
+int cvo_multi_align_async(cvo_multi m, int n);
+int cvo_multi_wait(cvo_multi m, int from_device, float* records_out /* n_devices * n * CVO_RESULT_FLOATS */);
+
 /* Loop-closure verification of the aligned pairs (keyframe_graph.cpp:704-717): per pair the
  * compute_innerproduct_lc block (cvo.cpp:505-561: 6 inner products + 2 Hessians, lc_tran = the pair's
  * own align() result, ell = what that align() left behind, Q1) and the reference's accept rule.  All

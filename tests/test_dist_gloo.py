@@ -25,6 +25,15 @@ def test_shard_range_partitions_exactly():
     assert list(shard.shard_range(512, 3, 8)) == list(range(192, 256))     # BASELINE config 4: 64 pairs per GPU
 
 
+def test_c_abi_shard_range_is_the_python_one(hiplib):
+    """cvo_shard_range (include/cvo_hip.h) and shard.shard_range deal the same contiguous blocks (no GPU needed)."""
+    from cvo_slam_amd import api
+    for n in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert list(api.shard_range(n, r, world)) == list(shard.shard_range(n, r, world))
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
