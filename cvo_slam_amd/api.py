@@ -78,6 +78,7 @@ ABI_SYMBOLS = [
     "cvo_set_pcd_images", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
+    "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds",
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
 ]
@@ -153,6 +154,8 @@ def load_library():
     L.cvo_batch_compute_innerproduct.argtypes = [vp, C.c_int, C.POINTER(TrackScores)]
     for name in ("cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3"):
         getattr(L, name).argtypes = [C.c_int, C.c_int, fp, fp]
+    L.cvo_function_inner_product_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, C.POINTER(InnP)]
+    L.cvo_se3_hessian_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, dp, ip]
     L.cvo_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     L.cvo_comm_unique_id.argtypes = [C.c_char_p]
     L.cvo_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
@@ -325,6 +328,18 @@ class Cvo:
     def se3_hessian(self, slot_a, tran_a, slot_b, inliers: int = 0):
         H = np.zeros(36); inl = C.c_int(inliers); t, tp = _tran(tran_a)
         _check(self.L.cvo_se3_hessian(self.h, slot_a, tp, slot_b, H.ctypes.data_as(C.POINTER(C.c_double)), C.byref(inl)))
+        return H.reshape(6, 6), inl.value
+
+    # -- the same two on clouds handed in directly, as the reference's members take them (cvo.hpp:222, 260)
+    def function_inner_product_clouds(self, xyz_a, feat_a, xyz_b, feat_b):
+        a, ap, fa, fap = _cloud_args(xyz_a, feat_a); b, bp, fb, fbp = _cloud_args(xyz_b, feat_b); r = InnP()
+        _check(self.L.cvo_function_inner_product_clouds(self.h, ap, fap, a.shape[0], bp, fbp, b.shape[0], C.byref(r)))
+        return (r.value, r.num, r.num_e)
+
+    def se3_hessian_clouds(self, xyz_a, feat_a, xyz_b, feat_b, inliers: int = 0):
+        a, ap, fa, fap = _cloud_args(xyz_a, feat_a); b, bp, fb, fbp = _cloud_args(xyz_b, feat_b)
+        H = np.zeros(36); inl = C.c_int(inliers)
+        _check(self.L.cvo_se3_hessian_clouds(self.h, ap, fap, a.shape[0], bp, fbp, b.shape[0], H.ctypes.data_as(C.POINTER(C.c_double)), C.byref(inl)))
         return H.reshape(6, 6), inl.value
 
     # -- cvo.cpp:475-503

@@ -664,6 +664,7 @@ struct cvo_handle_s {
     Aff transform, prev_transform, accum_transform;
     int iter = 0, A_nonzero = 0;
     int num_want = 3000;                                             // pcd_generator.cpp:22
+    Cloud scratch_a, scratch_b;                                      // host clouds handed to function_inner_product / se3_Hessian directly
 };
 
 struct cvo_batch_s {
@@ -884,6 +885,35 @@ int cvo_se3_hessian(cvo_handle h, int slot_a, const float* tran_a, int slot_b, d
     const Engine::ScoreReq rq[1] = {{a, tran_a, b, true, h->ell}};
     int rc = h->eng.score_many(rq, 1, r); if (rc) return rc;
     *inliers += (int)r[0][1];                                        // cvo.cpp:708 increments the caller's variable
+    finish_hessian(r[0] + 2, *inliers, H);
+    return CVO_OK;
+}
+
+namespace {
+int stage_clouds(cvo_handle h, const float* xyz_a, const float* feat_a, int n_a, const float* xyz_b, const float* feat_b, int n_b) {
+    if (n_a <= 0 || n_b <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "empty cloud");
+    int rc = h->eng.upload(h->scratch_a, xyz_a, feat_a, n_a); if (rc) return rc;
+    return h->eng.upload(h->scratch_b, xyz_b, feat_b, n_b);
+}
+}  // namespace
+int cvo_function_inner_product_clouds(cvo_handle h, const float* xyz_a, const float* feat_a, int n_a, const float* xyz_b, const float* feat_b, int n_b,
+                                      cvo_inn_p* out) {
+    if (!h || !out) return fail(CVO_ERR_INVALID, "null argument");
+    int rc = stage_clouds(h, xyz_a, feat_a, n_a, xyz_b, feat_b, n_b); if (rc) return rc;
+    double r[1][24];
+    const Engine::ScoreReq rq[1] = {{&h->scratch_a, nullptr, &h->scratch_b, false, h->ell}};
+    rc = h->eng.score_many(rq, 1, r); if (rc) return rc;
+    finish_inn_p(r[0], out);
+    return CVO_OK;
+}
+int cvo_se3_hessian_clouds(cvo_handle h, const float* xyz_a, const float* feat_a, int n_a, const float* xyz_b, const float* feat_b, int n_b,
+                           double H[36], int* inliers) {
+    if (!h || !H || !inliers) return fail(CVO_ERR_INVALID, "null argument");
+    int rc = stage_clouds(h, xyz_a, feat_a, n_a, xyz_b, feat_b, n_b); if (rc) return rc;
+    double r[1][24];
+    const Engine::ScoreReq rq[1] = {{&h->scratch_a, nullptr, &h->scratch_b, true, h->ell}};
+    rc = h->eng.score_many(rq, 1, r); if (rc) return rc;
+    *inliers += (int)r[0][1];                                        // cvo.cpp:708
     finish_hessian(r[0] + 2, *inliers, H);
     return CVO_OK;
 }

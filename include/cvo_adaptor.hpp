@@ -10,11 +10,17 @@
 // (the reference's pcd_generator + DSO PixelSelector) runs on the GPU too (cvo_set_pcd_images); define
 // CVO_ADAPTOR_CPU_PCD to keep the reference's own CPU pcd_generator in front of the boundary instead
 // (it then needs thirdparty/cvo/include/pcd_generator.hpp and its sources in the `cvo` target).
-// NOT compiled in the build container (no Eigen/OpenCV there); the dependency-free twin that IS
-// compiled and run is cvo_slam_amd/csrc/cvo_hip.hpp.
+// The build container has neither Eigen nor OpenCV: there this header is compile-checked (syntax, signatures, every call into the
+// C ABI) against minimal stand-in declarations of the few Eigen / OpenCV / data_type.h names it touches (tests/stubs/,
+// tests/test_adaptor_compiles.py), and its public members are diffed against cvo.hpp:216-276.  The dependency-free twin that is
+// compiled AND run is cvo_slam_amd/csrc/cvo_hip.hpp.
+//
+// Device: the GPU a cvo object lives on is CVO_HIP_DEVICE (environment, default 0) or cvo::cvo::set_default_device(d) before the
+// object is made -- the reference's constructor signature has no room for it.
 #ifndef CVO_H
 #define CVO_H
 
+#include <cstdlib>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -82,6 +88,12 @@ class cvo {
 #endif
     }
     static void to(const cvo_inn_p& a, inn_p& b) { b.value = a.value; b.num = a.num; b.num_e = a.num_e; }
+    static int& default_device_ref() { static int d = -1; return d; }
+    static int pick_device() {
+        if (default_device_ref() >= 0) return default_device_ref();
+        const char* e = std::getenv("CVO_HIP_DEVICE");
+        return e ? std::atoi(e) : 0;
+    }
 
 public:
     bool first_frame = true;          // cvo.hpp:139
@@ -96,9 +108,30 @@ public:
         cam_info.fx = fSettings["Camera.fx"]; cam_info.fy = fSettings["Camera.fy"];
         cam_info.cx = fSettings["Camera.cx"]; cam_info.cy = fSettings["Camera.cy"];
         cam_info.scaling_factor = fSettings["DepthMapFactor"];
-        if (cvo_create(nullptr, 0, &h_) != CVO_OK) std::cerr << "cvo_create: " << cvo_last_error() << "\n";
+        if (cvo_create(nullptr, pick_device(), &h_) != CVO_OK) std::cerr << "cvo_create: " << cvo_last_error() << "\n";
     }
     ~cvo() { cvo_destroy(h_); }
+    static void set_default_device(int device) { default_device_ref() = device; }   // GPU of the objects made from now on (-1: CVO_HIP_DEVICE / 0)
+
+    // function_inner_product(cloud_a, cloud_b), cvo.hpp:222 / cvo.cpp:388-459: on clouds the caller holds (the handle's current ell applies)
+    const inn_p function_inner_product(point_cloud* cloud_a, point_cloud* cloud_b) {
+        cvo_inn_p r = {0.f, 0, 0};
+        static_assert(sizeof(Eigen::Vector3f) == 12, "cloud_t must be 12-byte AoS");
+        if (cvo_function_inner_product_clouds(h_, cloud_a->num_points ? cloud_a->positions[0].data() : nullptr, cloud_a->features.data(), cloud_a->num_points,
+                                              cloud_b->num_points ? cloud_b->positions[0].data() : nullptr, cloud_b->features.data(), cloud_b->num_points, &r) != CVO_OK)
+            std::cerr << "cvo function_inner_product: " << cvo_last_error() << "\n";
+        return inn_p(r.value, r.num, r.num_e);
+    }
+    // se3_Hessian(cloud_a, cloud_b, inliers), cvo.hpp:260 / cvo.cpp:620-759
+    Eigen::Matrix<double, 6, 6> se3_Hessian(point_cloud* cloud_a, point_cloud* cloud_b, int& inliers) {
+        double H[36]; for (int i = 0; i < 36; ++i) H[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        if (cvo_se3_hessian_clouds(h_, cloud_a->num_points ? cloud_a->positions[0].data() : nullptr, cloud_a->features.data(), cloud_a->num_points,
+                                   cloud_b->num_points ? cloud_b->positions[0].data() : nullptr, cloud_b->features.data(), cloud_b->num_points, H, &inliers) != CVO_OK)
+            std::cerr << "cvo se3_Hessian: " << cvo_last_error() << "\n";
+        Eigen::Matrix<double, 6, 6> out;
+        for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) out(r, q) = H[r * 6 + q];
+        return out;
+    }
 
     void set_pcd(const cv::Mat& RGB_img, const cv::Mat& dep_img) {      // cvo.cpp:345-386
         if (!init) { generate_and_upload(RGB_img, dep_img, ptr_fixed_fr.get(), CVO_SLOT_FIXED); sync(); return; }

@@ -134,6 +134,15 @@ int cvo_match_keyframe(cvo_handle h, const float* xyz, const float* feat, int n,
 int cvo_function_inner_product(cvo_handle h, int slot_a, const float* tran_a, int slot_b, cvo_inn_p* out);
 int cvo_se3_hessian(cvo_handle h, int slot_a, const float* tran_a, int slot_b, double H[36], int* inliers /* in/out, accumulated */);
 
+/* The same two members as the reference declares them -- function_inner_product(point_cloud* cloud_a, point_cloud* cloud_b)
+ * cvo.hpp:222 and se3_Hessian(point_cloud* cloud_a, point_cloud* cloud_b, int& inliers) cvo.hpp:260 -- on clouds the caller
+ * holds in host memory (reference layout: n x 3 positions, 5 channel-major feature arrays); the handle's CURRENT ell applies
+ * (cvo.cpp:395, 626) and *inliers accumulates (cvo.cpp:708).  Both clouds are staged in scratch buffers of the handle. */
+int cvo_function_inner_product_clouds(cvo_handle h, const float* xyz_a, const float* feat_a, int n_a,
+                                      const float* xyz_b, const float* feat_b, int n_b, cvo_inn_p* out);
+int cvo_se3_hessian_clouds(cvo_handle h, const float* xyz_a, const float* feat_a, int n_a,
+                           const float* xyz_b, const float* feat_b, int n_b, double H[36], int* inliers /* in/out */);
+
 /* ---- compute_innerproduct  cvo.cpp:475-503 */
 int cvo_compute_innerproduct(cvo_handle h, cvo_inn_p* inn_pre, cvo_inn_p* inn_post, double post_hessian[36],
                              const float tran[12], int* inliers, cvo_inn_p* inn_fixed_pcd,

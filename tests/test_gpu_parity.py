@@ -487,6 +487,30 @@ def test_reset_keyframe_slot_moves(hiplib):
     g.close()
 
 
+def test_score_functions_on_host_clouds_match_slots_and_oracle(hiplib, oracle):
+    """function_inner_product(point_cloud*, point_cloud*) / se3_Hessian(point_cloud*, point_cloud*, int&) as the reference
+    declares them (cvo.hpp:222, 260): clouds handed in directly give what the slot forms and the oracle give."""
+    S = hiplib.api
+    gd = load("small_pair_12.npz")
+    A, B = (gd["fixed_xyz"], gd["fixed_feat"]), (gd["moving_xyz"], gd["moving_feat"])
+    g = hiplib.Cvo(); g.set_pcd(*A); g.set_pcd(*B)
+    o = oracle.OracleCvo(); o.set_pcd(*A); o.set_pcd(*B)
+    for ell in (0.15, 0.06):
+        st = g.get_state(); g.set_state(st["R"], st["T"], ell)
+        so = o.get_state(); o.set_state(so["R"], so["T"], ell)
+        r_slot = g.function_inner_product(S.SLOT_MOVING, None, S.SLOT_FIXED)
+        r_host = g.function_inner_product_clouds(B[0], B[1], A[0], A[1])
+        rc, r_orc = o.function_inner_product(S.SLOT_MOVING, None, S.SLOT_FIXED)
+        assert rc == 0 and r_host == r_slot
+        assert r_host[1] == r_orc[1] and r_host[0] == pytest.approx(r_orc[0], rel=1e-6)
+        H_slot, n_slot = g.se3_hessian(S.SLOT_MOVING, None, S.SLOT_FIXED, inliers=3)
+        H_host, n_host = g.se3_hessian_clouds(B[0], B[1], A[0], A[1], inliers=3)
+        rc, H_orc, n_orc, _ = o.se3_hessian(S.SLOT_MOVING, None, S.SLOT_FIXED)
+        np.testing.assert_array_equal(H_host, H_slot)
+        assert n_host == n_slot == n_orc + 3                              # the caller's counter accumulates (cvo.cpp:708)
+    g.close()
+
+
 def test_reset_keyframe_matches_the_oracle_state_machine(hiplib, oracle):
     """cvo.cpp:591-604 against orc_reset_keyframe, both branches: before any update_previous_pcd (FIXED <- MOVING) and after
     one (FIXED <- PREVIOUS, MOVING -> PREVIOUS); the slots are identified by what an alignment and the inner products on
