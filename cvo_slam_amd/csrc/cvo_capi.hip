@@ -14,7 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -121,6 +124,20 @@ int check_device(int device, int* num_cus) {
     return CVO_OK;
 }
 
+// Co-residency of cooperating workgroups.  The G > 1 workgroups of a pair wait for each other inside the kernel (tagged granules
+// through L2), so all of a launch's workgroups must be resident at the same time.  One launch alone is sized to the CU count, but
+// launches of OTHER handles (tracker thread + back-end thread, keyframe_graph.cpp:212-240; a thread pool of loop-closure checks) share
+// the CUs: with more cooperating workgroups in flight than the device holds, every launch can end up partially resident and spin until
+// the in-kernel timeout.  So the library keeps count, per device and process-wide, of the workgroup slots its G > 1 launches hold; a
+// launch that does not fit takes fewer workgroups per pair (down to G = 1, which waits for nobody and needs no slot), or, when its
+// clouds force G > 1, waits on the host until slots are free.  Results do not depend on G.  Slots are returned when the launch has
+// been waited for (or the handle goes away).  Launches of other processes on the same GPU are outside this count.
+struct SlotBook {
+    std::mutex mu; std::condition_variable cv;
+    std::map<int, int> used;           // device -> workgroup slots held by G > 1 launches
+};
+SlotBook& slot_book() { static SlotBook b; return b; }
+
 // Launch machinery shared by single-object handles and batches.
 struct Engine {
     int device = 0, num_cus = 256;
@@ -139,6 +156,33 @@ struct Engine {
     int per_cu = 1;              // workgroups resident per CU: 1 x 512 threads, or 2 x 256 threads (half the LDS each)
     float last_ms = 0.f;
     bool launched = false;
+    int held_slots = 0;          // workgroup slots this engine's cooperative (G > 1) launch holds in the SlotBook
+    int last_G = 1;              // workgroups per pair of the last launch
+
+    void release_slots() {
+        if (held_slots <= 0) return;
+        SlotBook& b = slot_book();
+        { std::lock_guard<std::mutex> lk(b.mu); b.used[device] -= held_slots; }
+        held_slots = 0;
+        b.cv.notify_all();
+    }
+    // How many workgroups per pair this launch may use (<= G_want, >= g_min) given what other handles hold; takes the slots.
+    int acquire_slots(int G_want, int g_min, int n_pairs) {
+        const int capacity = num_cus * per_cu;
+        SlotBook& b = slot_book();
+        std::unique_lock<std::mutex> lk(b.mu);
+        int& used = b.used[device];
+        used -= held_slots; held_slots = 0;                       // an earlier launch of this engine runs before this one on its stream: same slots
+        for (;;) {
+            int G = G_want;
+            while (G > g_min && G > 1 && std::max(1, std::min(n_pairs, capacity / G)) * G > capacity - used) G /= 2;
+            G = std::max(G, g_min);
+            if (G <= 1) { b.cv.notify_all(); return 1; }          // G = 1 waits for nobody: always safe, no slot
+            const int need = std::max(1, std::min(n_pairs, capacity / G)) * G;
+            if (need <= capacity - used) { used += need; held_slots = need; return G; }
+            b.cv.wait(lk);                                        // the clouds force G > 1 and the device is full: wait for a launch to finish
+        }
+    }
 
     int init(int dev, const cvo_params& prm) {
         device = dev;
@@ -158,6 +202,8 @@ struct Engine {
     void destroy() {
         (void)hipSetDevice(device);
         if (stream) (void)hipStreamSynchronize(stream);
+        if (last_stream && last_stream != stream) (void)hipStreamSynchronize(last_stream);
+        release_slots();
         d_scoredescs.release(); h_scoredescs.release(); h_counts.release();
         for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts, &d_tiles}) b->release();
         for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
@@ -328,6 +374,12 @@ struct Engine {
     // first when upload_states is set; results land in h_states after wait().
     int launch(const std::vector<PairIn>& pairs, const PairState* states_in, bool upload_states, hipStream_t on_stream,
                bool want_trace, int trace_cap) {
+        const int rc = launch_impl(pairs, states_in, upload_states, on_stream, want_trace, trace_cap);
+        if (rc != CVO_OK) release_slots();                            // nothing of this call is on the device
+        return rc;
+    }
+    int launch_impl(const std::vector<PairIn>& pairs, const PairState* states_in, bool upload_states, hipStream_t on_stream,
+                    bool want_trace, int trace_cap) {
         HIP_TRY(hipSetDevice(device));
         const int n = (int)pairs.size();
         if (n <= 0) return fail(CVO_ERR_INVALID, "no pairs to align");
@@ -335,7 +387,9 @@ struct Engine {
         { int rcs = settle_uploads(s); if (rcs) return rcs; }
         int nf_max = 0, nm_max = 0;
         for (const PairIn& p : pairs) { nf_max = std::max(nf_max, p.fixed ? p.fixed->n : 0); nm_max = std::max(nm_max, p.moving ? p.moving->n : 0); }
-        const int G = pick_workgroups(n, nf_max);
+        const int g_floor = std::max(1, (((nf_max + 127) / 128) + (MAX_ROWS_PER_WG / 128) - 1) / (MAX_ROWS_PER_WG / 128));
+        const int G = acquire_slots(pick_workgroups(n, nf_max), g_floor, n);   // fewer workgroups per pair when other handles' cooperative launches hold the CUs
+        last_G = G;
         const int slots = std::max(1, std::min(n, num_cus * per_cu / G));   // every workgroup of the grid must be resident
         const int grid = slots * G;
         const int nf_pad = round_up(std::max(nf_max, 1), 64), nm_pad = round_up(std::max(nm_max, 1), 64);
@@ -453,7 +507,9 @@ struct Engine {
     int wait() {
         HIP_TRY(hipSetDevice(device));
         if (!launched) return fail(CVO_ERR_INVALID, "no launch to wait for");
-        HIP_TRY(hipStreamSynchronize(last_stream));
+        const hipError_t es = hipStreamSynchronize(last_stream);
+        release_slots();                                             // the launch has left the device, whatever it returned
+        if (es != hipSuccess) return fail(CVO_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(es));
         HIP_TRY(hipEventElapsedTime(&last_ms, ev0, ev1));
         return CVO_OK;
     }

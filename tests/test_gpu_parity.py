@@ -548,6 +548,44 @@ def test_reset_keyframe_matches_the_oracle_state_machine(hiplib, oracle):
     g.close()
 
 
+def test_many_threads_with_cooperating_workgroups_never_time_out(hiplib):
+    """12 host threads, each with its own cvo object forced to 32 cooperating workgroups per pair: 384 workgroups wanted, 256 CUs.
+    Workgroups of a pair wait for each other inside the kernel, so unbounded this can leave every launch partially resident
+    until the in-kernel timeout (CVO_ERR_TIMEOUT).  The library bounds the cooperative workgroups in flight per device (later
+    launches take fewer workgroups per pair): every call returns CVO_OK and -- results do not depend on G -- the same bits."""
+    import threading
+    from cvo_slam_amd import synth
+    p = synth.make_pair(3)
+    ref = hiplib.Cvo(); ref.set_workgroups(1); ref.set_pcd(p.fixed.xyz, p.fixed.feat); ref.set_pcd(p.moving.xyz, p.moving.feat); ref.align()
+    want = ref.transform.copy(); want_it = ref.get_iteration_number(); ref.close()
+    n_threads, rounds = 12, 3
+    objs = []
+    for _ in range(n_threads):
+        g = hiplib.Cvo(); g.set_workgroups(32); g.set_pcd(p.fixed.xyz, p.fixed.feat); g.set_pcd(p.moving.xyz, p.moving.feat)
+        objs.append(g)
+    errors, results = [], [None] * n_threads
+    barrier = threading.Barrier(n_threads)
+
+    def work(i):
+        try:
+            for _ in range(rounds):
+                objs[i].set_state(np.eye(3), np.zeros(3), 0.15)
+                barrier.wait()                                       # all twelve launch together
+                objs[i].align()
+            results[i] = (objs[i].transform.copy(), objs[i].get_iteration_number())
+        except Exception as e:                                       # CvoError(6) = CVO_ERR_TIMEOUT would land here
+            errors.append((i, repr(e)))
+            barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errors, errors
+    for tf, it in results:
+        np.testing.assert_array_equal(tf, want); assert it == want_it
+    for g in objs:
+        g.close()
+
+
 # ----------------------------------------------------------------------------- batches
 def test_batch_matches_single_objects_and_warm_start(hiplib, oracle):
     from cvo_slam_amd import synth
