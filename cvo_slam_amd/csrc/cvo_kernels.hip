@@ -520,7 +520,7 @@ struct Ctx {
     const gfloat* fixed; const gfloat* moving;
     int nf, nm, nrows, rows_per, rows_pad, capn, nm_pad, flat_cap, g, G;
     GF4 ybuf; gv2u* surv;
-    gu16* jT; gv2u* ent; gu64* xch;
+    gv2u* jT4; gv2u* ent; gu64* xch;
     size_t fbase;
 };
 __device__ __forceinline__ void pair_rows(int nf, int g, int G, int& rows_per, int& nrows) {
@@ -541,7 +541,7 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
     c.ybuf = GF4{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
     c.surv = (gv2u*)D.surv;
-    c.jT = (gu16*)D.jT + (size_t)g * D.capn * D.rows_pad;
+    c.jT4 = (gv2u*)D.jT + (size_t)g * (D.capn / 4) * D.rows_pad;    // the cull's lists: four 16-bit columns per 8-byte word, word q of local row li at [q][li]
     c.ent = (gv2u*)D.ent + (size_t)g * D.capn * D.rows_pad;
     c.xch = (gu64*)D.xch;
     c.fbase = (size_t)g * c.rows_per * D.capf;
@@ -696,6 +696,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
         const int ngr = tnp >> 5;
         for (int b2 = wave; b2 < nblk2; b2 += nwaves) {
             float x[SWEEP_R][3]; int li[SWEEP_R]; int cnt[SWEEP_R];
+            unsigned long long buf[SWEEP_R];                        // the row's last, not yet full word of four columns
             float blo[4] = {INF, INF, INF, INF}, bhi[4] = {-INF, -INF, -INF, -INF};
 #pragma unroll
             for (int r = 0; r < SWEEP_R; ++r) {
@@ -711,6 +712,11 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                     x[r][0] = x[r][1] = x[r][2] = FAR_ROW;
                 }
                 cnt[r] = (t0 == 0) ? 0 : rowlen[li[r]];
+                buf[r] = 0ull;
+                if (t0 != 0 && (cnt[r] & 3) && cnt[r] < c.capn) {   // a later tile of a large cloud: pick the row's partial word up again
+                    const v2u w = c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]];
+                    buf[r] = ((unsigned long long)w.y << 32) | w.x;
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) { blo[q] = wave_min(blo[q]); bhi[q] = wave_max(bhi[q]); }
@@ -744,7 +750,14 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                         uint32_t ww = w[r];
                         while (ww) {                                // bit 31 = first column of the group: ascending columns
                             const int kbit = __clz(ww);
-                            if (cnt[r] < c.capn) c.jT[(size_t)cnt[r] * c.rows_pad + li[r]] = (uint16_t)(col0 + (uint32_t)kbit);
+                            if (cnt[r] < c.capn) {                  // four hits make one 8-byte store (a 2-byte store per hit was the cull's bottleneck)
+                                buf[r] |= (unsigned long long)(col0 + (uint32_t)kbit) << (16 * (cnt[r] & 3));
+                                if ((cnt[r] & 3) == 3) {
+                                    v2u w; w.x = (unsigned)buf[r]; w.y = (unsigned)(buf[r] >> 32);
+                                    c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]] = w;
+                                    buf[r] = 0ull;
+                                }
+                            }
                             ++cnt[r];
                             ww &= ~(0x80000000u >> kbit);
                         }
@@ -752,7 +765,13 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                 }
             }
 #pragma unroll
-            for (int r = 0; r < SWEEP_R; ++r) rowlen[li[r]] = (uint16_t)cnt[r];   // rowlen has room for the padding rows of the last block pair
+            for (int r = 0; r < SWEEP_R; ++r) {
+                if ((cnt[r] & 3) && cnt[r] < c.capn) {              // the partial word (capn is a multiple of 4: a full list never leaves one)
+                    v2u w; w.x = (unsigned)buf[r]; w.y = (unsigned)(buf[r] >> 32);
+                    c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]] = w;
+                }
+                rowlen[li[r]] = (uint16_t)cnt[r];                   // rowlen has room for the padding rows of the last block pair
+            }
         }
     }
     if (tid == 0) { sh->Rb = Rb; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1; for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i]; }
@@ -991,12 +1010,19 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         const float xi[3] = {lo.x, lo.y, lo.z};
         const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
-        const gu16* jp = c.jT + li;                                 // entry n of this row: jp[n * rows_pad]
+        const gv2u* jp = c.jT4 + li;                                // entries 4q .. 4q+3 of this row: jp[q * rows_pad]
+        static_assert(PF == 4, "the cull packs four columns per word");
         gv2u* ep = c.ent + slot;
         const unsigned stag = (unsigned)slot << 16;
         auto cols = [&](int n0, int (&jo)[PF]) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) jo[u] = (n0 + u < len) ? (int)jp[(size_t)(n0 + u) * c.rows_pad] : 0;
+            for (int u = 0; u < PF; ++u) jo[u] = 0;
+            if (n0 < len) {
+                const v2u w = jp[(size_t)(n0 >> 2) * c.rows_pad];
+                const int q[PF] = {(int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16)};
+#pragma unroll
+                for (int u = 0; u < PF; ++u) jo[u] = (n0 + u < len) ? q[u] : 0;
+            }
         };
         auto feats = [&](const int (&ji)[PF], float4 (&go)[PF]) {
 #pragma unroll
