@@ -26,10 +26,10 @@
 #include "cvo_math.hpp"
 
 namespace cvohip {
-size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap);
+size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab_cols);
 int align_tile_granule();
 int align_blocks_per_cu();
-hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         unsigned launch_tag, const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 hipError_t pcd_launch_pyramid(const uint8_t* bgr, int w, int h, float* I0, float* I1, float* I2, float* dx0, float* dy0, float* abs0, float* abs1, float* abs2,
@@ -410,19 +410,22 @@ struct Engine {
         int y_mode = 0, tile = tile_request > 0 ? round_up(tile_request, tgran) : tile_full;
         if (const char* e = std::getenv("CVO_HIP_Y_MODE")) {                                // test knob: force a layout (must fit)
             y_mode = std::max(0, std::min(2, std::atoi(e)));
-            if (tile_request <= 0) { tile = y_mode == 1 ? tile_full : std::min(tile_full, std::max(tile_rows, 512)); while (tile > tgran && align_shared_bytes(tile, rows_cap, y_mode, nm_pad) > lds_cap) tile -= tgran; }
-            if (align_shared_bytes(tile, rows_cap, y_mode, nm_pad) > lds_cap) return fail(CVO_ERR_INVALID, "CVO_HIP_Y_MODE: the requested LDS layout does not fit");
+            if (tile_request <= 0) { tile = y_mode == 1 ? tile_full : std::min(tile_full, std::max(tile_rows, 512)); while (tile > tgran && align_shared_bytes(tile, rows_cap, y_mode, nm_pad, 0) > lds_cap) tile -= tgran; }
+            if (align_shared_bytes(tile, rows_cap, y_mode, nm_pad, 0) > lds_cap) return fail(CVO_ERR_INVALID, "CVO_HIP_Y_MODE: the requested LDS layout does not fit");
         } else if (tile_request > 0) {
-            if (allow_lds && align_shared_bytes(tile, rows_cap, 1, nm_pad) <= lds_cap) y_mode = 1;
-            else if (allow_lds && align_shared_bytes(tile, rows_cap, 2, nm_pad) <= lds_cap) y_mode = 2;
-            else while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0) > lds_cap) tile -= tgran;
+            if (allow_lds && align_shared_bytes(tile, rows_cap, 1, nm_pad, 0) <= lds_cap) y_mode = 1;
+            else if (allow_lds && align_shared_bytes(tile, rows_cap, 2, nm_pad, 0) <= lds_cap) y_mode = 2;
+            else while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0, 0) > lds_cap) tile -= tgran;
         } else {
-            int t1 = tile_full; while (t1 > 512 && align_shared_bytes(t1, rows_cap, 1, nm_pad) > lds_cap) t1 -= tgran;
-            int t2 = std::min(tile_full, tile_rows); while (t2 > 512 && align_shared_bytes(t2, rows_cap, 2, nm_pad) > lds_cap) t2 -= tgran;
-            if (allow_lds && align_shared_bytes(t1, rows_cap, 1, nm_pad) <= lds_cap) { y_mode = 1; tile = t1; }
-            else if (allow_lds && align_shared_bytes(t2, rows_cap, 2, nm_pad) <= lds_cap) { y_mode = 2; tile = t2; }
-            else { tile = std::min(tile_full, 2048); while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0) > lds_cap) tile -= tgran; }
+            int t1 = tile_full; while (t1 > 512 && align_shared_bytes(t1, rows_cap, 1, nm_pad, 0) > lds_cap) t1 -= tgran;
+            int t2 = std::min(tile_full, tile_rows); while (t2 > 512 && align_shared_bytes(t2, rows_cap, 2, nm_pad, 0) > lds_cap) t2 -= tgran;
+            if (allow_lds && align_shared_bytes(t1, rows_cap, 1, nm_pad, 0) <= lds_cap) { y_mode = 1; tile = t1; }
+            else if (allow_lds && align_shared_bytes(t2, rows_cap, 2, nm_pad, 0) <= lds_cap) { y_mode = 2; tile = t2; }
+            else { tile = std::min(tile_full, 2048); while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0, 0) > lds_cap) tile -= tgran; }
         }
+        // line-search table (cvo_kernels.hip, phase L): 16 bytes per moving point behind the resident cloud, when that fits
+        int tab_cols = 0;
+        if (!std::getenv("CVO_HIP_NO_TABLE") && y_mode != 0 && align_shared_bytes(tile, rows_cap, y_mode, nm_pad, nm_pad) <= (size_t)(160 / per_cu) * 1024 - 512) tab_cols = nm_pad;
         const int rows_per = rows_per_w;
         int block = rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64));
         if (per_cu > 1) block = std::min(block, 256);
@@ -495,7 +498,7 @@ struct Engine {
             xch_zeroed_bytes = d_xch.bytes;
         }
         HIP_TRY(hipEventRecord(ev0, s));
-        hipError_t e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, P);
+        hipError_t e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, P);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));
         launched = true;

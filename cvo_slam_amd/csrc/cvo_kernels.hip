@@ -39,6 +39,7 @@
 #include <stdint.h>
 #include "cvo_device.h"
 #include "cvo_math.hpp"
+#include <algorithm>
 #include <type_traits>
 
 namespace cvohip {
@@ -84,6 +85,7 @@ struct __attribute__((aligned(16))) Shared {
     int y_cap;             // points the LDS-resident moving cloud has room for (stride of the SoA planes)
     int x_lds;             // the fixed points, by slot, sit in the (otherwise idle) cull tile: lx/ly/lz[slot]
     int ctx_rows_per, ctx_nrows;   // this workgroup's share of the current pair's rows (pair_rows)
+    int tab_cols;          // columns the line-search table has room for (0 = no table)
     unsigned launch_tag;   // high 16 bits of every exchange tag: this launch's sequence number (granules of earlier launches never match)
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
 #ifdef CVO_KTRACE
@@ -402,27 +404,48 @@ __device__ __forceinline__ double div6(double x) {
     const double r = __builtin_fma(-6.0, q, x);
     return __builtin_fma(r, y, q);
 }
-// one nonzero of A: adds its B, C, D, E terms (cvo.cpp:282-306)
-__device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float A_ij, const LsConsts& L, double& Bi, double& Ci, double& Di, double& Ei) {
+// The line-search terms of one nonzero (cvo.cpp:282-306) in two parts.  ls_point: what depends on the moving point alone
+// (cvo.cpp:252-264 and the scalar factors Eigen applies to the rows in :288-297), as four float4:
+//   t0 = {s_beta*z1, |z1|^2}   t1 = {2*z2, -z1.z2}   t2 = {-z3, |z2|^2 + 2 z1.z3}   t3 = {2*z4, -}
+// ls_pair: the rest, from df = x_i - y_j.  Evaluated per nonzero in one go (ls_terms), or with the last quarter of the point part
+// ({2*z4, t2.w}) read from a table made once per iteration (phase_linesearch): the float sequence is the same either way.
+template <bool WITH_Z4>
+__device__ __forceinline__ void ls_point(const float4 yj, const LsConsts& L, float4& t0, float4& t1, float4& t2, float4& t3) {
     const float y[3] = {yj.x, yj.y, yj.z};
-    float z1[3], z2[3], z3[3], z4[3], t[3];
+    float z1[3], z2[3], z3[3], t[3];
     cross3(L.omega, y, t); for (int q = 0; q < 3; ++q) z1[q] = t[q] + L.v[q];       // cvo.cpp:254
     mat3_vec(L.O2, y, t);  for (int q = 0; q < 3; ++q) z2[q] = t[q] + L.Ov[q];      // cvo.cpp:255-256
     mat3_vec(L.O3, y, t);  for (int q = 0; q < 3; ++q) z3[q] = t[q] + L.O2v[q];     // cvo.cpp:257-258
-    mat3_vec(L.O4, y, t);  for (int q = 0; q < 3; ++q) z4[q] = t[q] + L.O3v[q];     // cvo.cpp:259-260
     const float nrm = dot3_seq(z1, z1);                                            // cvo.cpp:261
     const float mdot = -dot3_seq(z1, z2);                                          // cvo.cpp:262
-    const float econst = dot3_seq(z2, z2) + 2 * dot3_seq(z1, z3);                  // cvo.cpp:263
-    const float df[3] = {xi[0] - y[0], xi[1] - y[1], xi[2] - y[2]};                // cvo.cpp:286
-    const float beta_ij = sum3f((L.s_beta * z1[0]) * df[0], (L.s_beta * z1[1]) * df[1], (L.s_beta * z1[2]) * df[2]);              // cvo.cpp:288
-    const float gamma_ij = L.s_gamma * (nrm + sum3f((2.f * z2[0]) * df[0], (2.f * z2[1]) * df[1], (2.f * z2[2]) * df[2]));       // cvo.cpp:290-291
-    const float delta_ij = L.s_delta * (mdot + sum3f((-z3[0]) * df[0], (-z3[1]) * df[1], (-z3[2]) * df[2]));                     // cvo.cpp:293-294
-    const float epsil_ij = L.s_gamma * (econst + sum3f((2.f * z4[0]) * df[0], (2.f * z4[1]) * df[1], (2.f * z4[2]) * df[2]));    // cvo.cpp:296-297
+    t0 = make_float4(L.s_beta * z1[0], L.s_beta * z1[1], L.s_beta * z1[2], nrm);   // the row factors of cvo.cpp:288, 290, 293, 296
+    t1 = make_float4(2.f * z2[0], 2.f * z2[1], 2.f * z2[2], mdot);
+    t2 = make_float4(-z3[0], -z3[1], -z3[2], 0.f);
+    if (WITH_Z4) {
+        float z4[3];
+        mat3_vec(L.O4, y, t);  for (int q = 0; q < 3; ++q) z4[q] = t[q] + L.O3v[q]; // cvo.cpp:259-260
+        t2.w = dot3_seq(z2, z2) + 2 * dot3_seq(z1, z3);                            // cvo.cpp:263
+        t3 = make_float4(2.f * z4[0], 2.f * z4[1], 2.f * z4[2], 0.f);
+    }
+}
+__device__ __forceinline__ void ls_pair(const float (&df)[3] /* x_i - y_j, cvo.cpp:286 */, float A_ij, const float4 t0, const float4 t1, const float4 t2, const float4 t3,
+                                        const LsConsts& L, double& Bi, double& Ci, double& Di, double& Ei) {
+    const float beta_ij = sum3f(t0.x * df[0], t0.y * df[1], t0.z * df[2]);                        // cvo.cpp:288
+    const float gamma_ij = L.s_gamma * (t0.w + sum3f(t1.x * df[0], t1.y * df[1], t1.z * df[2]));  // cvo.cpp:290-291
+    const float delta_ij = L.s_delta * (t1.w + sum3f(t2.x * df[0], t2.y * df[1], t2.z * df[2]));  // cvo.cpp:293-294
+    const float epsil_ij = L.s_gamma * (t2.w + sum3f(t3.x * df[0], t3.y * df[1], t3.z * df[2]));  // cvo.cpp:296-297
     Bi += double(A_ij * beta_ij);                                                                                              // cvo.cpp:301
     Ci += double(A_ij * (gamma_ij + beta_ij * beta_ij / 2.0));                                                                 // cvo.cpp:302
     Di += double(A_ij * (delta_ij + beta_ij * gamma_ij + div6((double)(beta_ij * beta_ij * beta_ij))));                        // cvo.cpp:303
     Ei += double(A_ij * (epsil_ij + beta_ij * delta_ij + 1 / 2.0 * beta_ij * beta_ij * gamma_ij                                // cvo.cpp:304-305
                          + 1 / 2.0 * gamma_ij * gamma_ij + 1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij));
+}
+// one nonzero of A: adds its B, C, D, E terms (cvo.cpp:282-306)
+__device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float A_ij, const LsConsts& L, double& Bi, double& Ci, double& Di, double& Ei) {
+    float4 t0, t1, t2, t3;
+    ls_point<true>(yj, L, t0, t1, t2, t3);
+    const float df[3] = {xi[0] - yj.x, xi[1] - yj.y, xi[2] - yj.z};                // cvo.cpp:286
+    ls_pair(df, A_ij, t0, t1, t2, t3, L, Bi, Ci, Di, Ei);
 }
 
 // ---------------------------------------------------------------- S: dense cull
@@ -490,25 +513,30 @@ constexpr int NCLS = 128;             // list-length classes (ceil(len / PF), th
 struct Lds {
     Shared* sh; uint16_t* lenS; uint16_t* row_of; uint16_t* rowlen; int* hist; int* base; float* gbox; float* lx; float* ly; float* lz; float4* ylds;
     float* ysx; float* ysy; float* ysz;
+    float4* tab;
 };
-// Shared | list length per slot | row of a slot | list length per local row | sort histograms | group boxes (8 planes) |
-// cull tile, SoA | resident transformed moving cloud (optional).  The table and cloud sizes are launch parameters kept in Shared.
+// Shared | list length per slot | row of a slot | cull tile, SoA (between culls: the fixed points by slot) | resident transformed moving
+// cloud (optional) | scratch of the list rebuild: list length per local row, sort histograms, group boxes (8 planes).  The line-search
+// table (16 bytes per column) is laid over the scratch, which is dead outside the rebuild.  The table and cloud sizes are launch
+// parameters kept in Shared.
 // tgeo packs the launch's LDS geometry into one scalar every phase receives: tile | rows_cap/64 << 13 | y_cap/64 << 20
 __device__ __forceinline__ int pack_geometry(int tile, int rows_cap, int y_cap) { return tile | ((rows_cap >> 6) << 13) | ((y_cap >> 6) << 20); }
-__device__ __forceinline__ Lds lds_layout(int tgeo) {
+__device__ __forceinline__ Lds lds_layout(int tgeo, int y_mode) {
     Lds L;
     L.sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tile = tgeo & 0x1FFF, rows_cap = ((tgeo >> 13) & 0x7F) << 6, y_cap = ((tgeo >> 20) & 0x7FF) << 6;
     L.lenS = reinterpret_cast<uint16_t*>(cvo_smem + ((sizeof(Shared) + 15) & ~size_t(15)));
     L.row_of = L.lenS + rows_cap;
-    L.rowlen = L.row_of + rows_cap;
-    L.hist = reinterpret_cast<int*>(L.rowlen + rows_cap);
-    L.base = L.hist + MAX_WAVES * NCLS;
-    L.gbox = reinterpret_cast<float*>(L.base + MAX_WAVES * NCLS);
-    L.lx = L.gbox + 8 * (tile >> 5);
+    L.lx = reinterpret_cast<float*>(L.row_of + rows_cap);
     L.ly = L.lx + tile; L.lz = L.ly + tile;
     L.ylds = reinterpret_cast<float4*>(L.lz + tile);
     L.ysx = reinterpret_cast<float*>(L.ylds); L.ysy = L.ysx + y_cap; L.ysz = L.ysy + y_cap;
+    float* behind = L.ysx + (y_mode == 1 ? 4 * (size_t)y_cap : (y_mode == 2 ? 3 * (size_t)y_cap : 0));
+    L.tab = reinterpret_cast<float4*>(behind);
+    L.rowlen = reinterpret_cast<uint16_t*>(behind);
+    L.hist = reinterpret_cast<int*>(L.rowlen + rows_cap);
+    L.base = L.hist + MAX_WAVES * NCLS;
+    L.gbox = reinterpret_cast<float*>(L.base + MAX_WAVES * NCLS);
     return L;
 }
 
@@ -628,7 +656,7 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
 // the layouts of large clouds (12-byte LDS planes, HBM): out of line, nothing pre-loaded -- keeps the common path's code small
 static __device__ __noinline__ void transform_large(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tgeo);
+    const Lds L = lds_layout(tgeo, y_lds);
     const Ctx c = make_ctx(Dp, g, G);
     float4 none[PRE_T];
 #pragma unroll
@@ -637,7 +665,7 @@ static __device__ __noinline__ void transform_large(const PairDesc* Dp_in, int g
 }
 static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tgeo);
+    const Lds L = lds_layout(tgeo, y_lds);
     const Ctx c = make_ctx(Dp, g, G);
     if (y_lds != 1) { transform_large(Dp, g, G, tgeo, y_lds); return; }
     float4 none[PRE_T];
@@ -654,7 +682,7 @@ static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g
 // turns the decisions into a scalar mask the wave then iterates).
 static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tgeo); Shared* sh = L.sh; uint16_t* rowlen = L.rowlen;
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh; uint16_t* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
@@ -787,9 +815,9 @@ __device__ __forceinline__ int len_class(int len) { return min(NCLS - 1, (len + 
 // i-th block of a wave in the serpentine deal
 __device__ __forceinline__ int wave_block(int i, int wave, int nwaves) { return i * nwaves + ((i & 1) ? nwaves - 1 - wave : wave); }
 
-static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, int G_in, int tile_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF;
-    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
+static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
@@ -1123,7 +1151,7 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
 
 static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
@@ -1143,7 +1171,7 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
 
 static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
-    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
@@ -1207,7 +1235,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 // ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
 static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
-    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6;
     float omega[3], v[3];
@@ -1224,20 +1252,60 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
         const bool x_lds = sh->x_lds != 0;
         const int wave = tid >> 6;
         const int cnt_w = sh->wcnt[wave];
+        int cnt_wg = 0;
+        for (int w = 0; w < nwaves; ++w) cnt_wg += sh->wcnt[w];
         const gv2u* sp = c.surv + c.fbase + (size_t)sh->wbase[wave];
-        v2u rnext = sp[min(lane, max(cnt_w - 1, 0))];
-        auto walk = [&](auto ym) {
+        // With several nonzeros per column the last quarter of the point part ({2*z4, |z2|^2 + 2 z1.z3}: 33 of a nonzero's ~120
+        // instructions) is tabulated once per iteration, 16 bytes per column in LDS over the rebuild scratch.  (Tabulating all of
+        // the point part was measured: its four 16-byte gathers per nonzero make the LDS the bottleneck -- 88 against 118 cycles
+        // per 64 nonzeros -- and two table passes need the records binned by column in the candidate phase; one gather does not.)
+        const bool use_table = sh->tab_cols >= c.nm && cnt_wg > 4 * c.nm && y_lds != 0;
+        if (use_table) {
+            for (int j = tid; j < c.nm; j += nthreads) {
+                const float4 yj = y_lds == 1 ? load_y<1>(c, L, j) : load_y<2>(c, L, j);
+                float4 t0, t1, t2, t3;
+                ls_point<true>(yj, ls, t0, t1, t2, t3);
+                L.tab[j] = make_float4(t3.x, t3.y, t3.z, t2.w);
+            }
+            __syncthreads();
+        }
+        // records stream from L2 / HBM: four steps of them are in flight per lane (under load one step's arithmetic is shorter
+        // than a memory round trip)
+        constexpr int RD = 4;
+        auto walk = [&](auto ym, auto tb) {
             constexpr int YM = decltype(ym)::value;
-            for (int q = lane; q < cnt_w; q += 64) {
-                const v2u rec = rnext;
-                rnext = sp[min(q + 64, cnt_w - 1)];                 // next record in flight behind this one's arithmetic
-                const int slot = (int)(rec.y >> 16), j = (int)(rec.y & 0xFFFFu);
-                float xi[3]; load_x(c, L, x_lds, slot, xi);
-                const float4 yj = load_y<YM>(c, L, j);
-                ls_terms(xi, yj, __uint_as_float(rec.x), ls, acc4[0], acc4[1], acc4[2], acc4[3]);
+            constexpr bool TAB = decltype(tb)::value;
+            if (cnt_w <= 0) return;
+            v2u ring[RD];
+#pragma unroll
+            for (int u = 0; u < RD; ++u) ring[u] = sp[min(lane + 64 * u, cnt_w - 1)];
+            for (int q0 = lane; q0 < cnt_w; q0 += 64 * RD) {
+#pragma unroll
+                for (int u = 0; u < RD; ++u) {
+                    const int q = q0 + 64 * u;
+                    const v2u rec = ring[u];
+                    ring[u] = sp[min(q + 64 * RD, cnt_w - 1)];
+                    if (q < cnt_w) {
+                        const int slot = (int)(rec.y >> 16), j = (int)(rec.y & 0xFFFFu);
+                        float xi[3]; load_x(c, L, x_lds, slot, xi);
+                        const float4 yj = load_y<YM>(c, L, j);
+                        if (TAB) {
+                            const float4 tq = L.tab[j];
+                            float4 t0, t1, t2, t3;
+                            ls_point<false>(yj, ls, t0, t1, t2, t3);
+                            t2.w = tq.w; t3 = make_float4(tq.x, tq.y, tq.z, 0.f);
+                            const float df[3] = {xi[0] - yj.x, xi[1] - yj.y, xi[2] - yj.z};            // cvo.cpp:286
+                            ls_pair(df, __uint_as_float(rec.x), t0, t1, t2, t3, ls, acc4[0], acc4[1], acc4[2], acc4[3]);
+                        } else {
+                            ls_terms(xi, yj, __uint_as_float(rec.x), ls, acc4[0], acc4[1], acc4[2], acc4[3]);
+                        }
+                    }
+                }
             }
         };
-        if (y_lds == 1) walk(std::integral_constant<int, 1>{}); else if (y_lds == 2) walk(std::integral_constant<int, 2>{}); else walk(std::integral_constant<int, 0>{});
+        using T1 = std::true_type; using T0 = std::false_type;
+        if (use_table) { if (y_lds == 1) walk(std::integral_constant<int, 1>{}, T1{}); else walk(std::integral_constant<int, 2>{}, T1{}); }
+        else if (y_lds == 1) walk(std::integral_constant<int, 1>{}, T0{}); else if (y_lds == 2) walk(std::integral_constant<int, 2>{}, T0{}); else walk(std::integral_constant<int, 0>{}, T0{});
     } else {
         const Gates gates = make_gates(sh->ell, sh->P);
         for (int li = tid; li < c.nrows; li += nthreads) {
@@ -1272,7 +1340,7 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
 // ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
 static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in, int max_iter_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in), max_iter = uni(max_iter_in);
-    const Lds L = lds_layout(tgeo); Shared* sh = L.sh;
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     // every lane fetches its share of the moving cloud for the NEXT iteration's transform while lane 0 does the scalar work
     float4 pre[PRE_T];
@@ -1339,12 +1407,12 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 }
 
 __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
-                                                                         unsigned launch_tag, DevParams P) {
+                                                                         unsigned launch_tag, int tab_cols, DevParams P) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
     const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
-    if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; }
+    if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
     const int tgeo = pack_geometry(tile, rows_cap, y_cap);
 
     for (int p = slot; p < n_pairs; p += slots) {
@@ -1382,7 +1450,7 @@ __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(cons
                 const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
                 phase_cull(Dp, g, G, tgeo, y_lds);
                 const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
-                phase_sort(Dp, g, G, tgeo);
+                phase_sort(Dp, g, G, tgeo, y_lds);
                 ticks[6] += t_b - t_a; ticks[8] += __builtin_amdgcn_s_memrealtime() - t_b;
             } else if (sh->rebuild == 2) {
                 phase_refine(Dp, g, G, tgeo, y_lds);
@@ -1456,19 +1524,21 @@ int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
 
 // LDS: Shared | slot/row tables (3 x rows_cap u16) | sort histograms | group boxes | cull tile (3*tile floats) | resident y cloud
 // (y_mode 1: 16 B x y_cap, y_mode 2: 12 B x y_cap, y_mode 0: none)
-size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap) {
+// tab_cols: columns of the line-search table (16 bytes each, laid over the rebuild scratch behind the resident cloud; 0 = none)
+size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab_cols) {
     const size_t ybytes = y_mode == 1 ? (size_t)y_cap * sizeof(float4) : (y_mode == 2 ? (size_t)y_cap * 3 * sizeof(float) : 0);
-    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)3 * rows_cap * sizeof(uint16_t) + (size_t)2 * MAX_WAVES * NCLS * sizeof(int) +
-           (size_t)8 * (tile >> 5) * sizeof(float) + (size_t)3 * tile * sizeof(float) + ybytes;
+    const size_t scratch = (size_t)rows_cap * sizeof(uint16_t) + (size_t)2 * MAX_WAVES * NCLS * sizeof(int) + (size_t)8 * (tile >> 5) * sizeof(float);
+    return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)2 * rows_cap * sizeof(uint16_t) + (size_t)3 * tile * sizeof(float) + ybytes +
+           std::max(scratch, (size_t)tab_cols * sizeof(float4));
 }
 int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 
-hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         unsigned launch_tag, const DevParams& P) {
-    const size_t shmem = align_shared_bytes(tile, rows_cap, y_mode, y_cap);
+    const size_t shmem = align_shared_bytes(tile, rows_cap, y_mode, y_cap, tab_cols);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cvo_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_mode, rows_cap, y_cap, launch_tag, P);
+    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_mode, rows_cap, y_cap, launch_tag, tab_cols, P);
     return hipGetLastError();
 }
 

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:    # One HIP runtime per process: torch brings its own copy of libamdhip64; loaded first, libcvo_hip.so binds to that copy too.
+    import torch  # noqa: F401  (the other order -- /opt/rocm's runtime first, torch's second -- leaves torch without a GPU)
+except Exception:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
