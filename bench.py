@@ -222,11 +222,19 @@ def main():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="frame pairs per GPU per step")
     ap.add_argument("--workgroups", type=int, default=1, help="workgroups per pair (0 = auto: lowest latency of one batch alone; 1 = highest throughput)")
     ap.add_argument("--streams", type=int, default=8, help="steps in flight (batch objects on separate HIP streams)")
+    ap.add_argument("--max-workgroups", type=int, default=0, help="cap on the workgroups of one launch (0 = none): its share of the device when several launches run side by side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shape", choices=("tum", "eth3d"), default="tum", help="tum: 640x480, ~3 k points per cloud (the metric's configuration); eth3d: 736x456, ~9.3 k points (BASELINE config 5)")
     ap.add_argument("--gen-workers", type=int, default=0, help="host processes rendering the synthetic pairs (0 = one per host thread, 1 = no fork)")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
     args = ap.parse_args()
+    if args.shape == "eth3d":      # BASELINE config 5 defaults: 4 workgroups per pair, 4 launches side by side, a quarter of the device each
+        dflt = ap.parse_args([])
+        if args.workgroups == dflt.workgroups: args.workgroups = 4
+        if args.streams == dflt.streams: args.streams = 4
+        if args.max_workgroups == dflt.max_workgroups: args.max_workgroups = 64
+        if args.steps == dflt.steps: args.steps = 24
+        if args.warmup == dflt.warmup: args.warmup = 4
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -266,6 +274,8 @@ def main():
     for _ in range(depth):
         b = ca.CvoBatch(args.pairs, device=local_rank)
         b.set_workgroups(args.workgroups)
+        if args.max_workgroups:
+            b.set_max_workgroups(args.max_workgroups)
         for i, (_, fx, ff, mx, mf) in enumerate(pairs):
             b.set_pair(i, fx, ff, mx, mf)
         batches.append(b)

@@ -78,7 +78,7 @@ ABI_SYMBOLS = [
     "cvo_set_pcd_images", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
-    "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds",
+    "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups",
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
 ]
@@ -156,6 +156,7 @@ def load_library():
         getattr(L, name).argtypes = [C.c_int, C.c_int, fp, fp]
     L.cvo_function_inner_product_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, C.POINTER(InnP)]
     L.cvo_se3_hessian_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, dp, ip]
+    L.cvo_batch_set_max_workgroups.argtypes = [vp, C.c_int]
     L.cvo_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     L.cvo_comm_unique_id.argtypes = [C.c_char_p]
     L.cvo_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
@@ -539,6 +540,9 @@ class CvoBatch:
 
     def set_workgroups(self, g: int):
         _check(self.L.cvo_batch_set_workgroups(self.h, int(g)))
+
+    def set_max_workgroups(self, n: int):
+        _check(self.L.cvo_batch_set_max_workgroups(self.h, int(n)))
 
     def reset_states(self):
         _check(self.L.cvo_batch_reset_states(self.h))

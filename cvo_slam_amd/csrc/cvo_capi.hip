@@ -27,10 +27,11 @@
 
 namespace cvohip {
 size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab_cols);
+int align_min_tile(int rows_cap, int y_mode, int y_cap);
 int align_tile_granule();
 int align_blocks_per_cu();
 hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
-                        unsigned launch_tag, const DevParams& P);
+                        unsigned launch_tag, unsigned long long* queue, const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 hipError_t pcd_launch_pyramid(const uint8_t* bgr, int w, int h, float* I0, float* I1, float* I2, float* dx0, float* dy0, float* abs0, float* abs1, float* abs2,
                               hipStream_t s);
@@ -128,13 +129,17 @@ int check_device(int device, int* num_cus) {
 // through L2), so all of a launch's workgroups must be resident at the same time.  One launch alone is sized to the CU count, but
 // launches of OTHER handles (tracker thread + back-end thread, keyframe_graph.cpp:212-240; a thread pool of loop-closure checks) share
 // the CUs: with more cooperating workgroups in flight than the device holds, every launch can end up partially resident and spin until
-// the in-kernel timeout.  So the library keeps count, per device and process-wide, of the workgroup slots its G > 1 launches hold; a
-// launch that does not fit takes fewer workgroups per pair (down to G = 1, which waits for nobody and needs no slot), or, when its
-// clouds force G > 1, waits on the host until slots are free.  Results do not depend on G.  Slots are returned when the launch has
-// been waited for (or the handle goes away).  Launches of other processes on the same GPU are outside this count.
+// the in-kernel timeout.  So the library keeps a book, per device and process-wide, of the cooperative (G > 1) launches in flight and
+// the workgroup slots they hold.  A launch that does not fit beside them takes fewer workgroups per pair -- down to G = 1, which waits
+// for nobody and needs no slot; results do not depend on G.  When its clouds force G > 1 (more than MAX_ROWS_PER_WG rows per
+// workgroup otherwise) it is queued BEHIND the launches in the book instead (hipStreamWaitEvent on their completion events: no host
+// thread ever blocks), so it starts on an empty device.  Entries leave the book when their launch has been waited for or the handle
+// goes away.  Cooperative launches are submitted under the book's lock (acquire -> kernel launch -> completion event), a few
+// microseconds each.  Launches of other processes on the same GPU are outside this book.
 struct SlotBook {
-    std::mutex mu; std::condition_variable cv;
-    std::map<int, int> used;           // device -> workgroup slots held by G > 1 launches
+    struct Holder { const void* engine; int device; int slots; hipEvent_t done; };
+    std::mutex mu;
+    std::vector<Holder> holders;
 };
 SlotBook& slot_book() { static SlotBook b; return b; }
 
@@ -144,7 +149,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
-    DevBuf d_descs, d_states, d_ybuf, d_jT, d_ent, d_surv, d_xch, d_trace, d_tracelen, d_partials;
+    DevBuf d_descs, d_states, d_ybuf, d_jT, d_ent, d_surv, d_xch, d_queue, d_trace, d_tracelen, d_partials;
     PinBuf h_descs, h_states, h_states_in, h_stage, h_partials;   // h_states: final states, written by the kernel itself (mapped pinned memory)
     std::vector<unsigned char> descs_uploaded;                     // what d_descs holds: unchanged descriptors are not sent again
     unsigned launch_seq = 0;
@@ -154,34 +159,36 @@ struct Engine {
     int capf_request = 0;        // flat capacity per row (0 = auto)
     int block_request = 0;       // threads per workgroup (0 = auto)
     int per_cu = 1;              // workgroups resident per CU: 1 x 512 threads, or 2 x 256 threads (half the LDS each)
+    int max_wgs = 0;             // cap on the workgroups of one launch (0 = none): a share of the device for launches that run side by side
     float last_ms = 0.f;
     bool launched = false;
-    int held_slots = 0;          // workgroup slots this engine's cooperative (G > 1) launch holds in the SlotBook
     int last_G = 1;              // workgroups per pair of the last launch
 
     void release_slots() {
-        if (held_slots <= 0) return;
         SlotBook& b = slot_book();
-        { std::lock_guard<std::mutex> lk(b.mu); b.used[device] -= held_slots; }
-        held_slots = 0;
-        b.cv.notify_all();
+        std::lock_guard<std::mutex> lk(b.mu);
+        for (size_t i = 0; i < b.holders.size();) { if (b.holders[i].engine == this) b.holders.erase(b.holders.begin() + i); else ++i; }
     }
-    // How many workgroups per pair this launch may use (<= G_want, >= g_min) given what other handles hold; takes the slots.
-    int acquire_slots(int G_want, int g_min, int n_pairs) {
+    // How many workgroups per pair this launch may use (<= G_want, >= g_min) given the cooperative launches in flight.  Returns with
+    // `lk` locked when the launch is cooperative itself (the caller records its completion event, then unlocks); `wait_for` receives
+    // the completion events the launch has to be queued behind when it does not fit beside the launches in the book.
+    int acquire_slots(int G_want, int g_min, int n_pairs, std::unique_lock<std::mutex>& lk, std::vector<hipEvent_t>& wait_for) {
         const int capacity = num_cus * per_cu;
+        const int share = max_wgs > 0 ? std::min(max_wgs, capacity) : capacity;   // what this launch may take at most
         SlotBook& b = slot_book();
-        std::unique_lock<std::mutex> lk(b.mu);
-        int& used = b.used[device];
-        used -= held_slots; held_slots = 0;                       // an earlier launch of this engine runs before this one on its stream: same slots
-        for (;;) {
-            int G = G_want;
-            while (G > g_min && G > 1 && std::max(1, std::min(n_pairs, capacity / G)) * G > capacity - used) G /= 2;
-            G = std::max(G, g_min);
-            if (G <= 1) { b.cv.notify_all(); return 1; }          // G = 1 waits for nobody: always safe, no slot
-            const int need = std::max(1, std::min(n_pairs, capacity / G)) * G;
-            if (need <= capacity - used) { used += need; held_slots = need; return G; }
-            b.cv.wait(lk);                                        // the clouds force G > 1 and the device is full: wait for a launch to finish
-        }
+        lk = std::unique_lock<std::mutex>(b.mu);
+        for (size_t i = 0; i < b.holders.size();) { if (b.holders[i].engine == this) b.holders.erase(b.holders.begin() + i); else ++i; }   // an earlier launch of this engine precedes this one on its stream
+        int used = 0;
+        for (const SlotBook::Holder& h : b.holders) if (h.device == device) used += h.slots;
+        auto need = [&](int G) { return std::max(1, std::min(n_pairs, share / G)) * G; };
+        int G = std::max(G_want, g_min);
+        while (G > g_min && G > 1 && need(G) > capacity - used) G /= 2;
+        G = std::max(G, g_min);
+        if (G <= 1) { lk.unlock(); return 1; }                        // G = 1 waits for nobody: always safe, not in the book
+        if (need(G) > capacity - used)                                 // forced cooperative launch on a busy device: run after the others
+            for (const SlotBook::Holder& h : b.holders) if (h.device == device) wait_for.push_back(h.done);
+        b.holders.push_back(SlotBook::Holder{this, device, need(G), ev1});
+        return G;
     }
 
     int init(int dev, const cvo_params& prm) {
@@ -206,7 +213,7 @@ struct Engine {
         release_slots();
         d_scoredescs.release(); h_scoredescs.release(); h_counts.release();
         for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts, &d_tiles}) b->release();
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_queue, &d_trace, &d_tracelen, &d_partials}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -388,9 +395,10 @@ struct Engine {
         int nf_max = 0, nm_max = 0;
         for (const PairIn& p : pairs) { nf_max = std::max(nf_max, p.fixed ? p.fixed->n : 0); nm_max = std::max(nm_max, p.moving ? p.moving->n : 0); }
         const int g_floor = std::max(1, (((nf_max + 127) / 128) + (MAX_ROWS_PER_WG / 128) - 1) / (MAX_ROWS_PER_WG / 128));
-        const int G = acquire_slots(pick_workgroups(n, nf_max), g_floor, n);   // fewer workgroups per pair when other handles' cooperative launches hold the CUs
+        std::unique_lock<std::mutex> book_lock; std::vector<hipEvent_t> run_after;
+        const int G = acquire_slots(pick_workgroups(n, nf_max), g_floor, n, book_lock, run_after);   // fewer workgroups per pair beside other handles' cooperative launches
         last_G = G;
-        const int slots = std::max(1, std::min(n, num_cus * per_cu / G));   // every workgroup of the grid must be resident
+        const int slots = std::max(1, std::min(n, (max_wgs > 0 ? std::min(max_wgs, num_cus * per_cu) : num_cus * per_cu) / G));   // every workgroup of the grid must be resident
         const int grid = slots * G;
         const int nf_pad = round_up(std::max(nf_max, 1), 64), nm_pad = round_up(std::max(nm_max, 1), 64);
         int capf = capf_request;
@@ -411,14 +419,17 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_Y_MODE")) {                                // test knob: force a layout (must fit)
             y_mode = std::max(0, std::min(2, std::atoi(e)));
             if (tile_request <= 0) { tile = y_mode == 1 ? tile_full : std::min(tile_full, std::max(tile_rows, 512)); while (tile > tgran && align_shared_bytes(tile, rows_cap, y_mode, nm_pad, 0) > lds_cap) tile -= tgran; }
+            tile = std::max(tile, align_min_tile(rows_cap, y_mode, nm_pad));
             if (align_shared_bytes(tile, rows_cap, y_mode, nm_pad, 0) > lds_cap) return fail(CVO_ERR_INVALID, "CVO_HIP_Y_MODE: the requested LDS layout does not fit");
         } else if (tile_request > 0) {
             if (allow_lds && align_shared_bytes(tile, rows_cap, 1, nm_pad, 0) <= lds_cap) y_mode = 1;
-            else if (allow_lds && align_shared_bytes(tile, rows_cap, 2, nm_pad, 0) <= lds_cap) y_mode = 2;
+            else if (allow_lds && align_shared_bytes(std::max(tile, align_min_tile(rows_cap, 2, nm_pad)), rows_cap, 2, nm_pad, 0) <= lds_cap) { y_mode = 2; tile = std::max(tile, align_min_tile(rows_cap, 2, nm_pad)); }
             else while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0, 0) > lds_cap) tile -= tgran;
         } else {
             int t1 = tile_full; while (t1 > 512 && align_shared_bytes(t1, rows_cap, 1, nm_pad, 0) > lds_cap) t1 -= tgran;
-            int t2 = std::min(tile_full, tile_rows); while (t2 > 512 && align_shared_bytes(t2, rows_cap, 2, nm_pad, 0) > lds_cap) t2 -= tgran;
+            // plane layout: the tile only holds the fixed points by slot (and the rebuild scratch during a rebuild); it is not used for columns
+            const int t2min = align_min_tile(rows_cap, 2, nm_pad);
+            int t2 = std::max(std::min(tile_full, tile_rows), t2min); while (t2 > t2min && align_shared_bytes(t2, rows_cap, 2, nm_pad, 0) > lds_cap) t2 -= tgran;
             if (allow_lds && align_shared_bytes(t1, rows_cap, 1, nm_pad, 0) <= lds_cap) { y_mode = 1; tile = t1; }
             else if (allow_lds && align_shared_bytes(t2, rows_cap, 2, nm_pad, 0) <= lds_cap) { y_mode = 2; tile = t2; }
             else { tile = std::min(tile_full, 2048); while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0, 0) > lds_cap) tile -= tgran; }
@@ -493,12 +504,19 @@ struct Engine {
             std::memcpy(h_states_in.p, states_in, sizeof(PairState) * n);
         }
         launch_seq = (launch_seq + 1) & 0xFFFFu;
+        {   // pair queue of launches with fewer slots than pairs: head word + one mailbox per slot; tags carry the launch number
+            const size_t qbytes = sizeof(unsigned long long) * (size_t)(1 + num_cus * per_cu);
+            const bool fresh = d_queue.bytes < qbytes;
+            if ((rc = d_queue.ensure(qbytes))) return rc;
+            if (fresh || launch_seq == 0) HIP_TRY(hipMemsetAsync(d_queue.p, 0, d_queue.bytes, s));
+        }
         if (G > 1 && (xch_zeroed_bytes != d_xch.bytes || launch_seq == 0)) {
             HIP_TRY(hipMemsetAsync(d_xch.p, 0, d_xch.bytes, s));
             xch_zeroed_bytes = d_xch.bytes;
         }
+        for (hipEvent_t ev : run_after) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         HIP_TRY(hipEventRecord(ev0, s));
-        hipError_t e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, P);
+        hipError_t e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));
         launched = true;
@@ -1153,6 +1171,10 @@ int cvo_batch_set_state(cvo_batch b, int p, const float R[9], const float T[3], 
 int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair) {
     if (!b || workgroups_per_pair < 0) return fail(CVO_ERR_INVALID, "bad argument");
     b->eng.wg_request = workgroups_per_pair; return CVO_OK;
+}
+int cvo_batch_set_max_workgroups(cvo_batch b, int max_workgroups) {
+    if (!b || max_workgroups < 0) return fail(CVO_ERR_INVALID, "bad argument");
+    b->eng.max_wgs = max_workgroups; return CVO_OK;
 }
 int cvo_batch_reset_states(cvo_batch b) { if (!b) return fail(CVO_ERR_INVALID, "null batch"); b->states_dirty = true; return CVO_OK; }
 

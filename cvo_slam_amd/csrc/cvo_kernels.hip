@@ -533,10 +533,13 @@ __device__ __forceinline__ Lds lds_layout(int tgeo, int y_mode) {
     L.ysx = reinterpret_cast<float*>(L.ylds); L.ysy = L.ysx + y_cap; L.ysz = L.ysy + y_cap;
     float* behind = L.ysx + (y_mode == 1 ? 4 * (size_t)y_cap : (y_mode == 2 ? 3 * (size_t)y_cap : 0));
     L.tab = reinterpret_cast<float4*>(behind);
-    L.rowlen = reinterpret_cast<uint16_t*>(behind);
-    L.hist = reinterpret_cast<int*>(L.rowlen + rows_cap);
+    // mode 2 (12-byte planes: large clouds): the cull reads its columns straight from the planes, so the tile is idle during a
+    // rebuild and holds the scratch itself -- the tile region then only has to be large enough for the fixed points by slot
+    float* scratch = (y_mode == 2) ? L.lx : behind;
+    L.gbox = scratch;                                                // 8 planes of (tile/32) floats, or of (y_cap/32) in mode 2
+    L.hist = reinterpret_cast<int*>(L.gbox + 8 * (size_t)((y_mode == 2 ? y_cap : tile) >> 5));
     L.base = L.hist + MAX_WAVES * NCLS;
-    L.gbox = reinterpret_cast<float*>(L.base + MAX_WAVES * NCLS);
+    L.rowlen = reinterpret_cast<uint16_t*>(L.base + MAX_WAVES * NCLS);
     return L;
 }
 
@@ -691,11 +694,14 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     const float thr_cull = Rb * Rb * 1.00001f;
     const float thr_box = thr_cull * 1.001f;                        // box gaps are compared with a margin: a skipped group holds no hit
     const float nthr = -thr_cull;
-    const int gplane = tile >> 5;                                   // stride of the eight bounding-box planes: lo/hi of x, y, z and of y/z
+    const bool planes = y_lds == 2;                                 // columns come straight from the resident y planes: one pass over the whole cloud
+    const int span = planes ? max(c.nm, 1) : tile;
+    const float* colx = planes ? L.ysx : L.lx; const float* coly = planes ? L.ysy : L.ly; const float* colz = planes ? L.ysz : L.lz;
+    const int gplane = (planes ? (((tgeo >> 20) & 0x7FF) << 6) : tile) >> 5;   // stride of the eight bounding-box planes: lo/hi of x, y, z and of y/z
     const int nblk2 = (nrows + 64 * SWEEP_R - 1) / (64 * SWEEP_R);  // row-block pairs of this workgroup
     const float INF = __builtin_inff();
-    for (int t0 = 0; t0 < c.nm; t0 += tile) {
-        const int tn = min(tile, c.nm - t0);
+    for (int t0 = 0; t0 < c.nm; t0 += span) {
+        const int tn = min(span, c.nm - t0);
         const int tnp = (tn + 31) & ~31;
         __syncthreads();                                            // previous tile fully consumed
         for (int jj = tid; jj < tnp; jj += nthreads) {              // a wave's half = one 32-column group
@@ -708,7 +714,8 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                 lo[0] = hi[0] = y.x; lo[1] = hi[1] = y.y; lo[2] = hi[2] = y.z;
                 if (y.z > 1.0e-3f) { lo[3] = hi[3] = y.y / y.z; } else { lo[3] = -INF; hi[3] = INF; }   // behind / at the camera: no slope bound
             }
-            L.lx[jj] = y.x; L.ly[jj] = y.y; L.lz[jj] = y.z;
+            if (!planes) { L.lx[jj] = y.x; L.ly[jj] = y.y; L.lz[jj] = y.z; }
+            else if (jj >= tn) { L.ysx[jj] = FAR_COL; L.ysy[jj] = FAR_COL; L.ysz[jj] = FAR_COL; }   // padding columns of the last group (the planes have room: y_cap is a multiple of 64)
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) {
 #pragma unroll
@@ -771,7 +778,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                     const int gi = gb + __builtin_ctzll(mask);
                     mask &= mask - 1ull;
                     uint32_t w[SWEEP_R];
-                    sweep_group(L.lx, L.ly, L.lz, gi * 32, x, nthr, w);
+                    sweep_group(colx, coly, colz, gi * 32, x, nthr, w);
                     const uint32_t col0 = (uint32_t)(t0 + gi * 32);
 #pragma unroll
                     for (int r = 0; r < SWEEP_R; ++r) {
@@ -1212,7 +1219,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 #pragma unroll
             for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * sw[q]); acc8[3 + q] += (double)(inv_d * sv[q]); }
             acc8[6] += (double)nz;
-            acc8[7] += (double)L.rowlen[li];
+            acc8[7] += (double)(y_lds == 2 ? c.nm : (int)L.rowlen[li]);   // statistics only (in the plane layout the row lengths have been overwritten by now)
         }
     }
     const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
@@ -1407,15 +1414,50 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 }
 
 __global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
-                                                                         unsigned launch_tag, int tab_cols, DevParams P) {
+                                                                         unsigned launch_tag, int tab_cols, unsigned long long* __restrict__ queue_in, DevParams P) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
     const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
     if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
     const int tgeo = pack_geometry(tile, rows_cap, y_cap);
+    gu64* queue = (gu64*)queue_in;
 
-    for (int p = slot; p < n_pairs; p += slots) {
+    // A launch with fewer pair slots than pairs (large clouds: G workgroups per pair, a share of the device per launch) hands the pairs out
+    // dynamically -- alignments have data-dependent iteration counts (33 ... 150), a static deal would leave slots idle behind the longest
+    // pair.  queue[0] = {launch tag, next pair}: the slot's first workgroup takes the next index (a CAS loop: the tag makes a stale word of
+    // an earlier launch start from 0, so nothing has to be cleared between launches) and passes it to the slot's other workgroups through
+    // queue[1 + slot] = {launch tag | pull number, pair}.  With a slot per pair there is nothing to hand out.
+    const bool dynamic = slots < n_pairs;
+    for (unsigned pull = 0;; ++pull) {
+        int p;
+        if (!dynamic) { if (pull) break; p = slot; }
+        else {
+            if (tid == 0) {
+                unsigned long long got = 0;
+                const unsigned long long seq = (unsigned long long)(launch_tag | (pull + 1u)) << 32;
+                if (g == 0) {
+                    unsigned long long old = __hip_atomic_load(&queue[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nw;
+                    do { nw = ((unsigned)(old >> 32) == launch_tag) ? old + 1ull : (((unsigned long long)launch_tag << 32) | 1ull); }
+                    while (!__hip_atomic_compare_exchange_strong(&queue[0], &old, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    got = ((unsigned)(old >> 32) == launch_tag) ? (old & 0xFFFFFFFFull) : 0ull;
+                    if (G > 1) __hip_atomic_store(&queue[1 + slot], seq | got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 8 bytes: the data is its own flag
+                } else {
+                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        const unsigned long long x = __hip_atomic_load(&queue[1 + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((x >> 32) == (seq >> 32)) { got = x & 0xFFFFFFFFull; break; }
+                        if (__builtin_amdgcn_s_memrealtime() - t_start > 300000000ull) { got = 0xFFFFFFFFull; break; }   // 3 s: give up, leave
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                sh->cand = (int)min(got, (unsigned long long)0x7FFFFFFF);   // (re-initialised below for the pair)
+            }
+            __syncthreads();
+            p = sh->cand;
+            __syncthreads();
+            if (p >= n_pairs) break;
+        }
         const PairDesc* Dp = descs + p;
         const int nf = Dp->nf, nm = Dp->nm;
         const int rows_per = ((((nf + ROW_DEAL - 1) / ROW_DEAL) + G - 1) / G) * ROW_DEAL;
@@ -1524,21 +1566,30 @@ int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
 
 // LDS: Shared | slot/row tables (3 x rows_cap u16) | sort histograms | group boxes | cull tile (3*tile floats) | resident y cloud
 // (y_mode 1: 16 B x y_cap, y_mode 2: 12 B x y_cap, y_mode 0: none)
-// tab_cols: columns of the line-search table (16 bytes each, laid over the rebuild scratch behind the resident cloud; 0 = none)
+// tab_cols: columns of the line-search table (16 bytes each, laid over the rebuild scratch behind the resident cloud; 0 = none).
+// y_mode 2: the rebuild scratch lives in the cull tile itself (lds_layout), which therefore has a minimum size (align_min_tile).
+size_t align_scratch_bytes(int tile, int rows_cap, int y_mode, int y_cap) {
+    return (size_t)rows_cap * sizeof(uint16_t) + (size_t)2 * MAX_WAVES * NCLS * sizeof(int) + (size_t)8 * ((y_mode == 2 ? y_cap : tile) >> 5) * sizeof(float);
+}
+int align_min_tile(int rows_cap, int y_mode, int y_cap) {
+    if (y_mode != 2) return 128;
+    const size_t need = align_scratch_bytes(0, rows_cap, 2, y_cap);
+    return (int)(((need + 3 * sizeof(float) - 1) / (3 * sizeof(float)) + 127) / 128 * 128);
+}
 size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab_cols) {
     const size_t ybytes = y_mode == 1 ? (size_t)y_cap * sizeof(float4) : (y_mode == 2 ? (size_t)y_cap * 3 * sizeof(float) : 0);
-    const size_t scratch = (size_t)rows_cap * sizeof(uint16_t) + (size_t)2 * MAX_WAVES * NCLS * sizeof(int) + (size_t)8 * (tile >> 5) * sizeof(float);
+    const size_t scratch = y_mode == 2 ? 0 : align_scratch_bytes(tile, rows_cap, y_mode, y_cap);
     return ((sizeof(Shared) + 15) & ~size_t(15)) + (size_t)2 * rows_cap * sizeof(uint16_t) + (size_t)3 * tile * sizeof(float) + ybytes +
            std::max(scratch, (size_t)tab_cols * sizeof(float4));
 }
 int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 
 hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
-                        unsigned launch_tag, const DevParams& P) {
+                        unsigned launch_tag, unsigned long long* queue, const DevParams& P) {
     const size_t shmem = align_shared_bytes(tile, rows_cap, y_mode, y_cap, tab_cols);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cvo_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_mode, rows_cap, y_cap, launch_tag, tab_cols, P);
+    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_mode, rows_cap, y_cap, launch_tag, tab_cols, queue, P);
     return hipGetLastError();
 }
 

@@ -215,6 +215,10 @@ int cvo_batch_set_pair(cvo_batch b, int p, const float* fixed_xyz, const float* 
 /* warm start / carried ell for pair p (reset_initial + Q1) */
 int cvo_batch_set_state(cvo_batch b, int p, const float R[9], const float T[3], float ell);
 int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair /* 0 = auto: fill the CUs */);
+/* cap on the workgroups one launch of this batch occupies (0 = no cap: up to the whole device).  Launches that are meant to run side
+ * by side (several batches in flight on their own streams) each take a share; a launch with fewer pair slots than pairs hands its pairs
+ * to the slots dynamically, so a slot is never idle behind the longest alignment. */
+int cvo_batch_set_max_workgroups(cvo_batch b, int max_workgroups);
 /* restore every pair's (R,T,ell) to what set_pair/set_state last gave it (bench loops re-run the same inputs) */
 int cvo_batch_reset_states(cvo_batch b);
 /* enqueue one persistent launch aligning pairs [0, n_pairs) on `stream` (a hipStream_t, NULL = the batch's own); asynchronous */

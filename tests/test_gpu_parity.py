@@ -790,3 +790,25 @@ def test_randomized_sweep_against_the_oracle(hiplib):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_stress.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "40 / 40 cases identical to the oracle" in r.stdout
+
+
+def test_dynamic_pair_queue_gives_the_same_results(hiplib):
+    """A launch capped to fewer pair slots than pairs (cvo_batch_set_max_workgroups) hands the pairs to its slots through the
+    in-kernel queue; with one and with several cooperating workgroups per pair, repeated launches: the same bits as a slot per pair."""
+    from cvo_slam_amd import synth
+    pairs = [synth.make_small_pair(900 + i, n=250 + 60 * (i % 4)) for i in range(13)]
+    B = hiplib.CvoBatch(len(pairs))
+    for i, p in enumerate(pairs):
+        B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+    B.set_workgroups(1)
+    want = B.align(len(pairs))
+    for wgs, cap in ((1, 3), (1, 1), (2, 4), (2, 6), (4, 8)):
+        B.set_workgroups(wgs); B.set_max_workgroups(cap)
+        for _ in range(2):
+            B.reset_states()
+            got = B.align(len(pairs))
+            for a, b in zip(want, got):
+                assert b["status"] == 0
+                np.testing.assert_array_equal(a["transform"], b["transform"])
+                assert (a["iter"], a["A_nonzero"], a["iterations_run"]) == (b["iter"], b["A_nonzero"], b["iterations_run"])
+    B.close()
