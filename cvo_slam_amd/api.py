@@ -59,6 +59,17 @@ class LcScores(C.Structure):
                 ("cos_angle", C.c_float), ("accept", C.c_int)]
 
 
+class AdaptiveParams(C.Structure):      # cvo_adaptive_params (adaptive_cvo.cpp:27-46)
+    _fields_ = [("ell_init", C.c_float), ("ell_min", C.c_float), ("ell_max", C.c_float), ("dl_step", C.c_float), ("sigma", C.c_float),
+                ("sp_thres", C.c_float), ("c", C.c_float), ("d", C.c_float), ("c_ell", C.c_float), ("c_sigma", C.c_float),
+                ("max_iter", C.c_int), ("min_step", C.c_float), ("eps", C.c_float), ("eps_2", C.c_float)]
+
+
+class AdaptiveRow(C.Structure):
+    _fields_ = [("omega", C.c_float * 3), ("v", C.c_float * 3), ("dl", C.c_float), ("ell", C.c_float), ("step", C.c_float),
+                ("nnz_xy", C.c_int), ("nnz_xx", C.c_int), ("nnz_yy", C.c_int)]
+
+
 class TrackScores(C.Structure):
     _fields_ = [("inn_pre", InnP), ("inn_post", InnP), ("inn_fixed_pcd", InnP), ("inn_moving_pcd", InnP), ("post_hessian", C.c_double * 36),
                 ("inliers", C.c_int), ("cos_angle", C.c_float)]
@@ -79,6 +90,7 @@ ABI_SYMBOLS = [
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
     "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups",
+    "cvo_adaptive_default_params", "cvo_adaptive_align",
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
 ]
@@ -157,6 +169,8 @@ def load_library():
     L.cvo_function_inner_product_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, C.POINTER(InnP)]
     L.cvo_se3_hessian_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, dp, ip]
     L.cvo_batch_set_max_workgroups.argtypes = [vp, C.c_int]
+    L.cvo_adaptive_default_params.argtypes = [C.POINTER(AdaptiveParams)]
+    L.cvo_adaptive_align.argtypes = [C.c_int, C.POINTER(AdaptiveParams), fp, fp, C.c_int, fp, fp, C.c_int, fp, fp, fp, fp, ip, C.POINTER(AdaptiveRow), C.c_int, ip]
     L.cvo_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     L.cvo_comm_unique_id.argtypes = [C.c_char_p]
     L.cvo_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
@@ -171,6 +185,26 @@ def load_library():
     L.cvo_multi_wait.argtypes = [vp, C.c_int, fp]
     _lib = L
     return L
+
+
+def adaptive_default_params() -> AdaptiveParams:
+    p = AdaptiveParams(); _check(load_library().cvo_adaptive_default_params(C.byref(p))); return p
+
+
+def adaptive_align(fixed_xyz, fixed_feat, moving_xyz, moving_feat, params: AdaptiveParams | None = None, R=None, T=None, trace_cap: int = 0, device: int = 0):
+    """acvo::align (adaptive_cvo.cpp:490-555) on the GPU from a fresh object: dict(transform, R, T, ell, iter, trace)."""
+    L = load_library()
+    p = params or adaptive_default_params()
+    fx, fxp, ff, ffp = _cloud_args(fixed_xyz, fixed_feat); mx, mxp, mf, mfp = _cloud_args(moving_xyz, moving_feat)
+    Rb = np.ascontiguousarray(np.eye(3) if R is None else R, np.float32).reshape(9).copy(); Tb = np.ascontiguousarray(np.zeros(3) if T is None else T, np.float32).copy()
+    tf = np.zeros(12, np.float32); ell = C.c_float(0); it = C.c_int(-1); n = C.c_int(0)
+    rows = (AdaptiveRow * max(1, trace_cap))()
+    fp = C.POINTER(C.c_float)
+    _check(L.cvo_adaptive_align(device, C.byref(p), fxp, ffp, fx.shape[0], mxp, mfp, mx.shape[0], Rb.ctypes.data_as(fp), Tb.ctypes.data_as(fp), C.byref(ell),
+                                tf.ctypes.data_as(fp), C.byref(it), rows if trace_cap else None, trace_cap, C.byref(n)))
+    tr = [dict(omega=np.array(r.omega[:], np.float32), v=np.array(r.v[:], np.float32), dl=r.dl, ell=r.ell, step=r.step,
+               nnz_xy=r.nnz_xy, nnz_xx=r.nnz_xx, nnz_yy=r.nnz_yy) for r in rows[: n.value]]
+    return dict(transform=tf.reshape(3, 4), R=Rb.reshape(3, 3), T=Tb, ell=ell.value, iter=it.value, trace=tr)
 
 
 def selftest_cubic_step(coef_minstep, device: int = 0):

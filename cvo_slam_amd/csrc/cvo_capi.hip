@@ -48,6 +48,7 @@ int score_row_blocks(int na);
 int score_groups(int n);
 size_t score_box_bytes(int n);
 hipError_t launch_cloud_boxes(const float* rec, int n, float* gbox, hipStream_t stream);
+hipError_t launch_adaptive(const AdaptiveArgs& A, hipStream_t stream);
 hipError_t launch_selftest(int kind, const float* in, float* out, int n, hipStream_t s);
 hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
                         double* out_pinned, hipStream_t stream);
@@ -56,6 +57,7 @@ hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, in
 using namespace cvohip;
 
 static_assert(sizeof(cvo_trace_row) == sizeof(TraceRow), "trace row layout");
+static_assert(sizeof(cvo_adaptive_row) == sizeof(AdaptiveRow), "adaptive trace row layout");
 
 namespace {
 
@@ -1124,6 +1126,62 @@ int selftest(int device, int kind, int n, const float* in, int in_w, float* out,
     return CVO_OK;
 }
 }  // namespace
+int cvo_adaptive_default_params(cvo_adaptive_params* p) {
+    if (!p) return fail(CVO_ERR_INVALID, "null params");
+    p->ell_init = 0.1; p->ell_min = 0.0391; p->ell_max = 0.15; p->dl_step = 0.3;
+    p->sigma = 0.1; p->sp_thres = 8.315e-3; p->c = 7.0; p->d = 7.0; p->c_ell = 0.5; p->c_sigma = 1;
+    p->max_iter = 2000; p->min_step = 2 * 1.0e-1; p->eps = 5 * 1.0e-5; p->eps_2 = 1.0e-5;
+    return CVO_OK;
+}
+int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float* fixed_xyz, const float* fixed_feat, int n_fixed,
+                       const float* moving_xyz, const float* moving_feat, int n_moving, float R_inout[9], float T_inout[3], float* ell_out,
+                       float transform_out[12], int* iter, cvo_adaptive_row* trace, int trace_cap, int* trace_len) {
+    if (trace_len) *trace_len = 0;
+    if (!R_inout || !T_inout) return fail(CVO_ERR_INVALID, "null pose");
+    if (n_fixed <= 0 || n_moving <= 0) return fail(CVO_ERR_EMPTY_CLOUD, "adaptive align: empty cloud");
+    cvo_adaptive_params ap; if (p_in) ap = *p_in; else cvo_adaptive_default_params(&ap);
+    cvo_params bp; cvo_default_params(&bp);
+    Engine eng;
+    int rc = eng.init(device, bp); if (rc) return rc;
+    struct Guard { Engine& e; ~Guard() { e.destroy(); } } guard{eng};
+    Cloud fx, mv;
+    if ((rc = eng.upload(fx, fixed_xyz, fixed_feat, n_fixed))) return rc;
+    if ((rc = eng.upload(mv, moving_xyz, moving_feat, n_moving))) return rc;
+    DevBuf d_y, d_state, d_trace, d_len;
+    struct Bufs { DevBuf *a, *b, *c, *d; ~Bufs() { a->release(); b->release(); c->release(); d->release(); } } bufs{&d_y, &d_state, &d_trace, &d_len};
+    const bool want_trace = trace && trace_cap > 0;
+    if ((rc = d_y.ensure(sizeof(float4) * (size_t)n_moving)) || (rc = d_state.ensure(sizeof(AdaptiveState))) ||
+        (rc = d_trace.ensure(sizeof(AdaptiveRow) * (size_t)std::max(1, trace_cap))) || (rc = d_len.ensure(sizeof(int) * 4))) return rc;
+    AdaptiveState st; std::memset(&st, 0, sizeof(st));
+    std::memcpy(st.R, R_inout, sizeof(st.R)); std::memcpy(st.T, T_inout, sizeof(st.T));
+    st.ell = ap.ell_init; st.ell_max = ap.ell_max; st.iter = iter ? *iter : 0; st.status = -1;
+    HIP_TRY(hipMemcpyAsync(d_state.p, &st, sizeof(st), hipMemcpyHostToDevice, eng.stream));
+    HIP_TRY(hipMemsetAsync(d_len.p, 0, sizeof(int) * 4, eng.stream));
+    AdaptiveArgs A; std::memset(&A, 0, sizeof(A));
+    A.fixed = fx.rec(); A.moving = mv.rec(); A.nf = n_fixed; A.nm = n_moving;
+    A.ybuf = static_cast<float4*>(d_y.p); A.state = static_cast<AdaptiveState*>(d_state.p);
+    A.trace = want_trace ? static_cast<AdaptiveRow*>(d_trace.p) : nullptr; A.trace_cap = want_trace ? trace_cap : 0; A.trace_len = static_cast<int*>(d_len.p);
+    A.ell_min = ap.ell_min; A.dl_step = ap.dl_step;
+    A.P.sigma = ap.sigma; A.P.sp_thres = ap.sp_thres; A.P.c = ap.c; A.P.d = ap.d; A.P.c_ell = ap.c_ell; A.P.c_sigma = ap.c_sigma;
+    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f;
+    hipError_t e = launch_adaptive(A, eng.stream);
+    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("adaptive kernel launch: ") + hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(eng.stream));
+    HIP_TRY(hipMemcpy(&st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.status != 0) return fail(CVO_ERR_HIP, "adaptive kernel did not complete");
+    std::memcpy(R_inout, st.R, sizeof(st.R)); std::memcpy(T_inout, st.T, sizeof(st.T));
+    if (ell_out) *ell_out = st.ell;
+    if (transform_out) std::memcpy(transform_out, st.transform, sizeof(float) * 12);
+    if (iter) *iter = st.iter;
+    if (want_trace) {
+        int n = 0; HIP_TRY(hipMemcpy(&n, d_len.p, sizeof(int), hipMemcpyDeviceToHost));
+        n = std::min(n, trace_cap);
+        if (n > 0) HIP_TRY(hipMemcpy(trace, d_trace.p, sizeof(AdaptiveRow) * (size_t)n, hipMemcpyDeviceToHost));
+        if (trace_len) *trace_len = n;
+    }
+    return CVO_OK;
+}
+
 int cvo_selftest_cubic_step(int device, int n, const float* coef_minstep, float* step_out) { return selftest(device, 0, n, coef_minstep, 5, step_out, 1); }
 int cvo_selftest_exp_sek3(int device, int n, const float* omega_v_dt, float* dR_dT_out) { return selftest(device, 1, n, omega_v_dt, 7, dR_dT_out, 12); }
 int cvo_selftest_dist_se3(int device, int n, const float* dR_dT, float* dist_out) { return selftest(device, 2, n, dR_dT, 12, dist_out, 1); }

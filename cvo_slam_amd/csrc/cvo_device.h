@@ -78,6 +78,22 @@ struct PairDesc {
     int* trace_len;
 };
 
+// adaptive-ell variant (acvo::align, thirdparty/cvo/src/adaptive_cvo.cpp:490-555)
+struct AdaptiveRow { float omega[3], v[3], dl, ell, step; int nnz_xy, nnz_xx, nnz_yy; };   // == cvo_adaptive_row
+struct AdaptiveState {
+    float R[9], T[3], ell, ell_max, transform[12];
+    int iter, iterations_run, status;
+};
+struct AdaptiveArgs {
+    const float* fixed; const float* moving;   // two planes of float4 each (lo_off / hi_off)
+    int nf, nm;
+    float4* ybuf;            // nm transformed moving points
+    AdaptiveState* state;    // in/out
+    AdaptiveRow* trace; int trace_cap; int* trace_len;
+    float ell_min, dl_step;
+    DevParams P;
+};
+
 // score kernels (function_inner_product / se3_Hessian)
 struct ScoreDesc {
     const float* a;          // two planes of na float4: queried cloud (positions optionally transformed by tran)

@@ -177,6 +177,26 @@ int cvo_set_state(cvo_handle h, const float R[9], const float T[3], float ell);
 /* number of workgroups that cooperate on this handle's alignment (latency knob; 0 = auto) */
 int cvo_set_workgroups(cvo_handle h, int workgroups_per_pair);
 
+/* ---- adaptive-ell variant of the alignment: acvo::align, thirdparty/cvo/src/adaptive_cvo.cpp:490-555, with its
+ * own constants (adaptive_cvo.cpp:27-46).  Per iteration the kernel matrices Axy, Axx and Ayy at the current ell give the length-scale
+ * gradient dl (:154-272); ell moves by dl_step*dl inside [ell_min, ell_max], ell_max shrinking by 0.7 whenever it is hit (:538-545).
+ * The reference's first loop never fills `sum_diff_yy_2` (:218-226 against :246-262): the rows of Ayy below num_fixed add nothing to
+ * dl, only those from num_fixed on do; reproduced as is.  The reference does not build that file and has no caller for it
+ * (thirdparty/cvo/CMakeLists.txt:66,77-81); its constants presume colour features scaled to [0,1] (c_ell = 0.5), which the shipped
+ * generator does not produce (Q7).  A dense, untuned path: one workgroup per call.  Fresh-object semantics as after acvo::set_pcd
+ * (ell = ell_init, ell_max as given, :476-477); R, T in: the start pose, out: the final one; transform_out = [R^T | -R^T T];
+ * *iter = k at the break (left alone when max_iter is hit).  Clouds as for cvo_set_pcd.  trace may be NULL. */
+typedef struct cvo_adaptive_params {
+    float ell_init, ell_min, ell_max, dl_step;      /* 0.1, 0.0391, 0.15, 0.3        adaptive_cvo.cpp:27-32 */
+    float sigma, sp_thres, c, d, c_ell, c_sigma;    /* 0.1, 8.315e-3, 7, 7, 0.5, 1   adaptive_cvo.cpp:35-42 (c_sp_thres = sp_thres) */
+    int   max_iter; float min_step, eps, eps_2;     /* 2000, 0.2, 5e-5, 1e-5         adaptive_cvo.cpp:44-47 */
+} cvo_adaptive_params;
+typedef struct cvo_adaptive_row { float omega[3], v[3], dl, ell, step; int nnz_xy, nnz_xx, nnz_yy; } cvo_adaptive_row;
+int cvo_adaptive_default_params(cvo_adaptive_params* p);
+int cvo_adaptive_align(int device, const cvo_adaptive_params* p /* NULL = defaults */, const float* fixed_xyz, const float* fixed_feat, int n_fixed,
+                       const float* moving_xyz, const float* moving_feat, int n_moving, float R_inout[9], float T_inout[3], float* ell_out,
+                       float transform_out[12], int* iter, cvo_adaptive_row* trace, int trace_cap, int* trace_len);
+
 /* ---- device self-test of the scalar closed forms the align kernel's epilogue runs once per iteration.  Each call
  * evaluates n cases on the device, one lane per case, with the very device functions the kernel calls:
  *   cubic_step: poly_solver + root selection + clamp, cvo.cpp:76-92,317-333   in: n x {c3, c2, c1, c0, min_step}  out: n steps

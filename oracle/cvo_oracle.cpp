@@ -279,11 +279,12 @@ void transform_pcd(orc_cvo* o) {
     for (int j = 0; j < m.n; ++j) aff_apply(o->transform.m, &m.xyz[(size_t)j * 3], &o->cloud_y[(size_t)j * 3]);
 }
 
-// se_kernel, cvo.cpp:122-184
-void se_kernel(orc_cvo* o, float l, float s2) {
+// se_kernel, cvo.cpp:122-184 (and adaptive_cvo.cpp:92-147, which takes the two clouds as arguments): sparse kernel matrix of
+// cloud a (positions a_xyz, features of cloud A) against cloud b, as CSR with ascending columns.
+void se_kernel_clouds(orc_cvo* o, const float* a_xyz, const Cloud& A, const float* b_xyz, const Cloud& B, float l, float s2,
+                      std::vector<int>& rowptr, std::vector<int>& colv, std::vector<float>& valv) {
     const orc_params& P = o->p;
-    const Cloud& X = *o->fixed; const Cloud& Y = *o->moving;
-    const int N = X.n, M = Y.n;
+    const int N = A.n, M = B.n;
     // float d2_thres = -2.0*l*l*log(sp_thres/s2);            cvo.cpp:125
     const float d2_thres = (float)(-2.0 * l * l * (double)std::log(P.sp_thres / s2));
     // float d2_c_thres = -2.0*c_ell*c_ell*log(sp_thres/c_sigma/c_sigma);   cvo.cpp:126
@@ -291,7 +292,7 @@ void se_kernel(orc_cvo* o, float l, float s2) {
 
     const auto tk0 = std::chrono::steady_clock::now();
     KdTree tree; const KdTree* tp = nullptr;
-    if (o->search_mode == ORC_SEARCH_KDTREE) { tree.build(o->cloud_y.data(), M); tp = &tree; }   // rebuilt every call, cvo.cpp:135-136
+    if (o->search_mode == ORC_SEARCH_KDTREE) { tree.build(b_xyz, M); tp = &tree; }   // rebuilt every call, cvo.cpp:135-136
     const auto tk1 = std::chrono::steady_clock::now();
 
     std::vector<std::vector<int>> cols(N); std::vector<std::vector<float>> vals(N);
@@ -300,11 +301,11 @@ void se_kernel(orc_cvo* o, float l, float s2) {
         std::vector<Match> ms;
 #pragma omp for schedule(dynamic, 64)
         for (int i = 0; i < N; ++i) {
-            radius_matches(o->cloud_y.data(), M, tp, &X.xyz[(size_t)i * 3], d2_thres, true, ms);
+            radius_matches(b_xyz, M, tp, &a_xyz[(size_t)i * 3], d2_thres, true, ms);
             for (const Match& mt : ms) {
                 const float d2 = mt.d2;
                 if (d2 < d2_thres) {                                              // cvo.cpp:166
-                    const float d2_color = feat_d2(X.feat.data(), N, i, Y.feat.data(), M, mt.j);   // cvo.cpp:169
+                    const float d2_color = feat_d2(A.feat.data(), N, i, B.feat.data(), M, mt.j);   // cvo.cpp:169
                     if (d2_color < d2_c_thres) {                                  // cvo.cpp:171
                         const float k = (float)(s2 * std::exp(-d2 / (2.0 * l * l)));                         // cvo.cpp:172
                         const float ck = (float)(P.c_sigma * P.c_sigma * std::exp(-d2_color / (2.0 * P.c_ell * P.c_ell)));   // cvo.cpp:173
@@ -317,19 +318,21 @@ void se_kernel(orc_cvo* o, float l, float s2) {
     }
     const auto tk2 = std::chrono::steady_clock::now();
     // A.setFromTriplets + makeCompressed (cvo.cpp:182-183): CSR, columns ascending
-    o->A_rowptr.assign(N + 1, 0);
-    for (int i = 0; i < N; ++i) o->A_rowptr[i + 1] = o->A_rowptr[i] + (int)cols[i].size();
-    o->A_col.resize(o->A_rowptr[N]); o->A_val.resize(o->A_rowptr[N]);
+    rowptr.assign(N + 1, 0);
+    for (int i = 0; i < N; ++i) rowptr[i + 1] = rowptr[i] + (int)cols[i].size();
+    colv.resize(rowptr[N]); valv.resize(rowptr[N]);
     for (int i = 0; i < N; ++i) {
-        std::copy(cols[i].begin(), cols[i].end(), o->A_col.begin() + o->A_rowptr[i]);
-        std::copy(vals[i].begin(), vals[i].end(), o->A_val.begin() + o->A_rowptr[i]);
+        std::copy(cols[i].begin(), cols[i].end(), colv.begin() + rowptr[i]);
+        std::copy(vals[i].begin(), vals[i].end(), valv.begin() + rowptr[i]);
     }
     const auto tk3 = std::chrono::steady_clock::now();
     o->t_sec[0] += std::chrono::duration<double>(tk1 - tk0).count(); o->t_sec[1] += std::chrono::duration<double>(tk2 - tk1).count();
     o->t_sec[2] += std::chrono::duration<double>(tk3 - tk2).count();
 }
+void se_kernel(orc_cvo* o, float l, float s2) {
+    se_kernel_clouds(o, o->fixed->xyz.data(), *o->fixed, o->cloud_y.data(), *o->moving, l, s2, o->A_rowptr, o->A_col, o->A_val);
+}
 
-// compute_flow, cvo.cpp:187-236
 struct SweepTimer {   // the two sparse sweeps (compute_flow after se_kernel, compute_step_size)
     orc_cvo* o; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     explicit SweepTimer(orc_cvo* p) : o(p) {}
@@ -684,6 +687,100 @@ extern "C" int orc_align(orc_cvo* o, orc_trace_row* trace, int trace_cap, int* t
     o->accum_transform = aff_mul(o->accum_transform, o->transform);               // cvo.cpp:816
     update_tf(o);                                                                 // cvo.cpp:817
     o->cloud_y.clear();                                                           // cvo.cpp:820
+    return 0;
+}
+
+// ---- adaptive-ell variant: acvo::align, adaptive_cvo.cpp:490-555 (see cvo_oracle.h)
+extern "C" void orc_adaptive_default_params(orc_adaptive_params* p) {
+    p->ell_init = 0.1; p->ell_min = 0.0391; p->ell_max = 0.15; p->dl_step = 0.3;                 // adaptive_cvo.cpp:27-32
+    p->sigma = 0.1; p->sp_thres = 8.315e-3; p->c = 7.0; p->d = 7.0; p->c_ell = 0.5; p->c_sigma = 1;   // :35-42
+    p->max_iter = 2000; p->min_step = 2 * 1.0e-1; p->eps = 5 * 1.0e-5; p->eps_2 = 1.0e-5;        // :44-47
+}
+extern "C" int orc_adaptive_align(const orc_adaptive_params* ap, const float* fixed_xyz, const float* fixed_feat, int n_fixed,
+                                  const float* moving_xyz, const float* moving_feat, int n_moving, float R_inout[9], float T_inout[3],
+                                  float* ell_out, float transform_out[12], int* iter, orc_adaptive_row* trace, int trace_cap, int* trace_len,
+                                  int search_mode, int threads) {
+    if (trace_len) *trace_len = 0;
+    if (n_fixed <= 0 || n_moving <= 0) return 2;
+    orc_params bp; orc_default_params(&bp);
+    bp.ell = ap->ell_init; bp.sigma = ap->sigma; bp.sp_thres = ap->sp_thres; bp.c = ap->c; bp.d = ap->d; bp.c_ell = ap->c_ell; bp.c_sigma = ap->c_sigma;
+    bp.max_iter = ap->max_iter; bp.min_step = ap->min_step; bp.eps = ap->eps; bp.eps_2 = ap->eps_2;
+    std::unique_ptr<orc_cvo> holder(orc_create(&bp));
+    orc_cvo* o = holder.get();
+    orc_set_exec(o, search_mode, threads);
+    orc_set_pcd(o, fixed_xyz, fixed_feat, n_fixed); orc_set_pcd(o, moving_xyz, moving_feat, n_moving);
+    std::memcpy(o->R, R_inout, sizeof(o->R)); std::memcpy(o->T, T_inout, sizeof(o->T));
+    o->ell = ap->ell_init;                                                        // set_pcd: ell = ell_init; ell_max = 0.15   adaptive_cvo.cpp:476-477
+    float ell_max = ap->ell_max;
+    const Cloud& X = *o->fixed; const Cloud& Y = *o->moving;
+    const int N = X.n, M = Y.n;
+    const float s2 = ap->sigma * ap->sigma;
+    std::vector<int> xx_rp, xx_c, yy_rp, yy_c; std::vector<float> xx_v, yy_v;
+    for (int k = 0; k < ap->max_iter; ++k) {
+        update_tf(o);                                                             // adaptive_cvo.cpp:497
+        transform_pcd(o);                                                         // :500
+        // compute_flow, adaptive_cvo.cpp:154-272
+        se_kernel(o, o->ell, s2);                                                                                   // Axy  :156
+        se_kernel_clouds(o, X.xyz.data(), X, X.xyz.data(), X, o->ell, s2, xx_rp, xx_c, xx_v);                       // Axx  :159
+        se_kernel_clouds(o, o->cloud_y.data(), Y, o->cloud_y.data(), Y, o->ell, s2, yy_rp, yy_c, yy_v);             // Ayy  :160
+        const float inv_c = 1 / ap->c, inv_d = 1 / ap->d;
+        const float ell_3 = o->ell * o->ell * o->ell;                                                                // :172
+        const float inv_l3 = 1 / ell_3;
+        double dw[3] = {0, 0, 0}, dv[3] = {0, 0, 0}, dl = 0;
+        auto d2_seq = [](const float* a, const float* b) { const float e0 = a[0] - b[0], e1 = a[1] - b[1], e2 = a[2] - b[2]; return (e0 * e0 + e1 * e1) + e2 * e2; };
+        for (int i = 0; i < N; ++i) {                                             // :175-240 (row order fixed here; the reference: TBB, any order)
+            const float* xi = &X.xyz[(size_t)i * 3];
+            float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0}, s_yx = 0.f, s_xx = 0.f;
+            for (int e = o->A_rowptr[i]; e < o->A_rowptr[i + 1]; ++e) {
+                const float* yj = &o->cloud_y[(size_t)o->A_col[e] * 3];
+                const float a = o->A_val[e];
+                float cr[3]; cross3(xi, yj, cr);                                  // :203
+                for (int q = 0; q < 3; ++q) { sw[q] += a * cr[q]; sv[q] += a * (yj[q] - xi[q]); }   // :227-228
+                s_yx += (inv_l3 * a) * d2_seq(yj, xi);                            // (1/ell_3*Ai*sum_diff_yx_2)(0,0)   :231, :205
+            }
+            for (int e = xx_rp[i]; e < xx_rp[i + 1]; ++e) s_xx += (inv_l3 * xx_v[e]) * d2_seq(&X.xyz[(size_t)xx_c[e] * 3], xi);   // :209-215, :234
+            double partial_dl = 0;
+            // :216-226: for i < num_moving the Ayy row is walked but sum_diff_yy_2 is never filled -> it adds 0 (cvo_oracle.h)
+            partial_dl -= double(2 * s_yx);                                       // :231
+            partial_dl += double(s_xx);                                           // :234
+            for (int q = 0; q < 3; ++q) { dw[q] += (double)(inv_c * sw[q]); dv[q] += (double)(inv_d * sv[q]); }   // :227-228, :237-238
+            dl += partial_dl;                                                     // :239
+        }
+        for (int i = N; i < M; ++i) {                                             // :243-266: the rows of Ayy beyond num_fixed, here with the squared norms
+            const float* yi = &o->cloud_y[(size_t)i * 3];
+            float s_yy = 0.f;
+            for (int e = yy_rp[i]; e < yy_rp[i + 1]; ++e) s_yy += (inv_l3 * yy_v[e]) * d2_seq(&o->cloud_y[(size_t)yy_c[e] * 3], yi);
+            dl += double(s_yy);
+        }
+        for (int q = 0; q < 3; ++q) { o->omega[q] = (float)dw[q]; o->v[q] = (float)dv[q]; }                         // :269-270
+        const int nnz_xy = o->A_rowptr[N], nnz_xx = xx_rp[N], nnz_yy = yy_rp[M];
+        const double dlf = dl / (nnz_xx + nnz_yy - 2 * nnz_xy);                   // :271 (dl and dl_step are double members, adaptive_cvo.hpp:76-77)
+        o->A_nonzero = nnz_xy;
+        compute_step_size(o);                                                     // :506, adaptive_cvo.cpp:275-365 = the base sequence
+        if (trace && k < trace_cap) {
+            orc_adaptive_row& tr = trace[k];
+            for (int q = 0; q < 3; ++q) { tr.omega[q] = o->omega[q]; tr.v[q] = o->v[q]; }
+            tr.dl = (float)dlf; tr.ell = o->ell; tr.step = o->step; tr.nnz_xy = nnz_xy; tr.nnz_xx = nnz_xx; tr.nnz_yy = nnz_yy;
+            if (trace_len) *trace_len = k + 1;
+        }
+        const double nw = std::sqrt((double)o->omega[0] * o->omega[0] + (double)o->omega[1] * o->omega[1] + (double)o->omega[2] * o->omega[2]);
+        const double nv = std::sqrt((double)o->v[0] * o->v[0] + (double)o->v[1] * o->v[1] + (double)o->v[2] * o->v[2]);
+        if (nw < ap->eps && nv < ap->eps) { o->iter = k; break; }                 // :509 (norms in double there)
+        float dR[9], dT[3];
+        orc_exp_sek3(o->omega, o->v, o->step, dR, dT);                            // :520
+        float RdT[3]; mat3_vec(o->R, dT, RdT);
+        for (int q = 0; q < 3; ++q) o->T[q] = RdT[q] + o->T[q];                    // :527
+        float Rn[9]; mat3_mul(o->R, dR, Rn); std::memcpy(o->R, Rn, sizeof(Rn));   // :528
+        if (orc_dist_se3(dR, dT) < ap->eps_2) { o->iter = k; break; }             // :531
+        o->ell = (float)(o->ell + (double)ap->dl_step * dlf);                     // :538 (double expression stored into the float member)
+        if (o->ell >= ell_max) { o->ell = (float)(ell_max * 0.7); ell_max = (float)(ell_max * 0.7); }   // :541-544
+        o->ell = (o->ell < ap->ell_min) ? ap->ell_min : o->ell;                   // :545
+    }
+    update_tf(o);                                                                 // :550
+    std::memcpy(R_inout, o->R, sizeof(o->R)); std::memcpy(T_inout, o->T, sizeof(o->T));
+    if (ell_out) *ell_out = o->ell;
+    if (transform_out) std::memcpy(transform_out, o->transform.m, sizeof(float) * 12);
+    if (iter) *iter = o->iter;
     return 0;
 }
 

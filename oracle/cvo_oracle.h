@@ -126,6 +126,29 @@ float orc_dist_se3_f32logm(const float dR[9], const float dT[3]);
 int   orc_test_eigenvalues(int n, const double* A /* n x n row-major */, double* re, double* im, int use_f32);
 int   orc_test_logm(int n, const double* A, double* out, int use_f32);
 
+/* ---- adaptive-ell variant: acvo::align of thirdparty/cvo/src/adaptive_cvo.cpp:490-555 with its own constants
+ * (adaptive_cvo.cpp:27-46).  Per iteration three kernel matrices at the current ell -- Axy, Axx (fixed against itself), Ayy (the
+ * transformed moving cloud against itself) -- give the length-scale gradient dl (adaptive_cvo.cpp:154-272); ell moves by dl_step*dl
+ * inside [ell_min, ell_max], ell_max shrinking by 0.7 whenever it is hit (:539-546).  The reference's compute_flow never fills
+ * `sum_diff_yy_2` in its first loop (:218-226 against :246-262), so the rows of Ayy below num_fixed add nothing to dl and only the
+ * rows from num_fixed on (present when the moving cloud is the larger one) do: reproduced as is.  The reference does not build this
+ * file (thirdparty/cvo/CMakeLists.txt:66,77-81) and ships no caller; c_sp_thres equals sp_thres in its constants and one value serves both. */
+typedef struct orc_adaptive_params {
+    float ell_init, ell_min, ell_max, dl_step;      /* 0.1, 0.0391, 0.15, 0.3   adaptive_cvo.cpp:27-32 */
+    float sigma, sp_thres, c, d, c_ell, c_sigma;    /* 0.1, 8.315e-3, 7, 7, 0.5, 1   :35-42 */
+    int   max_iter; float min_step, eps, eps_2;     /* 2000, 0.2, 5e-5, 1e-5   :44-47 */
+} orc_adaptive_params;
+typedef struct orc_adaptive_row {   /* one iteration */
+    float omega[3], v[3], dl, ell, step; int nnz_xy, nnz_xx, nnz_yy;
+} orc_adaptive_row;
+void orc_adaptive_default_params(orc_adaptive_params* p);
+/* fresh-object semantics (set_pcd resets ell = ell_init, ell_max = 0.15, adaptive_cvo.cpp:476-477; R = I, T = 0 unless given).
+ * transform_out = final [R^T | -R^T T]; *iter = k at the break (unchanged if max_iter is hit); returns 0, or 2 for an empty cloud. */
+int orc_adaptive_align(const orc_adaptive_params* p, const float* fixed_xyz, const float* fixed_feat, int n_fixed,
+                       const float* moving_xyz, const float* moving_feat, int n_moving, float R_inout[9], float T_inout[3],
+                       float* ell_out, float transform_out[12], int* iter, orc_adaptive_row* trace, int trace_cap, int* trace_len,
+                       int search_mode, int threads);
+
 /* one iteration's pieces, exposed for kernel-level parity */
 int  orc_flow_once(orc_cvo* o, float omega[3], float v[3], int* nnz, double BCDE[4], float* step,
                    int* csr_rowptr /* nf+1 or NULL */, int* csr_col /* cap or NULL */,

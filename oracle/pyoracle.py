@@ -60,6 +60,17 @@ class InnP(C.Structure):
     _fields_ = [("value", C.c_float), ("num", C.c_int), ("num_e", C.c_int)]
 
 
+class AdaptiveParams(C.Structure):
+    _fields_ = [("ell_init", C.c_float), ("ell_min", C.c_float), ("ell_max", C.c_float), ("dl_step", C.c_float), ("sigma", C.c_float),
+                ("sp_thres", C.c_float), ("c", C.c_float), ("d", C.c_float), ("c_ell", C.c_float), ("c_sigma", C.c_float),
+                ("max_iter", C.c_int), ("min_step", C.c_float), ("eps", C.c_float), ("eps_2", C.c_float)]
+
+
+class AdaptiveRow(C.Structure):
+    _fields_ = [("omega", C.c_float * 3), ("v", C.c_float * 3), ("dl", C.c_float), ("ell", C.c_float), ("step", C.c_float),
+                ("nnz_xy", C.c_int), ("nnz_xx", C.c_int), ("nnz_yy", C.c_int)]
+
+
 class TraceRow(C.Structure):
     _fields_ = [("omega", C.c_float * 3), ("v", C.c_float * 3), ("nnz", C.c_int), ("B", C.c_double), ("C", C.c_double),
                 ("D", C.c_double), ("E", C.c_double), ("step", C.c_float), ("ell", C.c_float), ("dist", C.c_float)]
@@ -261,6 +272,27 @@ class OracleCvo:
         rc = self.L.orc_flow_once(self.h, om.ctypes.data_as(fp), v.ctypes.data_as(fp), C.byref(nnz),
                                   bcde.ctypes.data_as(C.POINTER(C.c_double)), C.byref(step), None, None, None, 0)
         return rc, dict(omega=om, v=v, nnz=nnz.value, BCDE=bcde, step=step.value)
+
+
+def adaptive_default_params() -> AdaptiveParams:
+    p = AdaptiveParams(); lib().orc_adaptive_default_params(C.byref(p)); return p
+
+
+def adaptive_align(fixed_xyz, fixed_feat, moving_xyz, moving_feat, params: AdaptiveParams | None = None, R=None, T=None, trace_cap=0,
+                   search=SEARCH_KDTREE, threads=1):
+    """acvo::align (adaptive_cvo.cpp:490-555) from a fresh object: dict(transform, R, T, ell, iter, trace)."""
+    L = lib(); L.orc_adaptive_align.restype = C.c_int
+    p = params or adaptive_default_params()
+    fx, fxp = _f(fixed_xyz); ff, ffp = _f(fixed_feat); mx, mxp = _f(moving_xyz); mf, mfp = _f(moving_feat)
+    Rb = np.ascontiguousarray(np.eye(3) if R is None else R, np.float32).reshape(9).copy(); Tb = np.ascontiguousarray(np.zeros(3) if T is None else T, np.float32).copy()
+    tf = np.zeros(12, np.float32); ell = C.c_float(0); it = C.c_int(-1); n = C.c_int(0)
+    rows = (AdaptiveRow * max(1, trace_cap))()
+    fp = C.POINTER(C.c_float)
+    rc = L.orc_adaptive_align(C.byref(p), fxp, ffp, fx.shape[0], mxp, mfp, mx.shape[0], Rb.ctypes.data_as(fp), Tb.ctypes.data_as(fp), C.byref(ell),
+                              tf.ctypes.data_as(fp), C.byref(it), rows, trace_cap, C.byref(n), search, threads)
+    tr = [dict(omega=np.array(r.omega[:], np.float32), v=np.array(r.v[:], np.float32), dl=r.dl, ell=r.ell, step=r.step,
+               nnz_xy=r.nnz_xy, nnz_xx=r.nnz_xx, nnz_yy=r.nnz_yy) for r in rows[: n.value]]
+    return rc, dict(transform=tf.reshape(3, 4), R=Rb.reshape(3, 3), T=Tb, ell=ell.value, iter=it.value, trace=tr)
 
 
 def cubic_step(c3, c2, c1, c0, min_step=0.2):
