@@ -466,8 +466,8 @@ def main():
         traffic = valu_instr = pmc_src = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("shape", "tum") == args.shape and int(pmc.get("pairs", n)) == n:
+                pmc = json.load(f).get(args.shape, {})
+            if pmc and int(pmc.get("pairs", n)) == n:
                 traffic = float(pmc["hbm_bytes_per_launch"]); valu_instr = float(pmc.get("valu_wave_instructions_per_launch", 0)) or None
                 pmc_src = pmc.get("source")
         except Exception:

@@ -1,8 +1,9 @@
 #!/bin/bash
 # PMC passes for the align kernel: one rocprofv3 run per counter group (no trace domains),
 # each under its own timeout, progress appended to <outdir>/progress.log.
-# usage: scripts/pmc_run.sh <outdir> <pass> [<pass> ...]     passes: sq1 sq2 sq3 fetch write tcc
+# usage: [BENCH_ARGS="..."] scripts/pmc_run.sh <outdir> <pass> [<pass> ...]     passes: sq1 sq2 sq3 fetch write tcc
 OUT=${1:-gpurun_out/pmc}; shift
+BENCH_ARGS=${BENCH_ARGS:---steps 3 --warmup 1 --streams 1}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 declare -A C
@@ -13,8 +14,8 @@ C[fetch]="FETCH_SIZE"
 C[write]="WRITE_SIZE"
 C[tcc]="TCC_HIT_sum TCC_MISS_sum"
 for name in "$@"; do
-  echo "$(date +%T) start $name: ${C[$name]}" >> $OUT/progress.log
-  timeout -k 5 150 rocprofv3 --pmc ${C[$name]} --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency-probe --gen-workers 1 --streams 1 > $OUT/$name.log 2>&1
+  echo "$(date +%T) start $name: ${C[$name]}  [bench.py $BENCH_ARGS]" >> $OUT/progress.log
+  timeout -k 5 200 rocprofv3 --pmc ${C[$name]} --output-format csv -d $OUT/$name -- python3 bench.py $BENCH_ARGS --no-cpu-baseline --no-latency-probe > $OUT/$name.log 2>&1
   echo "$(date +%T) end $name rc=$?" >> $OUT/progress.log
 done
 cat $OUT/progress.log
