@@ -451,16 +451,16 @@ struct Engine {
         if ((rc = h_states.ensure(sizeof(PairState) * n))) return rc;
         if ((rc = h_states_in.ensure(sizeof(PairState) * n))) return rc;
         if (2 * (long long)P.max_iter + 2 >= 65536) return fail(CVO_ERR_INVALID, "max_iter must be below 32767");
-        if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)n * G * nm_pad))) return rc;
+        if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)slots * G * nm_pad))) return rc;   // work buffers: per pair SLOT of the launch
         const size_t plane = (size_t)G * rows_per * capf;                   // workgroup g's nonzero records start at g * rows_per * capf
         const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
         int capn = 64; while (capn < nm_max / 3 && capn < 4096) capn *= 2;   // longest list a row may have: 1024 at 3 k points, 4096 at 10 k
         if (const char* e = std::getenv("CVO_HIP_ROW_CAP")) capn = std::max(1, std::atoi(e));
         capn = std::max(8, round_up(capn, 4));                               // the candidate phase reads entries four at a time, one step ahead
         const size_t tplane = (size_t)G * capn * rows_pad;
-        if ((rc = d_jT.ensure(sizeof(uint16_t) * (size_t)n * tplane))) return rc;
-        if ((rc = d_ent.ensure(sizeof(uint2) * (size_t)n * tplane))) return rc;
-        if ((rc = d_surv.ensure(sizeof(uint2) * (size_t)n * plane))) return rc;
+        if ((rc = d_jT.ensure(sizeof(uint16_t) * (size_t)slots * tplane))) return rc;
+        if ((rc = d_ent.ensure(sizeof(uint2) * (size_t)slots * tplane))) return rc;
+        if ((rc = d_surv.ensure(sizeof(uint2) * (size_t)slots * plane))) return rc;
         const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n * 2 * G * XCH_WORDS;
         if ((rc = d_xch.ensure(xch_bytes))) return rc;
         if (want_trace) {
@@ -478,11 +478,12 @@ struct Engine {
             D.nf = pairs[i].fixed ? pairs[i].fixed->n : 0;
             D.nm = pairs[i].moving ? pairs[i].moving->n : 0;
             D.nf_pad = nf_pad; D.rows_pad = rows_pad; D.capf = capf; D.nm_pad = nm_pad;
-            D.ybuf = static_cast<float4*>(d_ybuf.p) + (size_t)i * G * nm_pad;
+            D.ybuf = static_cast<float4*>(d_ybuf.p);
+            D.ws_y_stride = (long long)G * nm_pad; D.ws_list_stride = (long long)tplane; D.ws_surv_stride = (long long)plane;
             D.capn = capn;
-            D.jT = static_cast<uint16_t*>(d_jT.p) + (size_t)i * tplane;
-            D.ent = static_cast<uint2*>(d_ent.p) + (size_t)i * tplane;
-            D.surv = static_cast<uint2*>(d_surv.p) + (size_t)i * plane;
+            D.jT = static_cast<uint16_t*>(d_jT.p);
+            D.ent = static_cast<uint2*>(d_ent.p);
+            D.surv = static_cast<uint2*>(d_surv.p);
             D.xch = static_cast<unsigned long long*>(d_xch.p) + (size_t)i * 2 * G * XCH_WORDS;
             D.state = static_cast<PairState*>(d_states.p) + i;
             D.state_in = upload_states ? static_cast<const PairState*>(h_states_in.p) + i : D.state;

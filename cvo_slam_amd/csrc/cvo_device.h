@@ -65,6 +65,10 @@ struct PairDesc {
     int capf;                // flat capacity per row, on average (a workgroup owning r rows may hold r*capf candidates)
     float4* ybuf;            // [G][nm_pad]     transformed moving points {y0,y1,y2,g0} (used when the cloud does not fit in LDS)
     // survivor planes: (nf_pad + G) * capf entries; workgroup g owns [g*rows_per*capf, (g+1)*rows_per*capf)
+    // The work buffers below belong to the launch's pair SLOTS, not to the pairs: the pointers are slot 0's, slot s (= blockIdx.x / G)
+    // adds s * the strides.  A slot aligns one pair after the other (in-kernel pair queue), so a launch with fewer slots than pairs
+    // needs slots x, not pairs x, the memory.
+    long long ws_y_stride, ws_list_stride, ws_surv_stride;   // elements per slot of ybuf, of jT (in 16-bit columns) / ent, of surv
     int capn;                // longest row the transposed lists hold (longer => dense fallback)
     uint16_t* jT;            // [G][capn][rows_pad]  the cull's transposed lists: column of entry n of local row li, columns ascending
     uint2* ent;              // same shape, by slot (rows sorted by list length): {colour factor ck as bits (NaN = failed the gate), column}

@@ -570,10 +570,11 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     const Shared* shc = reinterpret_cast<const Shared*>(cvo_smem);
     c.rows_per = shc->ctx_rows_per; c.nrows = shc->ctx_nrows;
     c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
-    c.ybuf = GF4{(gv4f*)D.ybuf + (size_t)g * D.nm_pad};
-    c.surv = (gv2u*)D.surv;
-    c.jT4 = (gv2u*)D.jT + (size_t)g * (D.capn / 4) * D.rows_pad;    // the cull's lists: four 16-bit columns per 8-byte word, word q of local row li at [q][li]
-    c.ent = (gv2u*)D.ent + (size_t)g * D.capn * D.rows_pad;
+    const size_t ws = (size_t)(blockIdx.x / (unsigned)G);           // the launch's pair slot this workgroup belongs to: owner of the work buffers
+    c.ybuf = GF4{(gv4f*)D.ybuf + ws * (size_t)D.ws_y_stride + (size_t)g * D.nm_pad};
+    c.surv = (gv2u*)D.surv + ws * (size_t)D.ws_surv_stride;
+    c.jT4 = (gv2u*)D.jT + (ws * (size_t)D.ws_list_stride) / 4 + (size_t)g * (D.capn / 4) * D.rows_pad;   // the cull's lists: four 16-bit columns per 8-byte word, word q of local row li at [q][li]
+    c.ent = (gv2u*)D.ent + ws * (size_t)D.ws_list_stride + (size_t)g * D.capn * D.rows_pad;
     c.xch = (gu64*)D.xch;
     c.fbase = (size_t)g * c.rows_per * D.capf;
     c.flat_cap = c.rows_per * D.capf;
