@@ -784,18 +784,29 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
 #pragma unroll
                     for (int r = 0; r < SWEEP_R; ++r) {
                         uint32_t ww = w[r];
-                        while (ww) {                                // bit 31 = first column of the group: ascending columns
-                            const int kbit = __clz(ww);
-                            if (cnt[r] < c.capn) {                  // four hits make one 8-byte store (a 2-byte store per hit was the cull's bottleneck)
-                                buf[r] |= (unsigned long long)(col0 + (uint32_t)kbit) << (16 * (cnt[r] & 3));
-                                if ((cnt[r] & 3) == 3) {
-                                    v2u w; w.x = (unsigned)buf[r]; w.y = (unsigned)(buf[r] >> 32);
-                                    c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]] = w;
-                                    buf[r] = 0ull;
+                        // bit 31 = first column of the group: ascending columns.  Up to four hits leave the word per trip (the loop runs
+                        // as long as the fullest row of the wave needs: a trip per hit was more than half of the cull) and go into the row's
+                        // 8-byte word of four columns; a full word is stored (a 2-byte store per hit was the cull's first bottleneck)
+                        while (ww) {
+                            const int n = min(__popc(ww), 4);
+                            const int k0 = __clz(ww);      const uint32_t w1 = ww & ~(0x80000000u >> k0);
+                            const int k1 = __clz(w1) & 31; const uint32_t w2 = w1 & ~(0x80000000u >> k1);
+                            const int k2 = __clz(w2) & 31; const uint32_t w3 = w2 & ~(0x80000000u >> k2);
+                            const int k3 = __clz(w3) & 31;
+                            ww = w3 & ~(0x80000000u >> k3);
+                            const uint32_t lo = (col0 + (uint32_t)k0) | (n > 1 ? (col0 + (uint32_t)k1) << 16 : 0u);
+                            const uint32_t hi = (n > 2 ? col0 + (uint32_t)k2 : 0u) | (n > 3 ? (col0 + (uint32_t)k3) << 16 : 0u);
+                            const unsigned long long four = ((unsigned long long)hi << 32) | lo;
+                            const int fill = cnt[r] & 3;
+                            if (cnt[r] < c.capn) {                  // capn is a multiple of 4: a word that starts below it ends at or below it
+                                buf[r] |= four << (16 * fill);
+                                if (fill + n >= 4) {
+                                    v2u wv; wv.x = (unsigned)buf[r]; wv.y = (unsigned)(buf[r] >> 32);
+                                    c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]] = wv;
+                                    buf[r] = fill ? (four >> (16 * (4 - fill))) : 0ull;
                                 }
                             }
-                            ++cnt[r];
-                            ww &= ~(0x80000000u >> kbit);
+                            cnt[r] += n;
                         }
                     }
                 }
