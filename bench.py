@@ -307,8 +307,21 @@ def main():
             if int(ok.item()) == 1:
                 idt = torch.frombuffer(bytearray(my_id), dtype=torch.uint8).to("cuda")
                 dist.broadcast(idt, 0)                                 # rank 0's id, everywhere
-                comm = ca.CvoComm(bytes(idt.cpu().numpy().tobytes()), world, rank, device=local_rank)   # ncclCommInitRank (collective)
-                gather_mode = "abi"
+                try:
+                    comm = ca.CvoComm(bytes(idt.cpu().numpy().tobytes()), world, rank, device=local_rank)   # ncclCommInitRank (collective)
+                except Exception as e:
+                    print(f"[bench] rank {rank}: cvo_comm_create failed ({e})", file=sys.stderr, flush=True)
+                    comm = None
+                ok2 = torch.tensor([1 if comm is not None else 0], device="cuda")
+                dist.all_reduce(ok2, op=dist.ReduceOp.MIN)             # every rank has its communicator, or nobody uses one
+                if int(ok2.item()) == 1:
+                    gather_mode = "abi"
+                else:
+                    if comm is not None:
+                        comm.close()
+                    comm = None
+                    if rank == 0:
+                        print("[bench] gathering with torch.distributed instead", file=sys.stderr, flush=True)
             elif rank == 0:
                 print("[bench] gathering with torch.distributed instead", file=sys.stderr, flush=True)
 
