@@ -30,6 +30,7 @@ size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab
 int align_min_tile(int rows_cap, int y_mode, int y_cap);
 int align_tile_granule();
 int align_blocks_per_cu();
+int align_block_max();
 hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         unsigned launch_tag, unsigned long long* queue, const DevParams& P);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
@@ -371,7 +372,8 @@ struct Engine {
             // lowest latency of this launch alone: as many workgroups per pair as the CUs allow, but not below ~384 rows per
             // workgroup -- a row's list is walked by one lane, so beyond one 64-row block per wave nothing gets shorter while the
             // partial-sum exchanges keep costing (measured at 3072 points: 2.37 ms at 4, 2.33 at 8, 2.44 at 16, 2.78 at 32, 4.9 at 1)
-            int want = 1; while (want * 2 * 384 <= nf_max && want < 32) want *= 2;
+            const int rows_min = 384 * (align_block_max() / 512);
+            int want = 1; while (want * 2 * rows_min <= nf_max && want < 32) want *= 2;
             G = 1; while (G * 2 * n_pairs <= num_cus * per_cu && G < want) G *= 2;
         }
         const int g_min = (((nf_max + 127) / 128) + (MAX_ROWS_PER_WG / 128) - 1) / (MAX_ROWS_PER_WG / 128);   // a workgroup owns at most MAX_ROWS_PER_WG rows, dealt in blocks of 128
@@ -440,9 +442,10 @@ struct Engine {
         int tab_cols = 0;
         if (!std::getenv("CVO_HIP_NO_TABLE") && y_mode != 0 && align_shared_bytes(tile, rows_cap, y_mode, nm_pad, nm_pad) <= (size_t)(160 / per_cu) * 1024 - 512) tab_cols = nm_pad;
         const int rows_per = rows_per_w;
-        int block = rows_per > 256 ? 512 : std::max(64, round_up(rows_per, 64));
+        const int bmax = align_block_max();
+        int block = rows_per > bmax / 2 ? bmax : std::max(64, round_up(rows_per, 64));
         if (per_cu > 1) block = std::min(block, 256);
-        if (block_request > 0) block = std::max(64, std::min(512, round_up(block_request, 64)));
+        if (block_request > 0) block = std::max(64, std::min(bmax, round_up(block_request, 64)));
 
         int rc;
         if ((rc = d_descs.ensure(sizeof(PairDesc) * n))) return rc;

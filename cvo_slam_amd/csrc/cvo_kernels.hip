@@ -47,7 +47,11 @@ namespace cvohip {
 #ifndef CVO_WAVES_PER_SIMD
 #define CVO_WAVES_PER_SIMD 2      // 2: 256 VGPRs, one 512-thread workgroup per CU (measured faster); 4: 128 VGPRs, two per CU
 #endif
-constexpr int MAX_WAVES = 8;        // workgroups are at most 512 threads: 256 VGPRs per lane, no spills in the survivor phases
+#ifndef CVO_BLOCK_MAX
+#define CVO_BLOCK_MAX 512         // threads of the largest workgroup: 512 = 2 waves per SIMD with 256 VGPRs each.  (1024 = 4 waves per SIMD with 128 each
+#endif                            //  is an experiment knob: measured, no phase gets faster -- DESIGN.md "Measured in round 2")
+constexpr int BLOCK_MAX = CVO_BLOCK_MAX;
+constexpr int MAX_WAVES = BLOCK_MAX / 64;
 constexpr float FAR_ROW = 3.0e18f;    // coordinates of padding rows / columns: d2 overflows, never < threshold
 constexpr float FAR_COL = -3.0e18f;
 
@@ -68,6 +72,7 @@ struct __attribute__((aligned(16))) Shared {
     int wtot[MAX_WAVES];   // candidates each wave owns (sum of its rows' list lengths)
     int wbase[MAX_WAVES];  // start of the wave's survivor segment (exclusive prefix of wtot)
     int wnb[MAX_WAVES];    // 64-slot blocks each wave walks in the candidate phase (serpentine deal, see phase_sort)
+    unsigned short blk_lmax[MAX_ROWS_PER_WG / 64 + 2];   // longest list of each block (kept by phase_sort / refine_lists: the walks need it before their first step)
     int lmax;              // longest candidate list of this workgroup's rows
     int list_valid;
     int dense_mode;        // candidates did not fit the lists: per-row dense fallback until the next rebuild
@@ -121,10 +126,11 @@ __device__ __forceinline__ float4 ld4(const gfloat* p) { const v4f t = *reinterp
 // ---------------------------------------------------------------- reductions
 // butterfly inside the wave (every lane ends with the wave total), one LDS slot
 // per wave, then lanes 0..K-1 of wave 0 add the waves in order: deterministic.
-template <int K>
+// KB < K: values KB..K-1 are per-wave numbers carried by lane 0 alone (counts): no butterfly for them.
+template <int K, int KB = K>
 __device__ __forceinline__ void block_reduce(double (&v)[K], Shared* sh, int tid, int nwaves) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < KB; ++k) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
     }
@@ -500,6 +506,7 @@ __device__ __forceinline__ float wave_max(float v) {
 extern __shared__ __attribute__((aligned(16))) unsigned char cvo_smem[];
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -604,7 +611,7 @@ __device__ __forceinline__ float4 load_y_rt(const Ctx& c, const Lds& L, int y_mo
 // ---- T: transform_pcd (cvo.cpp:336-341) into LDS (or ybuf); how far has any point moved since the candidate lists were
 // built (exact displacement of the very positions the tests use); rebuild decision.  The first PRE_T points of a thread may
 // arrive pre-loaded (the epilogue of the previous iteration fetches them while one lane does the scalar work).
-constexpr int PRE_T = 8;
+constexpr int PRE_T = 4096 / BLOCK_MAX;
 template <int YM>
 __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Shared* sh, const float4 (&pre)[PRE_T], bool have_pre) {
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
@@ -899,6 +906,7 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
         int lmaxb = len, ltot = len;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lmaxb = max(lmaxb, __shfl_xor(lmaxb, off, 64)); ltot += __shfl_xor(ltot, off, 64); }
+        if (lane == 0) sh->blk_lmax[b] = (unsigned short)lmaxb;
         my_lmax = max(my_lmax, lmaxb); my_tot += ltot; ++my_nb;
     }
     if (lane == 0) { sh->wsum[wave] = my_lmax; sh->wtot[wave] = my_tot; sh->wnb[wave] = my_nb; }
@@ -984,11 +992,10 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         for (int u = 0; u < PF; ++u) ehead[u] = eb0[(unsigned)lane + (unsigned)u * rp];
     }
     for (int bi = 0; bi < nb; ++bi) {
-        const int slot = wave_block(bi, wave, nwaves) * 64 + lane;
+        const int blk = wave_block(bi, wave, nwaves);
+        const int slot = blk * 64 + lane;
         const int len = L.lenS[slot];
-        int lw = len;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
+        const int lw = uni((int)sh->blk_lmax[blk]);                  // longest list of the block (phase_sort / refine_lists)
         float xi[3]; load_x(c, L, x_lds, slot, xi);
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
         const gv2u* eb = uni_ptr(c.ent + (slot - lane));             // scalar base of the block's entries + 32-bit lane offsets
@@ -1046,12 +1053,11 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
     int wcount = 0;
     const int nb = sh->wnb[wave];
     for (int bi = 0; bi < nb; ++bi) {
-        const int slot = wave_block(bi, wave, nwaves) * 64 + lane;
+        const int blk = wave_block(bi, wave, nwaves);
+        const int slot = blk * 64 + lane;
         const int len = L.lenS[slot];
         const int li = L.row_of[slot];
-        int lw = len;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
+        const int lw = uni((int)sh->blk_lmax[blk]);
         const int gi = global_row(c, li);
         const float4 lo = ld4(c.fixed + lo_off(gi)), hi = ld4(c.fixed + hi_off(c.nf, gi));
         const float xi[3] = {lo.x, lo.y, lo.z};
@@ -1130,11 +1136,10 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
     int kept = 0;
     const int nb = sh->wnb[wave];
     for (int bi = 0; bi < nb; ++bi) {
-        const int slot = wave_block(bi, wave, nwaves) * 64 + lane;
+        const int blk = wave_block(bi, wave, nwaves);
+        const int slot = blk * 64 + lane;
         const int len = L.lenS[slot];
-        int lw = len;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
+        const int lw = uni((int)sh->blk_lmax[blk]);
         float xi[3]; load_x(c, L, sh->x_lds != 0, slot, xi);
         gv2u* wp = c.ent + slot;                                    // where the next kept entry goes: never ahead of the reads
         const gv2u* ep = wp;
@@ -1162,6 +1167,10 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
         }
         L.lenS[slot] = (uint16_t)cnt;
         kept += cnt;
+        int cmax = cnt;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off, 64));
+        if (lane == 0) sh->blk_lmax[blk] = (unsigned short)cmax;   // read again by this wave only (same block, later phases)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
@@ -1236,7 +1245,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
     }
     const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
-    block_reduce<8>(acc8, sh, tid, nwaves);
+    if (dense_mode) block_reduce<8>(acc8, sh, tid, nwaves); else block_reduce<8, 6>(acc8, sh, tid, nwaves);   // list mode: nnz and candidates are per-wave counts in lane 0
     const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
     if (G > 1) {
         if (tid < 64) { if (!group_exchange<8>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 1u), lane)) sh->status = 6; }
@@ -1260,7 +1269,12 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
     float omega[3], v[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) { omega[q] = sh->omega[q]; v[q] = sh->v[q]; }
-    const LsConsts ls = make_ls(omega, v, sh->ell);
+    LsConsts ls = make_ls(omega, v, sh->ell);
+    {   // the same in every lane: keep the ~50 constants in scalar registers, not in each lane's vector registers
+        float* f = reinterpret_cast<float*>(&ls);
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(LsConsts) / sizeof(float)); ++q) f[q] = uni_f(f[q]);
+    }
     double acc4[4] = {0, 0, 0, 0};
 #ifdef CVO_KTRACE
     const unsigned long long kt0 = __builtin_amdgcn_s_memrealtime();
@@ -1425,7 +1439,7 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 #endif
 }
 
-__global__ __launch_bounds__(512, CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
+__global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
                                                                          unsigned launch_tag, int tab_cols, unsigned long long* __restrict__ queue_in, DevParams P) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
@@ -1584,7 +1598,7 @@ hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream
 // in the denominator (:271).  Then compute_step_size (:275-365, the base sequence), the stop tests (:509, :531), the pose update and
 // ell += dl_step*dl inside [ell_min, ell_max], ell_max shrinking by 0.7 when hit (:538-545).
 __global__ __launch_bounds__(512) void cvo_adaptive_kernel(AdaptiveArgs A) {
-    __shared__ double red[MAX_WAVES * 16];
+    __shared__ double red[8 * 16];
     __shared__ double tot[16];
     __shared__ float sM[12], s_omega[3], s_v[3], s_ell, s_ellmax, sR[9], sT[3], s_step;
     __shared__ int s_stop, s_iter;
@@ -1742,7 +1756,8 @@ hipError_t launch_adaptive(const AdaptiveArgs& A, hipStream_t stream) {
     return hipGetLastError();
 }
 
-int align_blocks_per_cu() { return CVO_WAVES_PER_SIMD / 2; }
+int align_blocks_per_cu() { return BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD / 2; }
+int align_block_max() { return BLOCK_MAX; }
 
 // LDS: Shared | slot/row tables (3 x rows_cap u16) | sort histograms | group boxes | cull tile (3*tile floats) | resident y cloud
 // (y_mode 1: 16 B x y_cap, y_mode 2: 12 B x y_cap, y_mode 0: none)
