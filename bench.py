@@ -228,11 +228,11 @@ def main():
     ap.add_argument("--gen-workers", type=int, default=0, help="host processes rendering the synthetic pairs (0 = one per host thread, 1 = no fork)")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
     args = ap.parse_args()
-    if args.shape == "eth3d":      # BASELINE config 5 defaults: 4 workgroups per pair, 4 launches side by side, a quarter of the device each
+    if args.shape == "eth3d":      # BASELINE config 5 defaults: 4 workgroups per pair, 6 launches side by side, 40 workgroups (10 pair slots) each
         dflt = ap.parse_args([])
         if args.workgroups == dflt.workgroups: args.workgroups = 4
-        if args.streams == dflt.streams: args.streams = 4
-        if args.max_workgroups == dflt.max_workgroups: args.max_workgroups = 64
+        if args.streams == dflt.streams: args.streams = 6
+        if args.max_workgroups == dflt.max_workgroups: args.max_workgroups = 40
         if args.steps == dflt.steps: args.steps = 24
         if args.warmup == dflt.warmup: args.warmup = 4
 
@@ -476,7 +476,7 @@ def main():
         # Counter figures come from separate rocprofv3 --pmc passes over this kernel (scripts/pmc_run.sh -> profiles/pmc_traffic.json,
         # taken at the commit named inside it): HBM bytes and VALU wave-instructions ONE launch of this workload executes.  Both are
         # properties of the work, not of the timing; the rates below divide them by times measured live in this run.
-        traffic = valu_instr = pmc_src = None
+        traffic = valu_instr = pmc_src = None; pmc = {}
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f).get(args.shape, {})
@@ -495,11 +495,21 @@ def main():
                         prof_ms = float(row["AverageNs"]) * 1e-6
         except Exception:
             prof_file = None
-        # The kernel is bound by VALU issue, not by HBM: the roofline object prices the issue slots.
-        # One wave64 VALU instruction occupies its SIMD for 4 cycles (plain f32, f64 FMA alike on gfx950), so the chip issues at most
-        # 256 CUs x 4 SIMDs x 2.4 GHz / 4 wave-instructions per second.
+        # The kernel is bound by VALU issue, not by HBM: the roofline object prices the vector pipe.
+        # MI355X_MICROARCH.md: a SIMD issues a wave64 f32 instruction in 2 cycles (one wave alone: one per 4) and f64 at half that rate
+        # (157.3 / 78.6 TFLOP/s vector peaks); scripts/micro/valu_rate.hip measures the same on this chip (profiles/r02_valu_issue_microbench.txt:
+        # 2.35 cycles for the f32/int32 class, 4.4 for f64 arithmetic, f64 conversions and 64-bit integer ops, 8.4 for transcendentals, two
+        # or more waves per SIMD).  The peak is therefore priced for THIS kernel's instruction mix, taken from the SQ_INSTS_VALU_* class
+        # counters of the same PMC passes: peak = 256 CUs x 4 SIMDs x 2.4 GHz / (mean issue cycles per instruction at the guide's rates).
+        # (Rounds 1-2 divided by 4 cycles per instruction -- what ONE wave per SIMD can issue, not the SIMD: that overstated the fraction
+        # by the factor kept below as `frac_of_one_wave_issue_rate`.)
         step_s = step_ms_rank * 1e-3
-        valu_peak = 256 * 4 * 2.4e9 / 4.0
+        simd_hz = 256 * 4 * 2.4e9
+        share4 = float(pmc.get("valu_half_rate_share", 0.0)) if pmc_src else 0.0        # f64 add/mul/fma + conversions + 64-bit integer: 4 cycles
+        share8 = float(pmc.get("valu_transcendental_share", 0.0)) if pmc_src else 0.0   # 8 cycles
+        cyc_nominal = 2.0 * (1.0 - share4 - share8) + 4.0 * share4 + 8.0 * share8
+        cyc_measured = 2.35 * (1.0 - share4 - share8) + 4.4 * share4 + 8.4 * share8
+        valu_peak = simd_hz / cyc_nominal
         valu_rate = (valu_instr / step_s) if valu_instr else None
         pair_tests = float(info.get("candidates_total", 0))          # list candidates the last launch evaluated (every launch of the region does the same work)
         out = {
@@ -518,11 +528,18 @@ def main():
                          "frac": (valu_rate / valu_peak) if valu_rate else None,
                          "traffic": traffic, "kernel": "cvo_align_kernel", "kernel_ms": k_ms,
                          "valu_wave_instructions_per_launch": valu_instr, "counters": pmc_src,
+                         "issue_cycles_per_instruction": {"guide_rates": cyc_nominal, "measured_rates": cyc_measured, "half_rate_share": share4, "transcendental_share": share8},
+                         "frac_of_measured_issue_rate": (valu_rate / (simd_hz / cyc_measured)) if valu_rate else None,
+                         "frac_of_one_wave_issue_rate": (valu_rate / (simd_hz / 4.0)) if valu_rate else None,
                          "launches_side_by_side": overlap, "profile": prof_file, "profile_kernel_ms": prof_ms,
                          "note": "achieved = VALU wave-instructions one launch executes (SQ_INSTS_VALU, rocprofv3 --pmc at the commit named in `counters`) / "
-                                 "time per step measured live (one launch retires per step); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 "
-                                 "instruction.  kernel_ms = mean HIP-event duration of a launch on its own stream with launches_side_by_side of them "
-                                 "sharing the CUs (so it contains queueing; the rocprofv3 --kernel-trace average of the same command is `profile_kernel_ms`)"},
+                                 "time per step measured live (one launch retires per step); peak = 256 CUs x 4 SIMDs x 2.4 GHz / issue cycles per instruction "
+                                 "of this kernel's mix at the guide's rates (f32/int32 class 2 cycles, f64 + conversions + int64 4, transcendental 8; the shares "
+                                 "are SQ_INSTS_VALU_* counters of the same passes).  frac_of_measured_issue_rate uses the rates scripts/micro/valu_rate.hip "
+                                 "measures on this chip instead (profiles/r02_valu_issue_microbench.txt); frac_of_one_wave_issue_rate is the round-1/2 "
+                                 "definition (4 cycles per instruction: what one wave per SIMD can issue), kept for comparison only.  kernel_ms = mean HIP-event "
+                                 "duration of a launch on its own stream with launches_side_by_side of them sharing the CUs (so it contains queueing; the "
+                                 "rocprofv3 --kernel-trace average of the same command is `profile_kernel_ms`)"},
             "hbm": {"bound": "hbm", "achieved": bytes_launch / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / step_s / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": bytes_launch, "traffic": traffic, "traffic_rate_GBs": (traffic / step_s / 1e9) if traffic else None,
                     "per_launch_achieved_GBs": achieved_gbs,

@@ -30,5 +30,12 @@ if alg:
 if "SQ_WAVE_CYCLES" in res:
     w = res["SQ_WAVE_CYCLES"]
     summary["sq_ratios"] = {k: res[k] / w for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES") if k in res}
+if "SQ_INSTS_VALU" in res and "SQ_INSTS_VALU_FMA_F64" in res and "SQ_INSTS_VALU_CVT" in res:
+    # instruction classes by issue cost (MI355X_MICROARCH.md rates, scripts/micro/valu_rate.hip): f64 arithmetic, conversions and 64-bit
+    # integer ops issue at half the f32 rate, transcendentals at a quarter.  (All conversions are counted in the half-rate class; the
+    # kernel's are f32 <-> f64 with few exceptions.)
+    half = sum(res.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT64"))
+    trans = sum(res.get(k, 0.0) for k in ("SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_TRANS_F64"))
+    summary["valu_classes"] = {"half_rate_share": half / res["SQ_INSTS_VALU"], "transcendental_share": trans / res["SQ_INSTS_VALU"]}
 json.dump(summary, open(out, "w"), indent=1)
 print(json.dumps(summary, indent=1))
