@@ -84,6 +84,7 @@ struct __attribute__((aligned(16))) Shared {
     int cand;
     int rebuilds;
     int refines;           // list rebuilds done by filtering the old lists (ell drops)
+    int resort;            // this refinement re-sorts the rows by their new list lengths (phase_refine)
     int dense_fallbacks;
     int rebuild;           // this iteration rebuilds the candidate lists
     int rows_cap;          // entries of the three row/slot tables in LDS (the workgroup's rows, padded)
@@ -841,12 +842,9 @@ __device__ __forceinline__ int len_class(int len) { return min(NCLS - 1, (len + 
 // i-th block of a wave in the serpentine deal
 __device__ __forceinline__ int wave_block(int i, int wave, int nwaves) { return i * nwaves + ((i & 1) ? nwaves - 1 - wave : wave); }
 
-static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
-    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
-    const Ctx c = make_ctx(Dp, g, G);
-    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
-    const int nrows = c.nrows;
+// rows -> slots: from L.rowlen[local row] to L.lenS[slot], L.row_of[slot].  Every thread; ends with a barrier.
+__device__ __forceinline__ void sort_slots(const Lds& L, int nrows, int tid, int nthreads) {
+    const int lane = tid & 63, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nblk = (nrows + 63) >> 6;
     int* hist = L.hist; int* base = L.base;
     for (int i = tid; i < MAX_WAVES * NCLS; i += nthreads) hist[i] = 0;
@@ -897,6 +895,13 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+}
+
+// what follows a new slot order: the waves' blocks and totals, the segments of the nonzero records, the fixed points by slot.
+// Every thread; ends with a barrier.
+__device__ __forceinline__ void finish_slots(const Ctx& c, const Lds& L, Shared* sh, int tile, int tid, int nthreads, bool fresh_lists) {
+    const int lane = tid & 63, nwaves = nthreads >> 6, wave = tid >> 6;
+    const int nblk = (c.nrows + 63) >> 6;
     // every wave sums up the blocks the serpentine deal gives it
     int my_lmax = 0, my_tot = 0, my_nb = 0;
     for (int i = 0;; ++i) {
@@ -907,18 +912,22 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lmaxb = max(lmaxb, __shfl_xor(lmaxb, off, 64)); ltot += __shfl_xor(ltot, off, 64); }
         if (lane == 0) sh->blk_lmax[b] = (unsigned short)lmaxb;
-        my_lmax = max(my_lmax, lmaxb); my_tot += ltot; ++my_nb;
+        my_lmax = max(my_lmax, lmaxb); my_tot += ltot;
+        if (lmaxb > 0) ++my_nb;                                      // slots are in descending length order: an empty block ends the wave's walk (at ell = 0.03 a sixth to a third of the rows have no neighbour left)
     }
     if (lane == 0) { sh->wsum[wave] = my_lmax; sh->wtot[wave] = my_tot; sh->wnb[wave] = my_nb; }
     __syncthreads();
     if (tid == 0) {
         int lmax_all = 0, run_w = 0;
         for (int w = 0; w < nwaves; ++w) { lmax_all = max(lmax_all, sh->wsum[w]); sh->wbase[w] = run_w; run_w += sh->wtot[w]; }
-        // candidates beyond what the survivor planes hold, or a row longer than the lists: dense per-row fallback until the
-        // next rebuild
-        const int dense = ((run_w > c.flat_cap) || (lmax_all > c.capn)) ? 1 : 0;
-        sh->dense_mode = dense; sh->total = run_w; sh->lmax = lmax_all;
-        sh->dense_fallbacks += dense;
+        sh->total = run_w; sh->lmax = lmax_all;
+        if (fresh_lists) {
+            // candidates beyond what the survivor planes hold, or a row longer than the lists: dense per-row fallback until the
+            // next rebuild
+            const int dense = ((run_w > c.flat_cap) || (lmax_all > c.capn)) ? 1 : 0;
+            sh->dense_mode = dense;
+            sh->dense_fallbacks += dense;
+        }
     }
     // the cull tile is idle until the next cull: it keeps the fixed points in slot order for the candidate and line-search phases
     const int xl = (nblk * 64 <= tile) ? 1 : 0;
@@ -930,6 +939,14 @@ static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, 
     }
     if (tid == 0) sh->x_lds = xl;
     __syncthreads();
+}
+
+static __device__ __noinline__ void phase_sort(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
+    sort_slots(L, c.nrows, threadIdx.x, blockDim.x);
+    finish_slots(c, L, sh, tile, threadIdx.x, blockDim.x, true);
 }
 
 // ---- C: exact kernel values + compute_flow row sums (cvo.cpp:202-231), reduced over the workgroup and the pair's workgroups.
@@ -1133,7 +1150,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
 // current positions), so the result is the list a dense cull would build now, with the colour factors it already carries.
 template <int YM>
 __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* sh, float nthr, int lane, int wave, int nwaves) {
-    int kept = 0;
+    int kept = 0, nb_left = 0;
     const int nb = sh->wnb[wave];
     for (int bi = 0; bi < nb; ++bi) {
         const int blk = wave_block(bi, wave, nwaves);
@@ -1171,17 +1188,23 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off, 64));
         if (lane == 0) sh->blk_lmax[blk] = (unsigned short)cmax;   // read again by this wave only (same block, later phases)
+        if (cmax > 0) nb_left = bi + 1;
     }
+    if (lane == 0) sh->wnb[wave] = nb_left;                          // blocks the filter emptied at the end of the wave's list are not walked again
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
     return kept;
 }
 
-static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
+#ifndef CVO_RESORT
+#define CVO_RESORT 1
+#endif
+static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
+    const int nblk = (c.nrows + 63) >> 6;
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
     const float Rb = r_c * (1.0f + sh->P.skin);
     const float nthr = -(Rb * Rb * 1.00001f);                       // = the cull's threshold for this ell
@@ -1189,12 +1212,58 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
     if (lane == 0) sh->wsum[wave] = kept;
     __syncthreads();
     if (tid == 0) {
-        int tot = 0;
+        int tot = 0, lmax_new = 0;
+        long long walked = 0;                                        // list slots a walk evaluates in the present order: 64 rows x the longest list of each block, in steps of PF
         for (int w = 0; w < nwaves; ++w) tot += sh->wsum[w];
-        sh->total = tot; sh->Rb = Rb; sh->ell_build = sh->ell; sh->refines += 1;
+        for (int bq = 0; bq < nblk; ++bq) { const int lm = (int)sh->blk_lmax[bq]; lmax_new = max(lmax_new, lm); walked += 64 * PF * ((lm + PF - 1) / PF); }
+        sh->total = tot; sh->lmax = lmax_new; sh->Rb = Rb; sh->ell_build = sh->ell; sh->refines += 1;
         for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i];          // displacements count from here again
+        // Re-sort (below) when it pays: it costs about 25 us + 1.7 ns per list entry (measured: 31 us at 13 k entries, 68 at 48 k, 240 at
+        // 126 k -- the lists change columns, 64 cache lines per wave load) and saves 0.28 ns per list slot no longer walked, in every
+        // iteration until the next rebuild: those left at this ell by the schedule of cvo.cpp:810-812, 24 assumed at the last one.
+        // The staging area is the (idle) record buffer: it has to hold the new lists in list layout.
+        const int left = k < 3 ? 3 - k : (k < 10 ? 10 - k : (k < 20 ? 20 - k : 24));
+        const float gain_ns = 0.28f * (float)left * ((float)walked - 1.3f * (float)tot), cost_ns = 25000.f + 1.7f * (float)tot;
+        sh->resort = (CVO_RESORT && lmax_new > 0 && (long long)lmax_new * c.rows_pad <= (long long)c.flat_cap && (CVO_RESORT == 2 || gain_ns > cost_ns)) ? 1 : 0;
     }
     __syncthreads();
+    if (!sh->resort) return;
+    // The filter keeps a third to a half of every list, unevenly: rows that were neighbours in the old length order now differ by a factor
+    // of two and more, and a wave walks its 64 rows for as long as the longest of them lasts (at ell = 0.03 the walk would evaluate 2.8 list
+    // slots per listed candidate).  So the rows are sorted again by their new lengths and the lists move to their new slots -- through the
+    // record buffer, which is idle between the line search of one iteration and the candidate phase of the next.
+    typedef CVO_GLOBAL uint16_t gu16;
+    gu16* slot_of = reinterpret_cast<gu16*>(c.jT4);                 // old slot of every local row (the cull's raw lists are dead by now)
+    for (int sl = tid; sl < c.nrows; sl += nthreads) {
+        const int li = L.row_of[sl];
+        L.rowlen[li] = L.lenS[sl]; slot_of[li] = (uint16_t)sl;
+    }
+    __syncthreads();
+    sort_slots(L, c.nrows, tid, nthreads);
+    gv2u* stage = c.surv + c.fbase;
+    const size_t rp = (size_t)c.rows_pad;
+    for (int pass = 0; pass < 2; ++pass) {                          // 0: old slot -> staging area at the new slot; 1: back into the lists
+        for (int bq = wave; bq < nblk; bq += nwaves) {
+            const int sn = bq * 64 + lane;
+            const int len = L.lenS[sn];
+            int lw = len;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
+            const int so = (pass == 0 && len > 0) ? (int)slot_of[L.row_of[sn]] : sn;
+            const gv2u* src = (pass == 0 ? c.ent : stage) + so;
+            gv2u* dst = (pass == 0 ? stage : c.ent) + sn;
+            constexpr int MV = 8;
+            for (int n0 = 0; n0 < lw; n0 += MV) {
+                v2u e[MV];
+#pragma unroll
+                for (int u = 0; u < MV; ++u) if (n0 + u < len) e[u] = src[(size_t)(n0 + u) * rp];
+#pragma unroll
+                for (int u = 0; u < MV; ++u) if (n0 + u < len) dst[(size_t)(n0 + u) * rp] = e[u];
+            }
+        }
+        __syncthreads();
+    }
+    finish_slots(c, L, sh, tile, tid, nthreads, false);
 }
 
 static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
@@ -1521,7 +1590,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                 phase_sort(Dp, g, G, tgeo, y_lds);
                 ticks[6] += t_b - t_a; ticks[8] += __builtin_amdgcn_s_memrealtime() - t_b;
             } else if (sh->rebuild == 2) {
-                phase_refine(Dp, g, G, tgeo, y_lds);
+                phase_refine(Dp, g, G, tgeo, y_lds, k);
             }
             CVO_PHASE(0);
             phase_candidates(Dp, g, G, tgeo, y_lds, k);

@@ -7,9 +7,11 @@ import bench
 import cvo_slam_amd as ca
 idx = int(os.environ.get("PAIR", "0"))
 (_, fx, ff, mx, mf), = bench.generate_pairs(idx, 1)
-h = ca.Cvo()
+prm = ca.default_params()
+if os.environ.get("MAX_ITER"): prm.max_iter = int(os.environ["MAX_ITER"])      # experiment builds whose results are garbage must still end
+h = ca.Cvo(prm)
 for rep in range(2):
-    h = ca.Cvo()
+    h = ca.Cvo(prm)
     h.set_pcd(fx, ff); h.set_pcd(mx, mf)
     out = h.align(trace_cap=128)
 rows = out
