@@ -127,14 +127,39 @@ __device__ __forceinline__ float4 ld4(const gfloat* p) { const v4f t = *reinterp
 // ---------------------------------------------------------------- reductions
 // butterfly inside the wave (every lane ends with the wave total), one LDS slot
 // per wave, then lanes 0..K-1 of wave 0 add the waves in order: deterministic.
+// v of lane (i ^ X) for X = 8, 4, 2, 1 by DPP moves inside the row of 16 lanes (vector pipe, no LDS round trip):
+// 8 = row_ror:8, 2 = quad_perm [2,3,0,1], 1 = quad_perm [1,0,3,2]; 4 = row_shl:4 into the lanes whose bit 2 is clear (banks 0, 2)
+// and row_shr:4 into the others (banks 1, 3).
+template <int X>
+__device__ __forceinline__ int dpp_xor_i32(int x) {
+    if (X == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);
+    if (X == 4) { const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0x5, false); return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false); }
+    if (X == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);
+}
+template <int X>
+__device__ __forceinline__ double dpp_xor(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)dpp_xor_i32<X>((int)(unsigned)b), hi = (unsigned)dpp_xor_i32<X>((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int X>
+__device__ __forceinline__ float dpp_xor(float v) { return __uint_as_float((unsigned)dpp_xor_i32<X>((int)__float_as_uint(v))); }
+// all-lanes sum of a wave: the xor-butterfly over 32, 16, 8, 4, 2, 1, the last four exchanges without the LDS (same partners, same bits)
+__device__ __forceinline__ double wave_sum_all(double v) {
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += dpp_xor<8>(v);
+    v += dpp_xor<4>(v);
+    v += dpp_xor<2>(v);
+    v += dpp_xor<1>(v);
+    return v;
+}
 // KB < K: values KB..K-1 are per-wave numbers carried by lane 0 alone (counts): no butterfly for them.
 template <int K, int KB = K>
 __device__ __forceinline__ void block_reduce(double (&v)[K], Shared* sh, int tid, int nwaves) {
 #pragma unroll
-    for (int k = 0; k < KB; ++k) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-    }
+    for (int k = 0; k < KB; ++k) v[k] = wave_sum_all(v[k]);
     const int lane = tid & 63, wave = tid >> 6;
     if (lane == 0) {
 #pragma unroll
@@ -150,8 +175,8 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], Shared* sh, int tid
 }
 
 __device__ __forceinline__ float block_max(float v, Shared* sh, int tid, int nwaves) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, dpp_xor<8>(v)); v = fmaxf(v, dpp_xor<4>(v)); v = fmaxf(v, dpp_xor<2>(v)); v = fmaxf(v, dpp_xor<1>(v));
     if ((tid & 63) == 0) sh->fred[tid >> 6] = v;
     __syncthreads();
     float m = sh->fred[0];
@@ -489,13 +514,13 @@ __device__ __forceinline__ void sweep_group(const float* lx, const float* ly, co
 }
 
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    v = fminf(v, __shfl_xor(v, 32, 64)); v = fminf(v, __shfl_xor(v, 16, 64));
+    v = fminf(v, dpp_xor<8>(v)); v = fminf(v, dpp_xor<4>(v)); v = fminf(v, dpp_xor<2>(v)); v = fminf(v, dpp_xor<1>(v));
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, dpp_xor<8>(v)); v = fmaxf(v, dpp_xor<4>(v)); v = fmaxf(v, dpp_xor<2>(v)); v = fmaxf(v, dpp_xor<1>(v));
     return v;
 }
 
@@ -726,9 +751,12 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             if (!planes) { L.lx[jj] = y.x; L.ly[jj] = y.y; L.lz[jj] = y.z; }
             else if (jj >= tn) { L.ysx[jj] = FAR_COL; L.ysy[jj] = FAR_COL; L.ysz[jj] = FAR_COL; }   // padding columns of the last group (the planes have room: y_cap is a multiple of 64)
 #pragma unroll
-            for (int off = 16; off > 0; off >>= 1) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], off, 64)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], off, 64)); }
+            for (int q = 0; q < 4; ++q) {                           // min / max over each half wave (a 32-column group): one LDS exchange, the rest in the vector pipe
+                lo[q] = fminf(lo[q], __shfl_xor(lo[q], 16, 64)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], 16, 64));
+                lo[q] = fminf(lo[q], dpp_xor<8>(lo[q])); hi[q] = fmaxf(hi[q], dpp_xor<8>(hi[q]));
+                lo[q] = fminf(lo[q], dpp_xor<4>(lo[q])); hi[q] = fmaxf(hi[q], dpp_xor<4>(hi[q]));
+                lo[q] = fminf(lo[q], dpp_xor<2>(lo[q])); hi[q] = fmaxf(hi[q], dpp_xor<2>(hi[q]));
+                lo[q] = fminf(lo[q], dpp_xor<1>(lo[q])); hi[q] = fmaxf(hi[q], dpp_xor<1>(hi[q]));
             }
             if ((lane & 31) == 0) {
                 const int gi = jj >> 5;
