@@ -156,8 +156,11 @@ __device__ __forceinline__ double wave_sum_all(double v) {
     return v;
 }
 // KB < K: values KB..K-1 are per-wave numbers carried by lane 0 alone (counts): no butterfly for them.
-template <int K, int KB = K>
-__device__ __forceinline__ void block_reduce(double (&v)[K], Shared* sh, int tid, int nwaves) {
+// The totals end up in sh->vals[0..K) AND in the return value of lanes 0..K-1 of wave 0.  SYNC_AFTER = false leaves out the closing
+// barrier: only wave 0 may then read sh->vals (its own lanes wrote them; LDS operations of one wave complete in order) until the
+// caller's next barrier.
+template <int K, int KB = K, bool SYNC_AFTER = true>
+__device__ __forceinline__ double block_reduce(double (&v)[K], Shared* sh, int tid, int nwaves) {
 #pragma unroll
     for (int k = 0; k < KB; ++k) v[k] = wave_sum_all(v[k]);
     const int lane = tid & 63, wave = tid >> 6;
@@ -166,12 +169,13 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], Shared* sh, int tid
         for (int k = 0; k < K; ++k) sh->red[wave * 8 + k] = v[k];
     }
     __syncthreads();
+    double s = 0;
     if (tid < K) {
-        double s = 0;
         for (int w = 0; w < nwaves; ++w) s += sh->red[w * 8 + tid];
         sh->vals[tid] = s;
     }
-    __syncthreads();
+    if (SYNC_AFTER) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    return s;
 }
 
 __device__ __forceinline__ float block_max(float v, Shared* sh, int tid, int nwaves) {
@@ -1341,16 +1345,23 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
         }
     }
     const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
-    __syncthreads();
-    if (dense_mode) block_reduce<8>(acc8, sh, tid, nwaves); else block_reduce<8, 6>(acc8, sh, tid, nwaves);   // list mode: nnz and candidates are per-wave counts in lane 0
+    // (no barrier before the reduction: its own barrier is the one every wave reaches after its walk)
+    const double mine = dense_mode ? block_reduce<8, 8, false>(acc8, sh, tid, nwaves) : block_reduce<8, 6, false>(acc8, sh, tid, nwaves);   // list mode: nnz and candidates are per-wave counts in lane 0
     const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
     if (G > 1) {
-        if (tid < 64) { if (!group_exchange<8>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 1u), lane)) sh->status = 6; }
-        __syncthreads();
+        if (tid < 64) { if (!group_exchange<8>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 1u), lane)) sh->status = 6; }   // wave 0: reads the totals its own lanes wrote
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) {
+            for (int q = 0; q < 3; ++q) { sh->omega[q] = (float)sh->vals[q]; sh->v[q] = (float)sh->vals[3 + q]; }   // cvo.cpp:234-235
+            sh->nnz = (int)sh->vals[6]; sh->cand = (int)sh->vals[7];
+        }
+    } else {                                                        // one workgroup per pair: the summing lanes publish their totals themselves
+        if (tid < 3) sh->omega[tid] = (float)mine;                  // cvo.cpp:234-235
+        else if (tid < 6) sh->v[tid - 3] = (float)mine;
+        else if (tid == 6) sh->nnz = (int)mine;
+        else if (tid == 7) sh->cand = (int)mine;
     }
     if (tid == 0) {
-        for (int q = 0; q < 3; ++q) { sh->omega[q] = (float)sh->vals[q]; sh->v[q] = (float)sh->vals[3 + q]; }   // cvo.cpp:234-235
-        sh->nnz = (int)sh->vals[6]; sh->cand = (int)sh->vals[7];
         const unsigned long long ts4 = __builtin_amdgcn_s_memrealtime();
         sh->sub[0] += ts1 - ts0; sh->sub[1] += ts2 - ts1; sh->sub[2] += ts3 - ts2; sh->sub[3] += ts4 - ts3;
     }
@@ -1456,14 +1467,16 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
 #ifdef CVO_KTRACE
     const unsigned long long kt1 = __builtin_amdgcn_s_memrealtime();
 #endif
-    __syncthreads();
-    block_reduce<4>(acc4, sh, tid, nwaves);
+    // no barrier before the reduction (its own is the one every wave reaches after its walk: the epilogue's transform may overwrite the
+    // resident cloud only behind it) and none after it: the totals are read by thread 0 of wave 0 alone (exchange, epilogue), whose
+    // own lanes wrote them; the next workgroup barrier is the epilogue's
+    block_reduce<4, 4, false>(acc4, sh, tid, nwaves);
 #ifdef CVO_KTRACE
     if (tid == 0) { sh->ksub[0] = kt1 - kt0; sh->ksub[1] = __builtin_amdgcn_s_memrealtime() - kt1; }
 #endif
     if (G > 1) {
         if (tid < 64) { if (!group_exchange<4>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 2u), lane)) sh->status = 6; }
-        __syncthreads();
+        __syncthreads();                                             // sh->status is read by every thread right after the phase
     }
 }
 
