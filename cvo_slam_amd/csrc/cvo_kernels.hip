@@ -94,6 +94,8 @@ struct __attribute__((aligned(16))) Shared {
     int tab_cols;          // columns the line-search table has room for (0 = no table)
     unsigned launch_tag;   // high 16 bits of every exchange tag: this launch's sequence number (granules of earlier launches never match)
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
+    unsigned long long ticks[10];   // thread 0's time per phase (PairState::phase_ticks), summed over the pair's iterations
+    unsigned long long cand_total;  // list candidates evaluated so far (PairState::candidates_total)
 #ifdef CVO_KTRACE
     unsigned long long ksub[4];  // experiment builds: line-search walk, line-search reduction, epilogue scalar part, epilogue transform (ticks, this iteration)
 #endif
@@ -1606,19 +1608,21 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             int rp, nr; pair_rows(nf, g, G, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
             sh->stop = 0; sh->status = 0; sh->iter_at_break = st->iter; sh->nnz = 0; sh->cand = 0;
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
+            for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
+            sh->cand_total = 0;
             sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
 
         int k = 0;
-        long long cand_total = 0;
-        unsigned long long ticks[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // phase timers and counters live in LDS, bumped by thread 0 with fire-and-forget ds_add: as registers of this function they were
+        // saved and restored around every phase call (the phases are out of line), ~1 us of lane moves per iteration
         unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
 #ifdef CVO_KTRACE
         unsigned long long kt_prev[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ksub_prev[4] = {0, 0, 0, 0};
 #endif
         const unsigned long long clk_t0 = t_prev, clk_c0 = __builtin_amdgcn_s_memtime();
-#define CVO_PHASE(idx) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); ticks[idx] += t_now - t_prev; t_prev = t_now; } while (0)
+#define CVO_PHASE(idx) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); if (tid == 0) atomicAdd(&sh->ticks[idx], t_now - t_prev); t_prev = t_now; } while (0)
         const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
         if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
 
@@ -1629,13 +1633,13 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                 phase_cull(Dp, g, G, tgeo, y_lds);
                 const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
                 phase_sort(Dp, g, G, tgeo, y_lds);
-                ticks[6] += t_b - t_a; ticks[8] += __builtin_amdgcn_s_memrealtime() - t_b;
+                if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], __builtin_amdgcn_s_memrealtime() - t_b); }
             } else if (sh->rebuild == 2) {
                 phase_refine(Dp, g, G, tgeo, y_lds, k);
             }
             CVO_PHASE(0);
             phase_candidates(Dp, g, G, tgeo, y_lds, k);
-            cand_total += sh->cand;
+            if (tid == 0) atomicAdd(&sh->cand_total, (unsigned long long)sh->cand);
             CVO_PHASE(1);
             if (sh->status != 0) break;
             phase_linesearch(Dp, g, G, tgeo, y_lds, k);
@@ -1646,6 +1650,8 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
 #ifdef CVO_KTRACE   // experiment builds only: the trace row's B..E carry this iteration's phase times (100 MHz ticks) instead
             if (tid == 0 && g == 0 && Dp->trace && k < Dp->trace_cap) {
                 TraceRow& tr = Dp->trace[k];
+                unsigned long long ticks[10];
+                for (int q = 0; q < 10; ++q) ticks[q] = sh->ticks[q];
                 tr.B = (double)(ticks[0] - kt_prev[0]); tr.C = (double)(ticks[1] - kt_prev[1]); tr.D = (double)(ticks[3] - kt_prev[3]); tr.E = (double)(ticks[5] - kt_prev[5]);
                 // omega = candidate phase (prologue, row walk, wait + reduction), v = line-search walk, its reduction, epilogue scalar part; step = fused transform
                 tr.omega[0] = (float)(sh->sub[0] - ksub_prev[0]); tr.omega[1] = (float)(sh->sub[1] - ksub_prev[1]); tr.omega[2] = (float)(sh->sub[2] - ksub_prev[2]);
@@ -1673,9 +1679,9 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             fin.status = sh->status;
             fin.rebuilds = sh->rebuilds;
             fin.dense_fallbacks = sh->dense_fallbacks;
-            fin.candidates_total = cand_total;
-            ticks[7] = sh->sub[0]; ticks[9] = sh->sub[1]; ticks[2] = sh->sub[2]; ticks[4] = sh->sub[3];
-            for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = ticks[i];
+            fin.candidates_total = (long long)sh->cand_total;
+            for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
+            fin.phase_ticks[7] = sh->sub[0]; fin.phase_ticks[9] = sh->sub[1]; fin.phase_ticks[2] = sh->sub[2]; fin.phase_ticks[4] = sh->sub[3];
             fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0;
             *Dp->state = fin;                                          // device copy: the next launch may start from it, the result packer reads it
             *Dp->state_host = fin;                                     // pinned host mirror: visible to the host when the kernel has completed
