@@ -85,6 +85,7 @@ struct __attribute__((aligned(16))) Shared {
     int rebuilds;
     int refines;           // list rebuilds done by filtering the old lists (ell drops)
     int resort;            // this refinement re-sorts the rows by their new list lengths (phase_refine)
+    int cull_next;         // next block pair of the cull to hand out
     int dense_fallbacks;
     int rebuild;           // this iteration rebuilds the candidate lists
     int rows_cap;          // entries of the three row/slot tables in LDS (the workgroup's rows, padded)
@@ -770,9 +771,17 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                 for (int q = 0; q < 4; ++q) { L.gbox[q * gplane + gi] = lo[q]; L.gbox[(4 + q) * gplane + gi] = hi[q]; }
             }
         }
+        if (tid == 0) sh->cull_next = 0;
         __syncthreads();
         const int ngr = tnp >> 5;
-        for (int b2 = wave; b2 < nblk2; b2 += nwaves) {
+        // Block pairs are handed out as the waves come for them: a pair's cost follows the hits of its 128 rows (near surfaces have several
+        // times the neighbours of far ones) and a fixed deal of three pairs per wave left the workgroup waiting for the unluckiest wave.  A
+        // row's list is made by one lane in column order whichever wave runs it: the lists do not depend on the order.
+        for (;;) {
+            int b2 = 0;
+            if (lane == 0) b2 = atomicAdd(&sh->cull_next, 1);
+            b2 = uni(b2);
+            if (b2 >= nblk2) break;
             float x[SWEEP_R][3]; int li[SWEEP_R]; int cnt[SWEEP_R];
             unsigned long long buf[SWEEP_R];                        // the row's last, not yet full word of four columns
             float blo[4] = {INF, INF, INF, INF}, bhi[4] = {-INF, -INF, -INF, -INF};

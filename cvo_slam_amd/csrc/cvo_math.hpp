@@ -108,6 +108,9 @@ CVO_HD int cubic_real_roots(double a, double b, double c, double* roots) {
     double* rr[2] = {&r2, &r3};
     for (int k = 0; k < 2; ++k) {
         double t = *rr[k];
+        // The caller keeps the smallest root > 0 and clamps it to 0.8 (cvo.cpp:326-333): a root that is clearly negative or above 1 cannot
+        // change the step whatever its last digits are (the deflated value is good to ~1e-15 relative), so it is not polished.
+        if (t < -1e-6 || t > 1.0) continue;
         for (int it = 0; it < 2; ++it) {          // the deflated roots are already good to ~1e-15; two Newton steps on the full cubic
             const double f = ((t + a) * t + b) * t + c, df = (3.0 * t + 2.0 * a) * t + b;
             const double tn = t - f / df;

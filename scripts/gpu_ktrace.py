@@ -6,6 +6,7 @@ import numpy as np
 import bench
 import cvo_slam_amd as ca
 idx = int(os.environ.get("PAIR", "0"))
+bench._SHAPE = os.environ.get("SHAPE", "tum")              # eth3d: the BASELINE config 5 shape
 (_, fx, ff, mx, mf), = bench.generate_pairs(idx, 1)
 prm = ca.default_params()
 if os.environ.get("MAX_ITER"): prm.max_iter = int(os.environ["MAX_ITER"])      # experiment builds whose results are garbage must still end
