@@ -112,6 +112,7 @@ DevParams to_dev(const cvo_params& p) {
     d.sigma = p.sigma; d.sp_thres = p.sp_thres; d.c = p.c; d.d = p.d; d.c_ell = p.c_ell; d.c_sigma = p.c_sigma;
     d.min_step = p.min_step; d.eps = p.eps; d.eps_2 = p.eps_2; d.max_iter = p.max_iter;
     d.skin = 0.25f;
+    d.resort = 1;
     return d;
 }
 
@@ -205,6 +206,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_BLOCK")) block_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS_PER_CU")) per_cu = std::max(1, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_SKIN")) P.skin = (float)std::atof(e);
+        if (const char* e = std::getenv("CVO_HIP_RESORT")) P.resort = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
         return CVO_OK;

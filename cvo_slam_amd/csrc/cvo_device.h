@@ -19,6 +19,7 @@ struct DevParams {           // cvo.cpp:35-51
     float sigma, sp_thres, c, d, c_ell, c_sigma, min_step, eps, eps_2;
     int max_iter;
     float skin;              // candidate lists are built with radius (1+skin)*r and reused until the cloud has moved skin*r
+    int resort;              // rows re-sorted after a list refinement: 0 never, 1 when the cost model says it pays (default), 2 always (tests)
 };
 
 // per-pair state, read at kernel start and written back at the end (Q1, Q2)

@@ -1239,9 +1239,6 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
     return kept;
 }
 
-#ifndef CVO_RESORT
-#define CVO_RESORT 1
-#endif
 static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
@@ -1267,7 +1264,8 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
         // The staging area is the (idle) record buffer: it has to hold the new lists in list layout.
         const int left = k < 3 ? 3 - k : (k < 10 ? 10 - k : (k < 20 ? 20 - k : 24));
         const float gain_ns = 0.28f * (float)left * ((float)walked - 1.3f * (float)tot), cost_ns = 25000.f + 1.7f * (float)tot;
-        sh->resort = (CVO_RESORT && lmax_new > 0 && (long long)lmax_new * c.rows_pad <= (long long)c.flat_cap && (CVO_RESORT == 2 || gain_ns > cost_ns)) ? 1 : 0;
+        const int mode = sh->P.resort;                               // CVO_HIP_RESORT: 0 never, 1 by the cost model, 2 always
+        sh->resort = (mode && lmax_new > 0 && (long long)lmax_new * c.rows_pad <= (long long)c.flat_cap && (mode == 2 || gain_ns > cost_ns)) ? 1 : 0;
     }
     __syncthreads();
     if (!sh->resort) return;

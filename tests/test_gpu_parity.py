@@ -120,7 +120,8 @@ def test_workgroup_counts_tiles_and_overflow_fallback_agree(hiplib, oracle):
     non-power-of-two and more workgroups than 64-row blocks), LDS tile smaller than the
     cloud (multi-tile streaming), flat candidate capacities so small that the dense
     per-row fallback runs, and candidate-list skins from 0 (cull every iteration)
-    to 150 % (one cull per ell).  All must land on the oracle's pose and sparse-set sizes."""
+    to 150 % (one cull per ell), rows re-sorted at every list refinement / never.  All must land on the
+    oracle's pose and sparse-set sizes."""
     from cvo_slam_amd import synth
     p = synth.make_small_pair(55, n=900)
     fixed, moving = (p.fixed.xyz, p.fixed.feat), (p.moving.xyz, p.moving.feat)
@@ -133,7 +134,9 @@ def test_workgroup_counts_tiles_and_overflow_fallback_agree(hiplib, oracle):
                dict(wgs=1, CVO_HIP_NO_YLDS=1), dict(wgs=3, CVO_HIP_NO_YLDS=1, CVO_HIP_TILE=128),          # transformed cloud in HBM/L2, not LDS
                dict(wgs=1, CVO_HIP_Y_MODE=2), dict(wgs=4, CVO_HIP_Y_MODE=2, CVO_HIP_TILE=256), dict(wgs=2, CVO_HIP_Y_MODE=0),   # 12-byte LDS layout / forced HBM
                dict(wgs=1, CVO_HIP_ROW_CAP=8), dict(wgs=2, CVO_HIP_ROW_CAP=16, CVO_HIP_SKIN=0.6),         # rows longer than the lists hold
-               dict(wgs=1, CVO_HIP_WGS_PER_CU=2)]                                                          # two 256-thread workgroups per CU
+               dict(wgs=1, CVO_HIP_WGS_PER_CU=2),                                                          # two 256-thread workgroups per CU
+               dict(wgs=1, CVO_HIP_RESORT=2), dict(wgs=3, CVO_HIP_RESORT=2), dict(wgs=2, CVO_HIP_RESORT=2, CVO_HIP_Y_MODE=2),   # rows re-sorted at EVERY list refinement
+               dict(wgs=2, CVO_HIP_RESORT=2, CVO_HIP_NO_YLDS=1, CVO_HIP_TILE=128), dict(wgs=1, CVO_HIP_RESORT=0)]
     for cfg in configs:
         envs = {k: v for k, v in cfg.items() if k.startswith("CVO_")}
         with env(**envs):
