@@ -24,6 +24,7 @@ for case in range(N):
     if rng.random() < 0.3: env["CVO_HIP_SKIN"] = str(float(rng.choice([0.0, 0.1, 0.5, 1.0])))
     if rng.random() < 0.2: env["CVO_HIP_ROW_CAP"] = str(int(rng.choice([8, 16, 64])))
     if rng.random() < 0.2: env["CVO_HIP_FLAT_CAP"] = str(int(rng.choice([1, 4, 32])))
+    if rng.random() < 0.5: env["CVO_HIP_RESORT"] = str(int(rng.choice([0, 2])))
     wgs = int(rng.choice([0, 1, 2, 3, 4, 5, 8, 16, 32]))
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
