@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shape", choices=("tum", "eth3d"), default="tum", help="tum: 640x480, ~3 k points per cloud (the metric's configuration); eth3d: 736x456, ~9.3 k points (BASELINE config 5)")
     ap.add_argument("--gen-workers", type=int, default=0, help="host processes rendering the synthetic pairs (0 = one per host thread, 1 = no fork)")
+    ap.add_argument("--no-adoption", action="store_true", help="do not let finished workgroups help with the pairs of their launch that still run (cvo_batch_set_adoption)")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
     args = ap.parse_args()
     if args.shape == "eth3d":      # BASELINE config 5 defaults: 4 workgroups per pair, 6 launches side by side, 40 workgroups (10 pair slots) each
@@ -274,6 +275,7 @@ def main():
     for _ in range(depth):
         b = ca.CvoBatch(args.pairs, device=local_rank)
         b.set_workgroups(args.workgroups)
+        b.set_adoption(not args.no_adoption)                    # takes effect in launches of one workgroup and one slot per pair: the tail of the job
         if args.max_workgroups:
             b.set_max_workgroups(args.max_workgroups)
         for i, (_, fx, ff, mx, mf) in enumerate(pairs):
@@ -522,7 +524,7 @@ def main():
                                    f"full align() from R=I,T=0,ell=0.15 to convergence",
                        "pairs_per_gpu": n, "points_fixed_mean": float(np.mean(nfs)), "points_moving_mean": float(np.mean(nms)),
                        "iterations_mean": float(np.mean(its)), "iterations_max": int(np.max(its)),
-                       "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth,
+                       "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth, "adoption": (not args.no_adoption),
                        "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": ((("RCCL ncclAllGather enqueued by the C ABI behind each align launch" if gather_mode == "abi" else ("RCCL" if backend == "nccl" else backend) + " all_gather via torch.distributed after the wait") + ", 64-byte result records") if world > 1 else "none (1 GPU)")},
             "roofline": {"bound": "valu_issue", "achieved": valu_rate, "peak": valu_peak, "unit": "wave-instructions/s",
                          "frac": (valu_rate / valu_peak) if valu_rate else None,

@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "cvo_set_pcd_images", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
-    "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups",
+    "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups", "cvo_batch_set_adoption", "cvo_batch_last_adoptions",
     "cvo_adaptive_default_params", "cvo_adaptive_align",
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
@@ -169,6 +169,8 @@ def load_library():
     L.cvo_function_inner_product_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, C.POINTER(InnP)]
     L.cvo_se3_hessian_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, dp, ip]
     L.cvo_batch_set_max_workgroups.argtypes = [vp, C.c_int]
+    L.cvo_batch_set_adoption.argtypes = [vp, C.c_int]
+    L.cvo_batch_last_adoptions.argtypes = [vp, C.POINTER(C.c_int)]
     L.cvo_adaptive_default_params.argtypes = [C.POINTER(AdaptiveParams)]
     L.cvo_adaptive_align.argtypes = [C.c_int, C.POINTER(AdaptiveParams), fp, fp, C.c_int, fp, fp, C.c_int, fp, fp, fp, fp, ip, C.POINTER(AdaptiveRow), C.c_int, ip]
     L.cvo_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
@@ -577,6 +579,15 @@ class CvoBatch:
 
     def set_max_workgroups(self, n: int):
         _check(self.L.cvo_batch_set_max_workgroups(self.h, int(n)))
+
+    def set_adoption(self, on: bool):
+        """finished workgroups help with the pairs of their launch that still run (cvo_hip.h: cvo_batch_set_adoption)"""
+        _check(self.L.cvo_batch_set_adoption(self.h, int(bool(on))))
+
+    def last_adoptions(self) -> int:
+        n = C.c_int(0)
+        _check(self.L.cvo_batch_last_adoptions(self.h, C.byref(n)))
+        return int(n.value)
 
     def reset_states(self):
         _check(self.L.cvo_batch_reset_states(self.h))

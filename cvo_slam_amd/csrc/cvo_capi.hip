@@ -32,7 +32,7 @@ int align_tile_granule();
 int align_blocks_per_cu();
 int align_block_max();
 hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
-                        unsigned launch_tag, unsigned long long* queue, const DevParams& P);
+                        unsigned launch_tag, unsigned long long* queue, const DevParams& P, const unsigned* wgs_submitted, unsigned* wgs_started);
 hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
 hipError_t pcd_launch_pyramid(const uint8_t* bgr, int w, int h, float* I0, float* I1, float* I2, float* dx0, float* dy0, float* abs0, float* abs1, float* abs2,
                               hipStream_t s);
@@ -147,6 +147,25 @@ struct SlotBook {
 };
 SlotBook& slot_book() { static SlotBook b; return b; }
 
+// Adoption (cvo_kernels.hip: finished workgroups help with pairs that still run): a workgroup only offers its help when nothing is
+// queued on the device, i.e. when every workgroup the library has submitted there has started.  Two counters per device: submitted
+// (host-written before each launch, pinned host memory the kernels read) and started (device memory, bumped by every workgroup).
+struct AdoptCounters { int device = -1; unsigned* submitted_host = nullptr; unsigned* submitted_dev = nullptr; unsigned* started_dev = nullptr; };
+AdoptCounters* adopt_counters(int device) {                          // null when they cannot be made: launches then run without adoption
+    static std::mutex mu; static std::vector<AdoptCounters*> all;
+    std::lock_guard<std::mutex> lk(mu);
+    for (AdoptCounters* a : all) if (a->device == device) return a->submitted_host ? a : nullptr;
+    AdoptCounters* a = new AdoptCounters; a->device = device;
+    void* h = nullptr; void* d = nullptr; void* s = nullptr;
+    if (hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess &&
+        hipMalloc(&s, sizeof(unsigned)) == hipSuccess && hipMemset(s, 0, sizeof(unsigned)) == hipSuccess) {
+        a->submitted_host = static_cast<unsigned*>(h); *a->submitted_host = 0u; a->submitted_dev = static_cast<unsigned*>(d); a->started_dev = static_cast<unsigned*>(s);
+    } else { (void)hipGetLastError(); }
+    all.push_back(a);
+    return a->submitted_host ? a : nullptr;
+}
+std::mutex& adopt_submit_mutex() { static std::mutex m; return m; }
+
 // Launch machinery shared by single-object handles and batches.
 struct Engine {
     int device = 0, num_cus = 256;
@@ -167,6 +186,7 @@ struct Engine {
     float last_ms = 0.f;
     bool launched = false;
     int last_G = 1;              // workgroups per pair of the last launch
+    bool adopt = false;          // finished workgroups help with the pairs of their launch that still run (one workgroup and one slot per pair; CVO_HIP_ADOPT)
 
     void release_slots() {
         SlotBook& b = slot_book();
@@ -207,6 +227,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_WGS_PER_CU")) per_cu = std::max(1, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_SKIN")) P.skin = (float)std::atof(e);
         if (const char* e = std::getenv("CVO_HIP_RESORT")) P.resort = std::max(0, std::min(2, std::atoi(e)));
+        if (const char* e = std::getenv("CVO_HIP_ADOPT")) adopt = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
         return CVO_OK;
@@ -457,16 +478,21 @@ struct Engine {
         if ((rc = h_states_in.ensure(sizeof(PairState) * n))) return rc;
         if (2 * (long long)P.max_iter + 2 >= 65536) return fail(CVO_ERR_INVALID, "max_iter must be below 32767");
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)slots * G * nm_pad))) return rc;   // work buffers: per pair SLOT of the launch
-        const size_t plane = (size_t)G * rows_per * capf;                   // workgroup g's nonzero records start at g * rows_per * capf
+        // Adoption (two workgroups share a slot's buffers from the iteration a helper joins): only for one workgroup and one slot per pair
+        // with the cloud resident in LDS; the buffers get the slack of one more 128-row block (rows are dealt in blocks of 128, so two
+        // halves may hold 128 rows more than the whole) and the exchange area room for two members.
+        AdoptCounters* const ac = (adopt && G == 1 && slots == n && y_mode != 0) ? adopt_counters(device) : nullptr;
+        const int Gx = ac ? 2 : G;                                           // members a pair's exchange area has room for
+        const size_t plane = (size_t)G * rows_per * capf + (ac ? (size_t)128 * capf : 0);   // workgroup g's nonzero records start at g * rows_per * capf
         const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
         int capn = 64; while (capn < nm_max / 3 && capn < 4096) capn *= 2;   // longest list a row may have: 1024 at 3 k points, 4096 at 10 k
         if (const char* e = std::getenv("CVO_HIP_ROW_CAP")) capn = std::max(1, std::atoi(e));
         capn = std::max(8, round_up(capn, 4));                               // the candidate phase reads entries four at a time, one step ahead
-        const size_t tplane = (size_t)G * capn * rows_pad;
+        const size_t tplane = (size_t)G * capn * rows_pad + (ac ? (size_t)128 * capn : 0);
         if ((rc = d_jT.ensure(sizeof(uint16_t) * (size_t)slots * tplane))) return rc;
         if ((rc = d_ent.ensure(sizeof(uint2) * (size_t)slots * tplane))) return rc;
         if ((rc = d_surv.ensure(sizeof(uint2) * (size_t)slots * plane))) return rc;
-        const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n * 2 * G * XCH_WORDS;
+        const size_t xch_bytes = sizeof(unsigned long long) * (size_t)n * 2 * Gx * XCH_WORDS;
         if ((rc = d_xch.ensure(xch_bytes))) return rc;
         if (want_trace) {
             if ((rc = d_trace.ensure(sizeof(TraceRow) * (size_t)std::max(1, trace_cap)))) return rc;
@@ -489,7 +515,7 @@ struct Engine {
             D.jT = static_cast<uint16_t*>(d_jT.p);
             D.ent = static_cast<uint2*>(d_ent.p);
             D.surv = static_cast<uint2*>(d_surv.p);
-            D.xch = static_cast<unsigned long long*>(d_xch.p) + (size_t)i * 2 * G * XCH_WORDS;
+            D.xch = static_cast<unsigned long long*>(d_xch.p) + (size_t)i * 2 * Gx * XCH_WORDS;
             D.state = static_cast<PairState*>(d_states.p) + i;
             D.state_in = upload_states ? static_cast<const PairState*>(h_states_in.p) + i : D.state;
             D.state_host = static_cast<PairState*>(h_states.p) + i;
@@ -518,13 +544,22 @@ struct Engine {
             if ((rc = d_queue.ensure(qbytes))) return rc;
             if (fresh || launch_seq == 0) HIP_TRY(hipMemsetAsync(d_queue.p, 0, d_queue.bytes, s));
         }
-        if (G > 1 && (xch_zeroed_bytes != d_xch.bytes || launch_seq == 0)) {
+        if (Gx > 1 && (xch_zeroed_bytes != d_xch.bytes || launch_seq == 0)) {
             HIP_TRY(hipMemsetAsync(d_xch.p, 0, d_xch.bytes, s));
             xch_zeroed_bytes = d_xch.bytes;
         }
         for (hipEvent_t ev : run_after) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         HIP_TRY(hipEventRecord(ev0, s));
-        hipError_t e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P);
+        hipError_t e;
+        if (ac) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
+            std::lock_guard<std::mutex> lk(adopt_submit_mutex());
+            *ac->submitted_host += (unsigned)grid;
+            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P,
+                             ac->submitted_dev, ac->started_dev);
+            if (e != hipSuccess) *ac->submitted_host -= (unsigned)grid;
+        } else {
+            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P, nullptr, nullptr);
+        }
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));
         launched = true;
@@ -1239,6 +1274,14 @@ int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair) {
 int cvo_batch_set_max_workgroups(cvo_batch b, int max_workgroups) {
     if (!b || max_workgroups < 0) return fail(CVO_ERR_INVALID, "bad argument");
     b->eng.max_wgs = max_workgroups; return CVO_OK;
+}
+int cvo_batch_set_adoption(cvo_batch b, int on) { if (!b) return fail(CVO_ERR_INVALID, "null batch"); b->eng.adopt = on != 0; return CVO_OK; }
+int cvo_batch_last_adoptions(cvo_batch b, int* pairs_helped) {
+    if (!b || !pairs_helped) return fail(CVO_ERR_INVALID, "null argument");
+    int rc = b->eng.wait(); if (rc) return rc;
+    const PairState* r = b->eng.results(); int n = 0;
+    for (int i = 0; i < b->last_n; ++i) n += r[i].joined_at > 0 ? 1 : 0;
+    *pairs_helped = n; return CVO_OK;
 }
 int cvo_batch_reset_states(cvo_batch b) { if (!b) return fail(CVO_ERR_INVALID, "null batch"); b->states_dirty = true; return CVO_OK; }
 

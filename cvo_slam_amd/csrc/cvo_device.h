@@ -33,6 +33,7 @@ struct PairState {
     int A_nonzero;            // nnz of the last iteration (Q5)
     int iterations_run;
     int status;
+    int joined_at;            // iteration at which a finished workgroup of the launch joined this pair (adoption), 0 = none
     int rebuilds;             // dense culls executed
     int dense_fallbacks;      // rebuilds whose candidates did not fit the lists (dense per-row path taken)
     long long candidates_total;

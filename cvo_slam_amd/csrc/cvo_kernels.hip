@@ -52,6 +52,7 @@ namespace cvohip {
 #endif                            //  is an experiment knob: measured, no phase gets faster -- DESIGN.md "Measured in round 2")
 constexpr int BLOCK_MAX = CVO_BLOCK_MAX;
 constexpr int MAX_WAVES = BLOCK_MAX / 64;
+constexpr unsigned ADOPT_FREE = 0u, ADOPT_REQUEST = 1u, ADOPT_ACCEPT = 2u, ADOPT_CLOSED = 3u;   // states of a pair's adoption word (cvo_align_kernel)
 constexpr float FAR_ROW = 3.0e18f;    // coordinates of padding rows / columns: d2 overflows, never < threshold
 constexpr float FAR_COL = -3.0e18f;
 
@@ -86,6 +87,11 @@ struct __attribute__((aligned(16))) Shared {
     int refines;           // list rebuilds done by filtering the old lists (ell drops)
     int resort;            // this refinement re-sorts the rows by their new list lengths (phase_refine)
     int cull_next;         // next block pair of the cull to hand out
+    int ws_slot;           // pair slot of the launch whose work buffers this workgroup uses (its own, or the one of the pair it helps with)
+    int adopt_req;         // a finished workgroup of the launch has asked to help with this pair (1 + its block index), seen by the epilogue
+    unsigned adopt_k;      // iteration at which a helper joins the pair it adopted
+    int joined_at;         // owner: iteration at which a helper joined this pair (0 = none)
+    unsigned long long* adopt_word;   // this pair's adoption word in the launch's queue area, or null (no adoption for this pair / any more)
     int dense_fallbacks;
     int rebuild;           // this iteration rebuilds the candidate lists
     int rows_cap;          // entries of the three row/slot tables in LDS (the workgroup's rows, padded)
@@ -604,17 +610,18 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     const PairDesc& D = *Dp;
     Ctx c;
     c.g = g; c.G = G;
-    c.nf = D.nf; c.nm = D.nm; c.nm_pad = D.nm_pad; c.rows_pad = D.rows_pad; c.capn = D.capn;
+    c.nf = D.nf; c.nm = D.nm; c.nm_pad = D.nm_pad; c.capn = D.capn;
     // rows_per / nrows of this workgroup: worked out once per pair (pair_rows: three divisions by G) and kept in Shared -- every
     // phase builds its own Ctx
     const Shared* shc = reinterpret_cast<const Shared*>(cvo_smem);
     c.rows_per = shc->ctx_rows_per; c.nrows = shc->ctx_nrows;
+    c.rows_pad = (c.rows_per + 127) & ~127;                         // = PairDesc::rows_pad for the launch's own G; smaller when a helper has joined (two workgroups share the slot's buffers)
     c.fixed = (const gfloat*)D.fixed; c.moving = (const gfloat*)D.moving;
-    const size_t ws = (size_t)(blockIdx.x / (unsigned)G);           // the launch's pair slot this workgroup belongs to: owner of the work buffers
+    const size_t ws = (size_t)shc->ws_slot;                         // the launch's pair slot whose work buffers this workgroup uses
     c.ybuf = GF4{(gv4f*)D.ybuf + ws * (size_t)D.ws_y_stride + (size_t)g * D.nm_pad};
     c.surv = (gv2u*)D.surv + ws * (size_t)D.ws_surv_stride;
-    c.jT4 = (gv2u*)D.jT + (ws * (size_t)D.ws_list_stride) / 4 + (size_t)g * (D.capn / 4) * D.rows_pad;   // the cull's lists: four 16-bit columns per 8-byte word, word q of local row li at [q][li]
-    c.ent = (gv2u*)D.ent + ws * (size_t)D.ws_list_stride + (size_t)g * D.capn * D.rows_pad;
+    c.jT4 = (gv2u*)D.jT + (ws * (size_t)D.ws_list_stride) / 4 + (size_t)g * (D.capn / 4) * c.rows_pad;   // the cull's lists: four 16-bit columns per 8-byte word, word q of local row li at [q][li]
+    c.ent = (gv2u*)D.ent + ws * (size_t)D.ws_list_stride + (size_t)g * D.capn * c.rows_pad;
     c.xch = (gu64*)D.xch;
     c.fbase = (size_t)g * c.rows_per * D.capf;
     c.flat_cap = c.rows_per * D.capf;
@@ -1506,6 +1513,9 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 #endif
     if (threadIdx.x == 0) {
         const DevParams& P = sh->P;
+        // has a finished workgroup of the launch asked to help with this pair?  (the load returns under the scalar work below)
+        unsigned long long aword = 0;
+        if (sh->adopt_word) aword = __hip_atomic_load((gu64*)sh->adopt_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double B = sh->vals[0], C = sh->vals[1], Dd = sh->vals[2], E = sh->vals[3];
         float omega[3], v[3];
         for (int q = 0; q < 3; ++q) { omega[q] = sh->omega[q]; v[q] = sh->v[q]; }
@@ -1537,6 +1547,7 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
             sh->ell = l;
         }
         sh->stop = stop; sh->step = step; sh->dist = dist;
+        sh->adopt_req = ((unsigned)(aword >> 32) == (sh->launch_tag | ADOPT_REQUEST)) ? 1 + (int)(unsigned)aword : 0;
         const PairDesc& D = *Dp;
         if (g == 0 && D.trace && k < D.trace_cap) {
             TraceRow& tr = D.trace[k];
@@ -1558,13 +1569,25 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 #endif
 }
 
+// ---- Adoption: finished workgroups help with the pairs that are still running (one workgroup per pair, a slot per pair).
+// Alignments take 33 ... 150 iterations: when a job runs out of queued work the last pairs drag on with most CUs idle.  A workgroup
+// that has finished its pair, and finds nothing queued on the device, offers itself to a pair of its launch that is still running:
+//   queue[1 + slot] = {launch tag | state, payload}: FREE (the pair runs alone) -> REQUEST (payload = helper's block; helper's CAS)
+//   -> ACCEPT (payload = iteration of the join; owner's CAS, after it has written the pair's state to PairDesc::state) or back to FREE
+//   (helper's CAS after a timeout); CLOSED when the pair ends (owner).  Both CAS on the same word: either both agree or neither.
+// From the join on the pair runs as G = 2: rows dealt anew (pair_rows), lists rebuilt, partial sums exchanged -- the path G > 1
+// launches always take.  A pair's results do not depend on G beyond the order of the double-precision partial sums (section 4.1).
+
 __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
-                                                                         unsigned launch_tag, int tab_cols, unsigned long long* __restrict__ queue_in, DevParams P) {
+                                                                         unsigned launch_tag, int tab_cols, unsigned long long* __restrict__ queue_in, DevParams P,
+                                                                         const unsigned* wgs_submitted /* host-mapped */, unsigned* wgs_started) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
     const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
     if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
+    const bool adopting = wgs_started != nullptr;                   // set by the host for launches of one workgroup and one slot per pair
+    if (adopting && tid == 0) atomicAdd(wgs_started, 1u);
     const int tgeo = pack_geometry(tile, rows_cap, y_cap);
     gu64* queue = (gu64*)queue_in;
 
@@ -1574,10 +1597,50 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
     // an earlier launch start from 0, so nothing has to be cleared between launches) and passes it to the slot's other workgroups through
     // queue[1 + slot] = {launch tag | pull number, pair}.  With a slot per pair there is nothing to hand out.
     const bool dynamic = slots < n_pairs;
+    const bool adopt_launch = adopting && !dynamic && G == 1;
     for (unsigned pull = 0;; ++pull) {
         int p;
-        if (!dynamic) { if (pull) break; p = slot; }
-        else {
+        int ge = g, Ge = G;                                             // this workgroup's place in the pair it works on
+        unsigned k_join = 0;                                            // > 0: it joins a running pair of another slot at that iteration
+        if (!dynamic && pull == 0) p = slot;
+        else if (!dynamic) {
+            if (!adopt_launch) break;
+            // this workgroup's pair is done.  With nothing queued on the device (every workgroup submitted so far has started), look for
+            // a pair of the launch that still runs alone and offer to help; leave when there is none.
+            if (tid == 0) {
+                int found = -1; unsigned kj = 0;
+                const unsigned sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sub == sta) {
+                    const unsigned long long free_w = (unsigned long long)(launch_tag | ADOPT_FREE) << 32;
+                    const unsigned long long want = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)blockIdx.x;
+                    for (int i = 1; i < slots && found < 0; ++i) {
+                        const int s2 = (slot + i) % slots;
+                        unsigned long long w = __hip_atomic_load(&queue[1 + s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (w != free_w) continue;                  // not started yet, has a helper, asked already, or over
+                        if (!__hip_atomic_compare_exchange_strong(&queue[1 + s2], &w, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                        for (;;) {                                  // the owner answers in its next epilogue
+                            const unsigned long long x = __hip_atomic_load(&queue[1 + s2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned st = (unsigned)(x >> 32) - launch_tag;
+                            if (st == ADOPT_ACCEPT) { found = s2; kj = (unsigned)x; break; }
+                            if (st != ADOPT_REQUEST) break;         // the pair ended meanwhile
+                            if (__builtin_amdgcn_s_memrealtime() - t_start > 200000ull) {   // 2 ms: take the offer back -- unless it has just been accepted
+                                unsigned long long e = want;
+                                if (__hip_atomic_compare_exchange_strong(&queue[1 + s2], &e, free_w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                            }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                    }
+                }
+                sh->cand = found; sh->adopt_k = kj;
+            }
+            __syncthreads();
+            p = sh->cand; k_join = sh->adopt_k;
+            __syncthreads();
+            if (p < 0) break;
+            ge = 1; Ge = 2;
+        } else {
             if (tid == 0) {
                 unsigned long long got = 0;
                 const unsigned long long seq = (unsigned long long)(launch_tag | (pull + 1u)) << 32;
@@ -1605,15 +1668,23 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
         }
         const PairDesc* Dp = descs + p;
         const int nf = Dp->nf, nm = Dp->nm;
-        const int rows_per = ((((nf + ROW_DEAL - 1) / ROW_DEAL) + G - 1) / G) * ROW_DEAL;
+        const int rows_per = ((((nf + ROW_DEAL - 1) / ROW_DEAL) + Ge - 1) / Ge) * ROW_DEAL;
+        const PairState* st_from = k_join ? (const PairState*)Dp->state : Dp->state_in;   // a helper starts from what the pair's owner published
         if (tid < 25) {                                               // R[9], T[3], ell, transform[12]: the head of PairState, one lane per word
-            const float v = ((const gfloat*)Dp->state_in)[tid];
+            const float v = __uint_as_float(__hip_atomic_load((const CVO_GLOBAL unsigned*)st_from + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (tid < 9) sh->R[tid] = v; else if (tid < 12) sh->T[tid - 9] = v; else if (tid == 12) sh->ell = v; else sh->M[tid - 13] = v;
         }
         if (tid == 32) {
-            const PairState* st = Dp->state_in;
-            int rp, nr; pair_rows(nf, g, G, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
-            sh->stop = 0; sh->status = 0; sh->iter_at_break = st->iter; sh->nnz = 0; sh->cand = 0;
+            const PairState* st = st_from;
+            int rp, nr; pair_rows(nf, ge, Ge, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
+            sh->ws_slot = k_join ? p : slot;                          // (one slot per pair when workgroups help each other)
+            sh->adopt_req = 0; sh->adopt_word = nullptr; sh->joined_at = 0;
+            if (adopt_launch && !k_join) {                            // this pair may be helped: its word says so from now on
+                __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_FREE) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh->adopt_word = (unsigned long long*)&queue[1 + slot];
+            }
+            sh->stop = 0; sh->status = 0; sh->nnz = 0; sh->cand = 0;
+            sh->iter_at_break = k_join ? (int)__hip_atomic_load((const CVO_GLOBAL unsigned*)&st->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->iter;
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
             for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
             sh->cand_total = 0;
@@ -1621,7 +1692,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
         }
         __syncthreads();
 
-        int k = 0;
+        int k = (int)k_join;
         // phase timers and counters live in LDS, bumped by thread 0 with fire-and-forget ds_add: as registers of this function they were
         // saved and restored around every phase call (the phases are out of line), ~1 us of lane moves per iteration
         unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
@@ -1633,29 +1704,29 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
         const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
         if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
 
-        if (ok_pair && k < P.max_iter) phase_transform(Dp, g, G, tgeo, y_lds);   // later iterations: done by the epilogue before them
+        if (ok_pair && k < P.max_iter) phase_transform(Dp, ge, Ge, tgeo, y_lds);   // later iterations: done by the epilogue before them
         for (; ok_pair && k < P.max_iter; ++k) {
             if (sh->rebuild == 1) {
                 const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
-                phase_cull(Dp, g, G, tgeo, y_lds);
+                phase_cull(Dp, ge, Ge, tgeo, y_lds);
                 const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
-                phase_sort(Dp, g, G, tgeo, y_lds);
+                phase_sort(Dp, ge, Ge, tgeo, y_lds);
                 if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], __builtin_amdgcn_s_memrealtime() - t_b); }
             } else if (sh->rebuild == 2) {
-                phase_refine(Dp, g, G, tgeo, y_lds, k);
+                phase_refine(Dp, ge, Ge, tgeo, y_lds, k);
             }
             CVO_PHASE(0);
-            phase_candidates(Dp, g, G, tgeo, y_lds, k);
+            phase_candidates(Dp, ge, Ge, tgeo, y_lds, k);
             if (tid == 0) atomicAdd(&sh->cand_total, (unsigned long long)sh->cand);
             CVO_PHASE(1);
             if (sh->status != 0) break;
-            phase_linesearch(Dp, g, G, tgeo, y_lds, k);
+            phase_linesearch(Dp, ge, Ge, tgeo, y_lds, k);
             CVO_PHASE(3);
             if (sh->status != 0) break;
-            phase_epilogue(Dp, g, G, tgeo, y_lds, k, P.max_iter);
+            phase_epilogue(Dp, ge, Ge, tgeo, y_lds, k, P.max_iter);
             CVO_PHASE(5);
 #ifdef CVO_KTRACE   // experiment builds only: the trace row's B..E carry this iteration's phase times (100 MHz ticks) instead
-            if (tid == 0 && g == 0 && Dp->trace && k < Dp->trace_cap) {
+            if (tid == 0 && ge == 0 && Dp->trace && k < Dp->trace_cap) {
                 TraceRow& tr = Dp->trace[k];
                 unsigned long long ticks[10];
                 for (int q = 0; q < 10; ++q) ticks[q] = sh->ticks[q];
@@ -1668,11 +1739,37 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             }
 #endif
             if (sh->stop) { ++k; break; }
+            if (sh->adopt_req && Ge == 1 && k + 1 < P.max_iter) {
+                // A finished workgroup offers to help.  Publish where the pair stands (the head of PairState: R, T, ell, the current
+                // transform; iter) and accept; from the next iteration on this workgroup is member 0 of 2: its rows are dealt anew and
+                // the lists rebuilt.  (The helper may have taken its offer back meanwhile: then nothing changes.)
+                if (tid == 0) {
+                    CVO_GLOBAL unsigned* pub = (CVO_GLOBAL unsigned*)Dp->state;
+                    for (int i = 0; i < 9; ++i) pub[i] = __float_as_uint(sh->R[i]);
+                    for (int i = 0; i < 3; ++i) pub[9 + i] = __float_as_uint(sh->T[i]);
+                    pub[12] = __float_as_uint(sh->ell);
+                    for (int i = 0; i < 12; ++i) pub[13 + i] = __float_as_uint(sh->M[i]);
+                    ((CVO_GLOBAL PairState*)Dp->state)->iter = sh->iter_at_break;
+                    unsigned long long e = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)(sh->adopt_req - 1);
+                    const unsigned long long acc = ((unsigned long long)(launch_tag | ADOPT_ACCEPT) << 32) | (unsigned)(k + 1);
+                    const bool ok = __hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e, acc, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh->adopt_req = ok ? 1 : 0;
+                    if (ok) {
+                        sh->adopt_word = nullptr; sh->joined_at = k + 1;
+                        int rp, nr; pair_rows(nf, 0, 2, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
+                        sh->list_valid = 0; sh->rebuild = 1; sh->dense_mode = 0;
+                    }
+                }
+                __syncthreads();
+                if (sh->adopt_req) Ge = 2;
+                __syncthreads();
+            }
         }
 
         // ---- after the loop (cvo.cpp:815-817): write the pair's state back
         __syncthreads();
-        if (tid == 0 && g == 0) {
+        if (tid == 0 && ge == 0) {
+            if (adopt_launch) __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_CLOSED) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody joins any more
             PairState fin;
             float R[9], T[3], M[12];
             for (int i = 0; i < 9; ++i) { R[i] = sh->R[i]; fin.R[i] = R[i]; }
@@ -1685,6 +1782,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             fin.iterations_run = k;
             fin.status = sh->status;
             fin.rebuilds = sh->rebuilds;
+            fin.joined_at = sh->joined_at;
             fin.dense_fallbacks = sh->dense_fallbacks;
             fin.candidates_total = (long long)sh->cand_total;
             for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
@@ -1903,11 +2001,12 @@ size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab
 int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 
 hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
-                        unsigned launch_tag, unsigned long long* queue, const DevParams& P) {
+                        unsigned launch_tag, unsigned long long* queue, const DevParams& P, const unsigned* wgs_submitted, unsigned* wgs_started) {
     const size_t shmem = align_shared_bytes(tile, rows_cap, y_mode, y_cap, tab_cols);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cvo_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_mode, rows_cap, y_cap, launch_tag, tab_cols, queue, P);
+    hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_mode, rows_cap, y_cap, launch_tag, tab_cols, queue, P,
+                       wgs_submitted, wgs_started);
     return hipGetLastError();
 }
 

@@ -239,6 +239,12 @@ int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair /* 0 = auto: f
  * by side (several batches in flight on their own streams) each take a share; a launch with fewer pair slots than pairs hands its pairs
  * to the slots dynamically, so a slot is never idle behind the longest alignment. */
 int cvo_batch_set_max_workgroups(cvo_batch b, int max_workgroups);
+/* Adoption (off by default): in launches with one workgroup and one slot per pair, a workgroup that has finished its pair and finds
+ * nothing queued on the device offers its help to a pair of the launch that still runs; from the next iteration on that pair runs on two
+ * workgroups.  Shortens the tail of a job whose alignments take different numbers of iterations (33 ... 150); the results are those of
+ * any other workgroup count.  cvo_batch_last_adoptions: pairs of the last launch that were helped. */
+int cvo_batch_set_adoption(cvo_batch b, int on);
+int cvo_batch_last_adoptions(cvo_batch b, int* pairs_helped);
 /* restore every pair's (R,T,ell) to what set_pair/set_state last gave it (bench loops re-run the same inputs) */
 int cvo_batch_reset_states(cvo_batch b);
 /* enqueue one persistent launch aligning pairs [0, n_pairs) on `stream` (a hipStream_t, NULL = the batch's own); asynchronous */

@@ -1,0 +1,55 @@
+"""Adoption (cvo_batch_set_adoption): finished workgroups help with the pairs of their launch that still run.  The results must be
+those of the same batch without it, and it must actually happen when alignments of very different lengths share a launch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(hiplib, pairs, adoption):
+    ca = hiplib
+    b = ca.CvoBatch(len(pairs))
+    b.set_workgroups(1)
+    b.set_adoption(adoption)
+    for i, p in enumerate(pairs):
+        b.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+    return b
+
+
+def test_adoption_happens_and_changes_no_result(hiplib):
+    from cvo_slam_amd import synth
+    pairs = [synth.make_pair(i) for i in range(24)]                   # 33 ... 92 iterations: the short ones finish with the long ones half way
+    ref = _batch(hiplib, pairs, False)
+    ref.align_async(len(pairs)); want = ref.wait(len(pairs))
+    assert ref.last_adoptions() == 0
+    b = _batch(hiplib, pairs, True)
+    helped = 0
+    for rep in range(3):                                            # every launch: same inputs, same results, whoever helped whom
+        b.reset_states(); b.align_async(len(pairs)); got = b.wait(len(pairs))
+        helped += b.last_adoptions()
+        for w, g in zip(want, got):
+            assert g["status"] == 0 and g["iter"] == w["iter"] and g["iterations_run"] == w["iterations_run"] and g["A_nonzero"] == w["A_nonzero"]
+            assert np.array_equal(g["transform"], w["transform"])
+    assert helped >= 3, helped
+    ref.close(); b.close()
+
+
+def test_adoption_with_several_launches_in_flight(hiplib):
+    """Four batch objects on their own streams, launches overlapping: helpers only offer themselves once nothing is queued on the
+    device, and every launch still returns the results of the batch without adoption."""
+    from cvo_slam_amd import synth
+    pairs = [synth.make_pair(100 + i) for i in range(32)]
+    ref = _batch(hiplib, pairs, False)
+    ref.align_async(len(pairs)); want = ref.wait(len(pairs)); ref.close()
+    bs = [_batch(hiplib, pairs, True) for _ in range(4)]
+    helped = 0
+    for rnd in range(3):
+        for b in bs:
+            b.reset_states(); b.align_async(len(pairs))
+        for b in bs:
+            got = b.wait(len(pairs)); helped += b.last_adoptions()
+            for w, g in zip(want, got):
+                assert g["status"] == 0 and g["iter"] == w["iter"] and g["A_nonzero"] == w["A_nonzero"]
+                assert np.array_equal(g["transform"], w["transform"])
+    assert helped >= 1, helped
+    for b in bs: b.close()
