@@ -1548,6 +1548,11 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         }
         sh->stop = stop; sh->step = step; sh->dist = dist;
         sh->adopt_req = ((unsigned)(aword >> 32) == (sh->launch_tag | ADOPT_REQUEST)) ? 1 + (int)(unsigned)aword : 0;
+        if (sh->adopt_word && (unsigned)(aword >> 32) == (sh->launch_tag | ADOPT_FREE) && !stop) {   // tell would-be helpers how far this pair has come (a CAS: an offer made meanwhile stays)
+            unsigned long long e = aword;
+            (void)__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e, ((unsigned long long)(sh->launch_tag | ADOPT_FREE) << 32) | (unsigned)(k + 1),
+                                                       __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const PairDesc& D = *Dp;
         if (g == 0 && D.trace && k < D.trace_cap) {
             TraceRow& tr = D.trace[k];
@@ -1607,33 +1612,47 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             if (!adopt_launch) break;
             // this workgroup's pair is done.  With nothing queued on the device (every workgroup submitted so far has started), look for
             // a pair of the launch that still runs alone and offer to help; leave when there is none.
-            if (tid == 0) {
+            if (tid < 64) {                                           // wave 0: a lane per slot looks, lane 0 asks
                 int found = -1; unsigned kj = 0;
                 const unsigned sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const unsigned sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sub == sta) {
-                    const unsigned long long free_w = (unsigned long long)(launch_tag | ADOPT_FREE) << 32;
-                    const unsigned long long want = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)blockIdx.x;
-                    for (int i = 1; i < slots && found < 0; ++i) {
-                        const int s2 = (slot + i) % slots;
+                for (int attempt = 0; attempt < 4 && found < 0 && sub == sta; ++attempt) {
+                    // the pair that runs alone and has the most left to do, as far as one can tell: the one with the fewest iterations behind it
+                    unsigned key = 0xFFFFFFFFu;                     // iteration << 12 | slot
+                    for (int s2 = tid; s2 < slots; s2 += 64) {
+                        if (s2 == slot) continue;
+                        const unsigned long long w = __hip_atomic_load(&queue[1 + s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(w >> 32) == (launch_tag | ADOPT_FREE)) key = min(key, (min((unsigned)w, 0xFFFFFu) << 12) | (unsigned)s2);
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, off, 64));
+                    if (key == 0xFFFFFFFFu) break;                  // nobody runs alone any more
+                    const int s2 = (int)(key & 0xFFFu);
+                    int got = 0;                                    // lane 0: 1 accepted, 0 try again, -1 (unused)
+                    if (tid == 0) {
                         unsigned long long w = __hip_atomic_load(&queue[1 + s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (w != free_w) continue;                  // not started yet, has a helper, asked already, or over
-                        if (!__hip_atomic_compare_exchange_strong(&queue[1 + s2], &w, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-                        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                        for (;;) {                                  // the owner answers in its next epilogue
-                            const unsigned long long x = __hip_atomic_load(&queue[1 + s2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned st = (unsigned)(x >> 32) - launch_tag;
-                            if (st == ADOPT_ACCEPT) { found = s2; kj = (unsigned)x; break; }
-                            if (st != ADOPT_REQUEST) break;         // the pair ended meanwhile
-                            if (__builtin_amdgcn_s_memrealtime() - t_start > 200000ull) {   // 2 ms: take the offer back -- unless it has just been accepted
-                                unsigned long long e = want;
-                                if (__hip_atomic_compare_exchange_strong(&queue[1 + s2], &e, free_w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        const unsigned long long want = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)blockIdx.x;
+                        if ((unsigned)(w >> 32) == (launch_tag | ADOPT_FREE) &&
+                            __hip_atomic_compare_exchange_strong(&queue[1 + s2], &w, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                            for (;;) {                              // the owner answers in its next epilogue
+                                const unsigned long long x = __hip_atomic_load(&queue[1 + s2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned st = (unsigned)(x >> 32) - launch_tag;
+                                if (st == ADOPT_ACCEPT) { got = 1; kj = (unsigned)x; break; }
+                                if (st != ADOPT_REQUEST) break;     // the pair ended meanwhile
+                                if (__builtin_amdgcn_s_memrealtime() - t_start > 200000ull) {   // 2 ms: take the offer back -- unless it has just been accepted
+                                    unsigned long long e = want;
+                                    const unsigned long long free_w = (unsigned long long)(launch_tag | ADOPT_FREE) << 32;
+                                    if (__hip_atomic_compare_exchange_strong(&queue[1 + s2], &e, free_w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                                }
+                                __builtin_amdgcn_s_sleep(8);
                             }
-                            __builtin_amdgcn_s_sleep(8);
                         }
                     }
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    if (got == 1) found = s2;
                 }
-                sh->cand = found; sh->adopt_k = kj;
+                if (tid == 0) { sh->cand = found; sh->adopt_k = kj; }
             }
             __syncthreads();
             p = sh->cand; k_join = sh->adopt_k;
