@@ -478,17 +478,20 @@ struct Engine {
         if ((rc = h_states_in.ensure(sizeof(PairState) * n))) return rc;
         if (2 * (long long)P.max_iter + 2 >= 65536) return fail(CVO_ERR_INVALID, "max_iter must be below 32767");
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)slots * G * nm_pad))) return rc;   // work buffers: per pair SLOT of the launch
-        // Adoption (two workgroups share a slot's buffers from the iteration a helper joins): only for one workgroup and one slot per pair
-        // with the cloud resident in LDS; the buffers get the slack of one more 128-row block (rows are dealt in blocks of 128, so two
-        // halves may hold 128 rows more than the whole) and the exchange area room for two members.
+        // Adoption (a pair can grow to four workgroups while it runs): only for one workgroup and one slot per pair with the cloud resident
+        // in LDS.  Every member keeps its lists and records in a region of its own, sized for the rows it owns when it joins (make_ctx:
+        // 1 + 1/2 + 1/3 + 1/4 of the rows, each rounded up to blocks of 128), and the exchange area has room for four members
+        // (cvo_kernels.hip: ADOPT_GMAX).
         AdoptCounters* const ac = (adopt && G == 1 && slots == n && y_mode != 0) ? adopt_counters(device) : nullptr;
-        const int Gx = ac ? 2 : G;                                           // members a pair's exchange area has room for
-        const size_t plane = (size_t)G * rows_per * capf + (ac ? (size_t)128 * capf : 0);   // workgroup g's nonzero records start at g * rows_per * capf
+        const int Gx = ac ? 4 : G;                                           // members a pair's exchange area has room for
+        size_t member_rows = 0;                                              // rows of all member regions of a slot under adoption
+        if (ac) { const int nbk = (std::max(nf_max, 1) + 127) / 128; for (int q = 1; q <= 4; ++q) member_rows += (size_t)((nbk + q - 1) / q) * 128; }
+        const size_t plane = ac ? member_rows * capf : (size_t)G * rows_per * capf;   // workgroup g's nonzero records start at g * rows_per * capf
         const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
         int capn = 64; while (capn < nm_max / 3 && capn < 4096) capn *= 2;   // longest list a row may have: 1024 at 3 k points, 4096 at 10 k
         if (const char* e = std::getenv("CVO_HIP_ROW_CAP")) capn = std::max(1, std::atoi(e));
         capn = std::max(8, round_up(capn, 4));                               // the candidate phase reads entries four at a time, one step ahead
-        const size_t tplane = (size_t)G * capn * rows_pad + (ac ? (size_t)128 * capn : 0);
+        const size_t tplane = ac ? member_rows * capn : (size_t)G * capn * rows_pad;
         if ((rc = d_jT.ensure(sizeof(uint16_t) * (size_t)slots * tplane))) return rc;
         if ((rc = d_ent.ensure(sizeof(uint2) * (size_t)slots * tplane))) return rc;
         if ((rc = d_surv.ensure(sizeof(uint2) * (size_t)slots * plane))) return rc;
@@ -522,6 +525,7 @@ struct Engine {
             D.trace = (want_trace && i == 0) ? static_cast<TraceRow*>(d_trace.p) : nullptr;
             D.trace_cap = want_trace ? trace_cap : 0;
             D.trace_len = want_trace ? static_cast<int*>(d_tracelen.p) : nullptr;
+            D.member_regions = ac ? 1 : 0;
         }
         // Steady state = no copy-engine work at all: copies queued on different streams share the DMA engines and a copy behind
         // another stream's running kernel would serialise the launches.  Descriptors go up only when they changed, start states
@@ -539,7 +543,7 @@ struct Engine {
         }
         launch_seq = (launch_seq + 1) & 0xFFFFu;
         {   // pair queue of launches with fewer slots than pairs: head word + one mailbox per slot; tags carry the launch number
-            const size_t qbytes = sizeof(unsigned long long) * (size_t)(1 + num_cus * per_cu);
+            const size_t qbytes = sizeof(unsigned long long) * (size_t)(1 + 2 * num_cus * per_cu);   // head, a mailbox / adoption word per slot, a control word per slot
             const bool fresh = d_queue.bytes < qbytes;
             if ((rc = d_queue.ensure(qbytes))) return rc;
             if (fresh || launch_seq == 0) HIP_TRY(hipMemsetAsync(d_queue.p, 0, d_queue.bytes, s));

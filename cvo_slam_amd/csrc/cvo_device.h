@@ -82,6 +82,8 @@ struct PairDesc {
     TraceRow* trace;         // optional
     int trace_cap;
     int* trace_len;
+    int member_regions;      // adoption launches: member g of a pair keeps its lists and records in a region of its own (sized for the rows it owns
+                             // when it joins, at g + 1 members) instead of sharing one region cut into G parts -- see make_ctx
 };
 
 // adaptive-ell variant (acvo::align, thirdparty/cvo/src/adaptive_cvo.cpp:490-555)

@@ -53,6 +53,10 @@ namespace cvohip {
 constexpr int BLOCK_MAX = CVO_BLOCK_MAX;
 constexpr int MAX_WAVES = BLOCK_MAX / 64;
 constexpr unsigned ADOPT_FREE = 0u, ADOPT_REQUEST = 1u, ADOPT_ACCEPT = 2u, ADOPT_CLOSED = 3u;   // states of a pair's adoption word (cvo_align_kernel)
+#ifndef CVO_ADOPT_GMAX
+#define CVO_ADOPT_GMAX 4
+#endif
+constexpr int ADOPT_GMAX = CVO_ADOPT_GMAX;                                    // workgroups a pair can grow to by adoption (the host sizes the exchange area and the buffers' slack for it)
 constexpr float FAR_ROW = 3.0e18f;    // coordinates of padding rows / columns: d2 overflows, never < threshold
 constexpr float FAR_COL = -3.0e18f;
 
@@ -620,10 +624,22 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     const size_t ws = (size_t)shc->ws_slot;                         // the launch's pair slot whose work buffers this workgroup uses
     c.ybuf = GF4{(gv4f*)D.ybuf + ws * (size_t)D.ws_y_stride + (size_t)g * D.nm_pad};
     c.surv = (gv2u*)D.surv + ws * (size_t)D.ws_surv_stride;
-    c.jT4 = (gv2u*)D.jT + (ws * (size_t)D.ws_list_stride) / 4 + (size_t)g * (D.capn / 4) * c.rows_pad;   // the cull's lists: four 16-bit columns per 8-byte word, word q of local row li at [q][li]
-    c.ent = (gv2u*)D.ent + ws * (size_t)D.ws_list_stride + (size_t)g * D.capn * c.rows_pad;
+    // Where member g's part of the slot's buffers starts, in rows.  A launch with a fixed G cuts the slot into G equal parts.  A launch
+    // whose pairs can gain members on the way (adoption) gives member g a region of its own, sized for the rows it owns when it joins
+    // (g + 1 members): a region is then only ever written and read by one workgroup -- the L2 caches of the XCDs are not coherent with
+    // each other for plain loads and stores inside a kernel, so a region handed from one workgroup to another could be overwritten by the
+    // first one's late write-backs.
+    size_t off_rows = (size_t)g * c.rows_pad, off_recs = (size_t)g * c.rows_per;
+    if (D.member_regions) {
+        const int nblocks = (D.nf + ROW_DEAL - 1) / ROW_DEAL;
+        off_rows = 0;
+        for (int j = 0; j < g; ++j) off_rows += (size_t)((nblocks + j) / (j + 1)) * ROW_DEAL;   // rows_per at j + 1 members (a multiple of 128)
+        off_recs = off_rows;
+    }
+    c.jT4 = (gv2u*)D.jT + (ws * (size_t)D.ws_list_stride) / 4 + off_rows * (D.capn / 4);   // the cull's lists: four 16-bit columns per 8-byte word, word q of local row li at [q][li]
+    c.ent = (gv2u*)D.ent + ws * (size_t)D.ws_list_stride + off_rows * D.capn;
     c.xch = (gu64*)D.xch;
-    c.fbase = (size_t)g * c.rows_per * D.capf;
+    c.fbase = off_recs * D.capf;
     c.flat_cap = c.rows_per * D.capf;
     return c;
 }
@@ -1638,7 +1654,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                             for (;;) {                              // the owner answers in its next epilogue
                                 const unsigned long long x = __hip_atomic_load(&queue[1 + s2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                                 const unsigned st = (unsigned)(x >> 32) - launch_tag;
-                                if (st == ADOPT_ACCEPT) { got = 1; kj = (unsigned)x; break; }
+                                if (st == ADOPT_ACCEPT) { got = 1; kj = (unsigned)x; break; }   // members after the join << 24 | this helper's index << 16 | iteration of the join
                                 if (st != ADOPT_REQUEST) break;     // the pair ended meanwhile
                                 if (__builtin_amdgcn_s_memrealtime() - t_start > 200000ull) {   // 2 ms: take the offer back -- unless it has just been accepted
                                     unsigned long long e = want;
@@ -1655,10 +1671,10 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                 if (tid == 0) { sh->cand = found; sh->adopt_k = kj; }
             }
             __syncthreads();
-            p = sh->cand; k_join = sh->adopt_k;
+            p = sh->cand;
+            { const unsigned kj = sh->adopt_k; k_join = kj & 0xFFFFu; ge = (int)((kj >> 16) & 0xFFu); Ge = (int)(kj >> 24); }
             __syncthreads();
             if (p < 0) break;
-            ge = 1; Ge = 2;
         } else {
             if (tid == 0) {
                 unsigned long long got = 0;
@@ -1710,6 +1726,10 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
+        // a helper has read what the owner published for it: if the pair may grow further, its word takes offers again (not earlier --
+        // the owner publishes the next newcomer's state in the same place)
+        if (k_join && Ge < ADOPT_GMAX && tid == 0)
+            __hip_atomic_store(&queue[1 + p], ((unsigned long long)(launch_tag | ADOPT_FREE) << 32) | k_join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         int k = (int)k_join;
         // phase timers and counters live in LDS, bumped by thread 0 with fire-and-forget ds_add: as registers of this function they were
@@ -1758,30 +1778,51 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             }
 #endif
             if (sh->stop) { ++k; break; }
-            if (sh->adopt_req && Ge == 1 && k + 1 < P.max_iter) {
-                // A finished workgroup offers to help.  Publish where the pair stands (the head of PairState: R, T, ell, the current
-                // transform; iter) and accept; from the next iteration on this workgroup is member 0 of 2: its rows are dealt anew and
-                // the lists rebuilt.  (The helper may have taken its offer back meanwhile: then nothing changes.)
+            if (adopt_launch && (Ge > 1 || sh->adopt_req) && k + 1 < P.max_iter) {
+                // Members of a pair that has (or is about to get) helpers agree on the member count of the next iteration: the owner
+                // decides -- it accepts an offer it saw in its epilogue, if the pair may still grow -- and writes {iteration, members}
+                // into the pair's control word; the helpers wait for that word.  On a change every member deals its rows anew
+                // (pair_rows) and the lists are rebuilt; the newcomer starts from the state the owner published (the head of
+                // PairState: R, T, ell, the current transform; iter) as member `old count`.
                 if (tid == 0) {
-                    CVO_GLOBAL unsigned* pub = (CVO_GLOBAL unsigned*)Dp->state;
-                    for (int i = 0; i < 9; ++i) pub[i] = __float_as_uint(sh->R[i]);
-                    for (int i = 0; i < 3; ++i) pub[9 + i] = __float_as_uint(sh->T[i]);
-                    pub[12] = __float_as_uint(sh->ell);
-                    for (int i = 0; i < 12; ++i) pub[13 + i] = __float_as_uint(sh->M[i]);
-                    ((CVO_GLOBAL PairState*)Dp->state)->iter = sh->iter_at_break;
-                    unsigned long long e = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)(sh->adopt_req - 1);
-                    const unsigned long long acc = ((unsigned long long)(launch_tag | ADOPT_ACCEPT) << 32) | (unsigned)(k + 1);
-                    const bool ok = __hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e, acc, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sh->adopt_req = ok ? 1 : 0;
-                    if (ok) {
-                        sh->adopt_word = nullptr; sh->joined_at = k + 1;
-                        int rp, nr; pair_rows(nf, 0, 2, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
+                    int g_next = Ge;
+                    gu64* ctrl = &queue[1 + slots + (ge == 0 ? slot : (int)sh->ws_slot)];
+                    if (ge == 0) {
+                        if (sh->adopt_req && Ge < ADOPT_GMAX) {
+                            CVO_GLOBAL unsigned* pub = (CVO_GLOBAL unsigned*)Dp->state;
+                            for (int i = 0; i < 9; ++i) pub[i] = __float_as_uint(sh->R[i]);
+                            for (int i = 0; i < 3; ++i) pub[9 + i] = __float_as_uint(sh->T[i]);
+                            pub[12] = __float_as_uint(sh->ell);
+                            for (int i = 0; i < 12; ++i) pub[13 + i] = __float_as_uint(sh->M[i]);
+                            ((CVO_GLOBAL PairState*)Dp->state)->iter = sh->iter_at_break;
+                            unsigned long long e = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)(sh->adopt_req - 1);
+                            const unsigned long long acc = ((unsigned long long)(launch_tag | ADOPT_ACCEPT) << 32) | ((unsigned)(Ge + 1) << 24) | ((unsigned)Ge << 16) | (unsigned)((k + 1) & 0xFFFF);
+                            if (__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e, acc, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                g_next = Ge + 1;
+                                if (!sh->joined_at) sh->joined_at = k + 1;
+                                if (g_next >= ADOPT_GMAX) sh->adopt_word = nullptr;     // full: no more offers are looked at (the newcomer leaves the word as it is)
+                            }
+                        }
+                        if (g_next > 1) __hip_atomic_store(ctrl, ((unsigned long long)(launch_tag | (unsigned)((k + 1) & 0xFFFF)) << 32) | (unsigned)g_next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                        for (;;) {
+                            const unsigned long long x = __hip_atomic_load(ctrl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(x >> 32) == (launch_tag | (unsigned)((k + 1) & 0xFFFF))) { g_next = (int)(unsigned)x; break; }
+                            if (__builtin_amdgcn_s_memrealtime() - t_start > 300000000ull) { sh->status = 6; break; }   // 3 s: the owner is gone
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    sh->adopt_req = g_next;
+                    if (g_next != Ge) {
+                        int rp, nr; pair_rows(nf, ge, g_next, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
                         sh->list_valid = 0; sh->rebuild = 1; sh->dense_mode = 0;
                     }
                 }
                 __syncthreads();
-                if (sh->adopt_req) Ge = 2;
+                Ge = sh->adopt_req;
                 __syncthreads();
+                if (sh->status != 0) break;
             }
         }
 
