@@ -24,13 +24,13 @@ def test_adoption_happens_and_changes_no_result(hiplib):
     assert ref.last_adoptions() == 0
     b = _batch(hiplib, pairs, True)
     helped = 0
-    for rep in range(3):                                            # every launch: same inputs, same results, whoever helped whom
+    for rep in range(8):                                            # every launch: same inputs, same results, whoever helped whom (pairs grow to four workgroups)
         b.reset_states(); b.align_async(len(pairs)); got = b.wait(len(pairs))
         helped += b.last_adoptions()
         for w, g in zip(want, got):
             assert g["status"] == 0 and g["iter"] == w["iter"] and g["iterations_run"] == w["iterations_run"] and g["A_nonzero"] == w["A_nonzero"]
             assert np.array_equal(g["transform"], w["transform"])
-    assert helped >= 3, helped
+    assert helped >= 8, helped
     ref.close(); b.close()
 
 
