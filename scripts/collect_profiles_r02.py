@@ -34,7 +34,7 @@ t["tum"] = {"kernel": "cvo_align_kernel", "shape": "tum", "pairs": 64,
             "hbm_bytes_per_launch": s["hbm_bytes_per_launch_corrected"], "hbm_bytes_per_launch_uncorrected": s["hbm_bytes_per_launch_uncorrected"],
             "valu_wave_instructions_per_launch": s["per_launch"]["SQ_INSTS_VALU"],
             "valu_half_rate_share": s["valu_classes"]["half_rate_share"], "valu_transcendental_share": s["valu_classes"]["transcendental_share"],
-            "source": f"profiles/r02_pmc_summary.json (rocprofv3 --pmc passes of scripts/pmc_run.sh at commit {commit}: 64 pairs, 3072 points, one workgroup per pair, one step in flight)",
+            "source": f"profiles/r02_pmc_summary.json (rocprofv3 --pmc passes of scripts/pmc_run.sh at commit {commit}: 64 pairs, 3072 points, one workgroup per pair, one step in flight, adoption off: the work of a launch)",
             "commit": commit}
 json.dump(t, open(tpath, "w"), indent=1)
 for row in csv.DictReader(open(os.path.join(DST, "r02_kernel_stats.csv"))):
