@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PAIRS_PER_GPU = 64
+ADOPTION_DEFAULT = True        # cvo_batch_set_adoption in the timed loops unless --no-adoption (tests/test_gpu_config3.py runs both modes against the oracle)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_VALU_PEAK_TF = 157.3      # MI355X_MICROARCH.md: peak FP32 vector
 
@@ -227,6 +228,8 @@ def main():
     ap.add_argument("--shape", choices=("tum", "eth3d"), default="tum", help="tum: 640x480, ~3 k points per cloud (the metric's configuration); eth3d: 736x456, ~9.3 k points (BASELINE config 5)")
     ap.add_argument("--gen-workers", type=int, default=0, help="host processes rendering the synthetic pairs (0 = one per host thread, 1 = no fork)")
     ap.add_argument("--no-adoption", action="store_true", help="do not let finished workgroups help with the pairs of their launch that still run (cvo_batch_set_adoption)")
+    ap.add_argument("--adoption", action="store_true", help="force adoption on (whatever ADOPTION_DEFAULT says)")
+    ap.add_argument("--total-pairs", type=int, default=0, help="pairs per step over ALL ranks, dealt in contiguous blocks (cvo_shard_range: blocks may differ by one, the gather pads); 0 = --pairs per rank")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
     args = ap.parse_args()
     if args.shape == "eth3d":      # BASELINE config 5 defaults: 4 workgroups per pair, 6 launches side by side, 40 workgroups (10 pair slots) each
@@ -245,8 +248,14 @@ def main():
 
     global _SHAPE
     _SHAPE = args.shape
+    adoption = args.adoption or (ADOPTION_DEFAULT and not args.no_adoption)
+    # this rank's block of the step's pairs (contiguous blocks; with --total-pairs they may differ by one between ranks)
+    total_pairs = args.total_pairs or world * args.pairs
+    base, rem = divmod(total_pairs, world)
+    first_pair, n_mine = rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+    n_block = (total_pairs + world - 1) // world
     # host-side input generation first (forks; no GPU state yet)
-    pairs = generate_pairs(rank * args.pairs, args.pairs, args.gen_workers)
+    pairs = generate_pairs(first_pair, n_mine, args.gen_workers) if n_mine else []
     if rank == 0:
         print(f"[bench] generated {len(pairs)} pairs per rank; starting GPU work", file=sys.stderr, flush=True)
 
@@ -273,21 +282,22 @@ def main():
     depth = max(1, args.streams)
     batches = []
     for _ in range(depth):
-        b = ca.CvoBatch(args.pairs, device=local_rank)
+        b = ca.CvoBatch(max(1, n_mine), device=local_rank)
         b.set_workgroups(args.workgroups)
-        b.set_adoption(not args.no_adoption)                    # takes effect in launches of one workgroup and one slot per pair: the tail of the job
+        b.set_adoption(adoption)                                # takes effect in launches of one workgroup and one slot per pair: the tail of the job
         if args.max_workgroups:
             b.set_max_workgroups(args.max_workgroups)
-        for i, (_, fx, ff, mx, mf) in enumerate(pairs):
-            b.set_pair(i, fx, ff, mx, mf)
         batches.append(b)
+    prepared = ca.CvoBatch.prepare_pairs([(fx, ff, mx, mf) for (_, fx, ff, mx, mf) in pairs]) if pairs else None
+    for b in batches:
+        if prepared:
+            b.set_pairs(prepared)                               # cvo_batch_set_pairs: one hand-over for the whole batch
     batch = batches[0]
 
     from cvo_slam_amd import shard, api
-    n = args.pairs
-    assert list(api.shard_range(world * n, rank, world)) == list(range(rank * n, rank * n + n))      # cvo_shard_range: contiguous blocks
-    sends = [torch.zeros((n, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda") for _ in range(depth)]
-    recvs = [torch.zeros((world * n, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda") for _ in range(depth)] if world > 1 else []
+    n = n_mine
+    assert list(api.shard_range(total_pairs, rank, world)) == list(range(first_pair, first_pair + n)) and api.shard_block(total_pairs, world) == n_block   # cvo_shard_range: contiguous blocks
+    recvs = [torch.zeros((world * n_block, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda") for _ in range(depth)] if world > 1 else []
     gathered = None
     inflight = []                                  # batch objects with a launch not yet waited for
     # The gather: ONE RCCL all-gather of the 64-byte records per step, enqueued by the C ABI behind the align launch on its
@@ -329,27 +339,41 @@ def main():
 
     kernel_ms = []                                 # HIP-event duration of every launch, on the stream it ran on
 
+    launch_status = [0] * depth                    # what cvo_batch_align_async returned for the step a batch object holds
+    send_ptr = [0] * depth
+
     def finish(bi):
         nonlocal gathered
-        batches[bi].wait()
-        kernel_ms.append(batches[bi].last_launch()["kernel_ms"])
+        if n and launch_status[bi] == 0:
+            batches[bi].wait()
+            kernel_ms.append(batches[bi].last_launch()["kernel_ms"])
+        else:
+            kernel_ms.append(0.0)
+            torch.cuda.synchronize()               # no launch to wait for: the rank's gather ran on the batch object's own stream
         if world > 1:
             if comm is not None:
                 gathered = recvs[bi]                                           # already there: the all-gather ran behind the kernel
-            else:
-                gathered = shard.gather_results(sends[bi], world * n, world)   # the SE(3) results of every rank, everywhere
+            else:                                                              # rehearsal backends: the rank's padded block through torch.distributed
+                torch.cuda.synchronize()
+                gathered = shard.gather_blocks(shard.device_view(send_ptr[bi], n_block), world)
 
     def step(i):
         bi = i % depth
         if bi in inflight:                         # the object is reused: its previous step must be complete first
             inflight.remove(bi); finish(bi)
         b = batches[bi]
-        b.reset_states()                           # every step starts from R=I, T=0, ell=0.15
-        b.align_async(n)
+        launch_status[bi] = 0
+        if n:
+            try:
+                b.reset_states()                   # every step starts from R=I, T=0, ell=0.15
+                b.align_async(n)
+            except ca.CvoError as e:               # the rank still enters the collective below: its records carry the status
+                launch_status[bi] = e.code
+        # the 64-byte records are written by the align kernel itself; every rank sends n_block of them (its own, then padding)
         if comm is not None:
-            b.gather_results(comm, n, recvs[bi].data_ptr())   # pack + ncclAllGather on the launch's stream
-        else:
-            b.results_to_device(sends[bi].data_ptr(), n)      # same stream, behind the kernel
+            b.gather_results_padded(comm, n, n_block, recvs[bi].data_ptr(), launch_status[bi])   # ONE ncclAllGather on the launch's stream
+        elif world > 1:
+            send_ptr[bi] = b.padded_records(n, n_block, launch_status[bi])
         inflight.append(bi)
 
     def drain():
@@ -380,13 +404,15 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     assert len(kernel_ms) == args.steps
+    if n == 0:                                     # a rank without pairs (fewer pairs than ranks): it only takes part in the gathers
+        kernel_ms[:] = [0.0]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    results = batch.wait(n)
-    info = batch.last_launch()
+    results = batch.wait(n) if n else []
+    info = batch.last_launch() if n else {}
 
     # Secondary figure ("alignments incl. the post-align score block"): every step also queues the tracker's score
     # block (4 inner products + 1 Hessian per pair, cvo.cpp:475-503) behind its align launch and collects it with the results.
@@ -435,8 +461,7 @@ def main():
             if bi in busy:
                 busy.remove(bi); batches[bi].wait()
             b = batches[bi]
-            for q, (_, fx, ff, mx, mf) in enumerate(pairs):
-                b.set_pair(q, fx, ff, mx, mf)
+            b.set_pairs(prepared)                  # cvo_batch_set_pairs: the batch's host arrays, as they are, in one hand-over
             b.align_async(n)
             busy.append(bi)
 
@@ -454,7 +479,8 @@ def main():
         el3 = time.perf_counter() - t3
         mb = sum(fx.nbytes + ff.nbytes + mx.nbytes + mf.nbytes for (_, fx, ff, mx, mf) in pairs) / 1e6
         with_upload = {"value": n * k3 / el3, "unit": "alignments/s", "steps": k3, "ms_per_step": 1e3 * el3 / k3, "host_MB_per_step": mb,
-                       "note": "clouds cross the boundary as host buffers every step (one host thread packs and copies them)"}
+                       "note": "clouds cross the boundary as host buffers every step (cvo_batch_set_pairs: the arrays are copied as they are into a pinned block, "
+                               "one host-to-device copy, one kernel builds the device layout)"}
         batch.reset_states(); batch.align_async(n); batch.wait()
     if rank == 0 and os.environ.get("CVO_BENCH_PHASES"):
         ph = batch.last_phase_seconds(); its_all = sum(r["iterations_run"] for r in results)
@@ -472,7 +498,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved_gbs = bytes_launch / (k_ms * 1e-3) / 1e9
         achieved_tf = flops_launch / (k_ms * 1e-3) / 1e12
-        value = world * n * args.steps / elapsed
+        value = total_pairs * args.steps / elapsed
         step_ms_rank = 1e3 * elapsed / args.steps          # one launch retires every step_ms_rank on this GPU
         overlap = k_ms / step_ms_rank                      # launches running side by side, on average
         # Counter figures come from separate rocprofv3 --pmc passes over this kernel (scripts/pmc_run.sh -> profiles/pmc_traffic.json,
@@ -520,11 +546,11 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n} independent synthetic {'640x480 TUM' if args.shape == 'tum' else '736x456 ETH3D'}-shape RGB-D pairs per GPU per step "
-                                   f"(BASELINE config {'3' if args.shape == 'tum' else '5'}; {world * n} pairs per step at {world} GPU(s); config 4 = 512 pairs at 8 GPUs), "
+                                   f"(BASELINE config {'3' if args.shape == 'tum' else '5'}; {total_pairs} pairs per step at {world} GPU(s); config 4 = 512 pairs at 8 GPUs), "
                                    f"full align() from R=I,T=0,ell=0.15 to convergence",
                        "pairs_per_gpu": n, "points_fixed_mean": float(np.mean(nfs)), "points_moving_mean": float(np.mean(nms)),
                        "iterations_mean": float(np.mean(its)), "iterations_max": int(np.max(its)),
-                       "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth, "adoption": (not args.no_adoption),
+                       "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth, "adoption": adoption,
                        "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": ((("RCCL ncclAllGather enqueued by the C ABI behind each align launch" if gather_mode == "abi" else ("RCCL" if backend == "nccl" else backend) + " all_gather via torch.distributed after the wait") + ", 64-byte result records") if world > 1 else "none (1 GPU)")},
             "roofline": {"bound": "valu_issue", "achieved": valu_rate, "peak": valu_peak, "unit": "wave-instructions/s",
                          "frac": (valu_rate / valu_peak) if valu_rate else None,
@@ -593,8 +619,9 @@ def main():
 
     if world > 1:
         if gathered is not None and rank == 0:
-            g = gathered.cpu().numpy()
-            assert g.shape == (world * n, shard.RESULT_FLOATS) and np.all(g[:, 15] == 0), "gathered records incomplete or a rank reported an error"
+            table, first_err = api.compact_records(gathered.cpu().numpy(), total_pairs, world)      # cvo_compact_records: global pair order, padding dropped
+            assert table.shape == (total_pairs, shard.RESULT_FLOATS) and first_err == 0, f"gathered records incomplete or a rank reported an error (status {first_err})"
+            print(f"[bench] gathered {total_pairs} records from {world} ranks (blocks of {n_block}, {world * n_block - total_pairs} padding records)", file=sys.stderr, flush=True)
         if comm is not None:
             comm.close()
         dist.destroy_process_group()

@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-CVO_OK, CVO_ERR_NOT_INITIALIZED, CVO_ERR_EMPTY_CLOUD, CVO_ERR_HIP, CVO_ERR_INVALID, CVO_ERR_NO_DEVICE, CVO_ERR_TIMEOUT = range(7)
+CVO_OK, CVO_ERR_NOT_INITIALIZED, CVO_ERR_EMPTY_CLOUD, CVO_ERR_HIP, CVO_ERR_INVALID, CVO_ERR_NO_DEVICE, CVO_ERR_TIMEOUT, CVO_ERR_PADDING = range(8)
 SLOT_FIXED, SLOT_MOVING, SLOT_PREVIOUS = 0, 1, 2
 RESULT_FLOATS = 16
 
@@ -93,6 +93,8 @@ ABI_SYMBOLS = [
     "cvo_adaptive_default_params", "cvo_adaptive_align",
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
+    "cvo_batch_set_pairs", "cvo_batch_result_records", "cvo_shard_block", "cvo_batch_gather_results_padded", "cvo_batch_padded_records",
+    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v",
 ]
 
 _lib = None
@@ -185,6 +187,15 @@ def load_library():
     L.cvo_multi_batch.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.cvo_multi_align_async.argtypes = [vp, C.c_int]
     L.cvo_multi_wait.argtypes = [vp, C.c_int, fp]
+    pp = C.POINTER(fp)
+    L.cvo_batch_set_pairs.argtypes = [vp, C.c_int, C.c_int, pp, pp, ip, pp, pp, ip]
+    L.cvo_batch_result_records.argtypes = [vp, C.POINTER(vp)]
+    L.cvo_shard_block.argtypes = [C.c_int, C.c_int]
+    L.cvo_batch_gather_results_padded.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.cvo_batch_padded_records.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.cvo_compact_records.argtypes = [fp, C.c_int, C.c_int, fp, ip]
+    L.cvo_gather_results_padded.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, ip, C.c_int, ip, C.POINTER(vp)]
+    L.cvo_multi_align_async_v.argtypes = [vp, ip]
     _lib = L
     return L
 
@@ -472,6 +483,20 @@ def shard_range(n_pairs: int, rank: int, world: int) -> range:
     return range(first.value, first.value + count.value)
 
 
+def shard_block(n_pairs: int, world: int) -> int:
+    """cvo_shard_block: records every rank contributes to a gather (its own, then padding)."""
+    return int(load_library().cvo_shard_block(n_pairs, world))
+
+
+def compact_records(gathered, n_pairs: int, world: int):
+    """cvo_compact_records: rank-major gathered blocks -> (n_pairs, 16) records in global pair order, first non-zero status."""
+    g = np.ascontiguousarray(gathered, np.float32)
+    assert g.size == world * shard_block(n_pairs, world) * RESULT_FLOATS, g.shape
+    out = np.zeros((n_pairs, RESULT_FLOATS), np.float32); err = C.c_int(0); fp = C.POINTER(C.c_float)
+    _check(load_library().cvo_compact_records(g.ctypes.data_as(fp), n_pairs, world, out.ctypes.data_as(fp), C.byref(err)))
+    return out, err.value
+
+
 def comm_unique_id() -> bytes:
     buf = C.create_string_buffer(COMM_ID_BYTES)
     _check(load_library().cvo_comm_unique_id(buf))
@@ -513,7 +538,13 @@ class CvoMulti:
         return CvoBatch._borrow(h, self.max_pairs, self.params)
 
     def align_async(self, n: int):
-        _check(self.L.cvo_multi_align_async(self.h, n)); self._n = n
+        self._n = n
+        _check(self.L.cvo_multi_align_async(self.h, n))
+
+    def align_async_v(self, n_pairs):
+        """n_pairs[i] pairs on device i; every device contributes max(n_pairs) records (padding behind its own)."""
+        arr = (C.c_int * len(self.devices))(*[int(v) for v in n_pairs]); self._n = max(int(v) for v in n_pairs)
+        _check(self.L.cvo_multi_align_async_v(self.h, arr))
 
     def wait(self, from_device: int = 0):
         out = np.zeros((len(self.devices) * self._n, RESULT_FLOATS), np.float32)
@@ -551,8 +582,26 @@ class CvoBatch:
         return b
 
     def gather_results(self, comm: "CvoComm", n: int, recv_device_ptr: int):
-        """pack + ONE ncclAllGather of the first n result records, enqueued behind the last launch on its stream."""
+        """ONE ncclAllGather of the first n result records (the align kernel wrote them), enqueued behind the last launch on its
+        stream.  n must be the same on every rank; see gather_results_padded."""
         _check(self.L.cvo_batch_gather_results(self.h, comm.h, n, C.c_void_p(recv_device_ptr)))
+
+    def gather_results_padded(self, comm: "CvoComm", n_valid: int, n_block: int, recv_device_ptr: int, launch_status: int = 0):
+        """Every rank sends n_block records: its n_valid own, then padding (status CVO_ERR_PADDING); launch_status != 0: this rank's
+        launch failed, all its records carry that code -- the rank still enters the collective."""
+        _check(self.L.cvo_batch_gather_results_padded(self.h, comm.h, n_valid, n_block, launch_status, C.c_void_p(recv_device_ptr)))
+
+    def padded_records(self, n_valid: int, n_block: int, launch_status: int = 0) -> int:
+        """Device address of the block this rank would send (for launchers that run the collective themselves)."""
+        p = C.c_void_p()
+        _check(self.L.cvo_batch_padded_records(self.h, n_valid, n_block, launch_status, C.byref(p)))
+        return int(p.value)
+
+    def result_records(self) -> int:
+        """Device address of the record table the align kernel writes (n x 16 floats), valid once the launch's stream has drained."""
+        p = C.c_void_p()
+        _check(self.L.cvo_batch_result_records(self.h, C.byref(p)))
+        return int(p.value)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value and getattr(self, "owned", True):
@@ -569,6 +618,22 @@ class CvoBatch:
         fx, fxp, ff, ffp = _cloud_args(fixed_xyz, fixed_feat)
         mx, mxp, mf, mfp = _cloud_args(moving_xyz, moving_feat)
         _check(self.L.cvo_batch_set_pair(self.h, p, fxp, ffp, fx.shape[0], mxp, mfp, mx.shape[0]))
+
+    @staticmethod
+    def prepare_pairs(pairs):
+        """pairs: sequence of (fixed_xyz, fixed_feat, moving_xyz, moving_feat).  Returns the pointer tables cvo_batch_set_pairs takes
+        (and keeps the arrays alive), so that a loop handing the same host buffers over every step pays for the hand-over only."""
+        fp = C.POINTER(C.c_float)
+        keep = [tuple(_cloud_args(fx, ff)[0::2] + _cloud_args(mx, mf)[0::2]) for fx, ff, mx, mf in pairs]
+        n = len(keep)
+        tab = lambda k: (fp * n)(*[q[k].ctypes.data_as(fp) for q in keep])
+        return dict(n=n, keep=keep, fx=tab(0), ff=tab(1), mx=tab(2), mf=tab(3),
+                    nf=(C.c_int * n)(*[q[0].shape[0] for q in keep]), nm=(C.c_int * n)(*[q[2].shape[0] for q in keep]))
+
+    def set_pairs(self, prepared, first: int = 0):
+        """cvo_batch_set_pairs: one hand-over for all pairs of `prepared` (prepare_pairs), or of a sequence of cloud tuples."""
+        pr = prepared if isinstance(prepared, dict) else self.prepare_pairs(prepared)
+        _check(self.L.cvo_batch_set_pairs(self.h, first, pr["n"], pr["fx"], pr["ff"], pr["nf"], pr["mx"], pr["mf"], pr["nm"]))
 
     def set_state(self, p, R, T, ell):
         r, rp = _f(np.asarray(R).reshape(9)); t, tp = _f(np.asarray(T).reshape(3))

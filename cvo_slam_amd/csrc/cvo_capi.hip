@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cvo_hip.h"
@@ -33,7 +34,11 @@ int align_blocks_per_cu();
 int align_block_max();
 hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
                         unsigned launch_tag, unsigned long long* queue, const DevParams& P, const unsigned* wgs_submitted, unsigned* wgs_started);
-hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream);
+int align_adopt_gmax();
+hipError_t launch_fill_records(float* rec, int from, int to, int status, hipStream_t stream);
+hipError_t launch_copy_records(const float* src, float* dst, int n, hipStream_t stream);
+hipError_t launch_pack_clouds(const float* raw, const PackDesc* descs, int n_clouds, int n_max, hipStream_t s);
+SelfCacheEntry* score_self_cache(float* gbox, int n);
 hipError_t pcd_launch_pyramid(const uint8_t* bgr, int w, int h, float* I0, float* I1, float* I2, float* dx0, float* dy0, float* abs0, float* abs1, float* abs2,
                               hipStream_t s);
 hipError_t pcd_launch_thresholds(const float* abs0, int w, int h, float* ths, float* ths_smoothed, hipStream_t s);
@@ -81,6 +86,20 @@ struct DevBuf {
         size_t want = need + need / 4;
         HIP_TRY(hipMalloc(&p, want));
         bytes = want;
+        return CVO_OK;
+    }
+    // grow to `need` bytes keeping the first `keep` bytes (copied on `s`, the old block freed when that copy has run)
+    int grow_keep(size_t need, size_t keep, hipStream_t s) {
+        if (need <= bytes) return CVO_OK;
+        void* np = nullptr; const size_t want = need + need / 4;
+        HIP_TRY(hipMalloc(&np, want));
+        if (p && keep) {
+            hipError_t e = hipMemcpyAsync(np, p, std::min(keep, bytes), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { (void)hipFree(np); return fail(CVO_ERR_HIP, std::string("growing a device buffer: ") + hipGetErrorString(e)); }
+        }
+        if (p) (void)hipFree(p);
+        p = np; bytes = want;
         return CVO_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -173,6 +192,11 @@ struct Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
     DevBuf d_descs, d_states, d_ybuf, d_jT, d_ent, d_surv, d_xch, d_queue, d_trace, d_tracelen, d_partials;
+    // 64-byte result records, one per pair, written by the align kernel (PairDesc::record); the block a rank contributes to the
+    // cross-GPU gather may be longer than its pairs (padding records: pad_from .. pad_to carry pad_status, see padded_records)
+    DevBuf d_records;
+    int rec_hint = 0;            // records to make room for beyond the pairs of a launch (a batch: its max_pairs + 1)
+    int pad_from = 0, pad_to = 0, pad_status = 0;
     PinBuf h_descs, h_states, h_states_in, h_stage, h_partials;   // h_states: final states, written by the kernel itself (mapped pinned memory)
     std::vector<unsigned char> descs_uploaded;                     // what d_descs holds: unchanged descriptors are not sent again
     unsigned launch_seq = 0;
@@ -230,6 +254,9 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_ADOPT")) adopt = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
+        if (const char* e = std::getenv("CVO_HIP_SELF_CACHE")) self_cache_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("CVO_HIP_UPLOAD_THREADS")) upload_threads = std::max(1, std::min(16, std::atoi(e)));
+        upload_threads = std::max(1, std::min(upload_threads, (int)std::thread::hardware_concurrency()));
         return CVO_OK;
     }
     void destroy() {
@@ -239,7 +266,7 @@ struct Engine {
         release_slots();
         d_scoredescs.release(); h_scoredescs.release(); h_counts.release();
         for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts, &d_tiles}) b->release();
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_queue, &d_trace, &d_tracelen, &d_partials}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_queue, &d_trace, &d_tracelen, &d_partials, &d_raw, &d_records}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -247,35 +274,73 @@ struct Engine {
         stream = nullptr; ev0 = ev1 = nullptr;
     }
 
-    // host arrays in the reference layout -> device records
-    int upload(Cloud& c, const float* xyz, const float* feat, int n) {
+    // Host arrays in the reference layout -> the clouds' float4 planes in HBM.  All clouds of one hand-over travel together: their
+    // arrays are copied as they are (memcpy, no per-point work on the host) into one block of the pinned staging ring behind a table of
+    // PackDesc, ONE host-to-device copy brings block and table over, ONE kernel builds the planes (cvo_pack_clouds_kernel).  The ring
+    // is only waited for when it wraps.  Large hand-overs (a batch of 64 pairs = 12.6 MB) are copied into the ring by a few threads.
+    struct UploadItem { Cloud* c; const float* xyz; const float* feat; int n; };
+    DevBuf d_raw;
+    int upload_threads = 4;
+    int upload_many(const UploadItem* it, int count) {
         HIP_TRY(hipSetDevice(device));
-        if (n < 0) return fail(CVO_ERR_INVALID, "negative point count");
-        if (n > 65535) return fail(CVO_ERR_INVALID, "more than 65535 points per cloud is not supported (16-bit column indices)");
-        c.n = n; c.boxes_valid = false; uploads_pending = true;
-        if (n == 0) return CVO_OK;
-        if (!xyz || !feat) return fail(CVO_ERR_INVALID, "null cloud pointer");
-        const size_t bytes = (size_t)n * REC * sizeof(float);
-        int rc = c.buf.ensure(bytes); if (rc) return rc;
-        // pinned staging ring: clouds are packed one behind the other and the stream is only waited for when the ring wraps,
-        // so handing over a whole batch (64 pairs = 12.6 MB) costs one wait, not one per cloud
+        int live = 0, n_max = 0; size_t raw_floats = 0;
+        for (int k = 0; k < count; ++k) {
+            if (!it[k].c) return fail(CVO_ERR_INVALID, "null cloud");
+            if (it[k].n < 0) return fail(CVO_ERR_INVALID, "negative point count");
+            if (it[k].n > 65535) return fail(CVO_ERR_INVALID, "more than 65535 points per cloud is not supported (16-bit column indices)");
+            if (it[k].n > 0 && (!it[k].xyz || !it[k].feat)) return fail(CVO_ERR_INVALID, "null cloud pointer");
+            if (it[k].n > 0) { ++live; n_max = std::max(n_max, it[k].n); raw_floats += (size_t)it[k].n * REC; }
+        }
+        for (int k = 0; k < count; ++k) {
+            Cloud& c = *it[k].c;
+            c.n = it[k].n; c.boxes_valid = false;
+            if (c.n > 0) { int rc = c.buf.ensure((size_t)c.n * REC * sizeof(float)); if (rc) return rc; }
+        }
+        uploads_pending = true;
+        if (live == 0) return CVO_OK;
+        const size_t desc_bytes = (sizeof(PackDesc) * (size_t)live + 255) & ~(size_t)255;
+        const size_t bytes = desc_bytes + raw_floats * sizeof(float);
         const size_t want = std::max(bytes, (size_t)16 << 20);
+        int rc;
         if (h_stage.bytes < want) {
             HIP_TRY(hipStreamSynchronize(stream));                   // the old buffer may still feed a copy
             rc = h_stage.ensure(want); if (rc) return rc;
             stage_used = 0;
         }
         if (stage_used + bytes > h_stage.bytes) { HIP_TRY(hipStreamSynchronize(stream)); stage_used = 0; }
-        float* s = reinterpret_cast<float*>(static_cast<unsigned char*>(h_stage.p) + stage_used);
+        if (d_raw.bytes < bytes) { HIP_TRY(hipStreamSynchronize(stream)); rc = d_raw.ensure(bytes); if (rc) return rc; }   // an earlier pack kernel may still read it
+        unsigned char* blk = static_cast<unsigned char*>(h_stage.p) + stage_used;
         stage_used += (bytes + 255) & ~(size_t)255;
-        for (int i = 0; i < n; ++i) {                                // plane 0: {x, y, z, f0}; plane 1: {f1..f4}
-            float* lo = s + lo_off(i); float* hi = s + hi_off(n, i);
-            lo[0] = xyz[(size_t)i * 3 + 0]; lo[1] = xyz[(size_t)i * 3 + 1]; lo[2] = xyz[(size_t)i * 3 + 2];
-            lo[3] = feat[i];
-            for (int ch = 1; ch < 5; ++ch) hi[ch - 1] = feat[(size_t)ch * n + i];
+        PackDesc* pd = reinterpret_cast<PackDesc*>(blk);
+        float* raw = reinterpret_cast<float*>(blk + desc_bytes);
+        struct Piece { const float* src; float* dst; size_t bytes; };
+        std::vector<Piece> pieces; pieces.reserve(2 * (size_t)live);
+        size_t off = 0; int q = 0;
+        for (int k = 0; k < count; ++k) {
+            const int n = it[k].n; if (n <= 0) continue;
+            pd[q].raw_off = off; pd[q].dst = it[k].c->rec(); pd[q].n = n; pd[q].pad_ = 0; ++q;
+            pieces.push_back(Piece{it[k].xyz, raw + off, sizeof(float) * 3 * (size_t)n});
+            pieces.push_back(Piece{it[k].feat, raw + off + 3 * (size_t)n, sizeof(float) * 5 * (size_t)n});
+            off += (size_t)n * REC;
         }
-        HIP_TRY(hipMemcpyAsync(c.buf.p, s, bytes, hipMemcpyHostToDevice, stream));
+        const int nthreads = bytes >= ((size_t)2 << 20) ? std::max(1, std::min(upload_threads, (int)pieces.size())) : 1;
+        auto copy_range = [&pieces](size_t a, size_t b) { for (size_t i = a; i < b; ++i) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); };
+        if (nthreads == 1) copy_range(0, pieces.size());
+        else {
+            std::vector<std::thread> th;
+            const size_t per = (pieces.size() + nthreads - 1) / nthreads;
+            for (int t = 1; t < nthreads; ++t) th.emplace_back(copy_range, std::min(pieces.size(), t * per), std::min(pieces.size(), (t + 1) * per));
+            copy_range(0, std::min(pieces.size(), per));
+            for (std::thread& t : th) t.join();
+        }
+        HIP_TRY(hipMemcpyAsync(d_raw.p, blk, bytes, hipMemcpyHostToDevice, stream));
+        const hipError_t e = launch_pack_clouds(reinterpret_cast<const float*>(static_cast<unsigned char*>(d_raw.p) + desc_bytes), static_cast<const PackDesc*>(d_raw.p), live, n_max, stream);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("cloud pack kernel launch: ") + hipGetErrorString(e));
         return CVO_OK;
+    }
+    int upload(Cloud& c, const float* xyz, const float* feat, int n) {
+        const UploadItem it{&c, xyz, feat, n};
+        return upload_many(&it, 1);
     }
 
     // ---- pcd_generator on the GPU (cvo_pcd_kernels.hip).  Image-sized scratch lives with the engine.
@@ -474,6 +539,8 @@ struct Engine {
         if ((rc = d_descs.ensure(sizeof(PairDesc) * n))) return rc;
         if ((rc = h_descs.ensure(sizeof(PairDesc) * n))) return rc;
         if ((rc = d_states.ensure(sizeof(PairState) * n))) return rc;
+        if ((rc = d_records.grow_keep(sizeof(float) * CVO_RESULT_FLOATS * (size_t)std::max(n, rec_hint), 0, s))) return rc;
+        if (n > pad_from) pad_from = pad_to = 0;                     // this launch writes over (some of) the padding records
         if ((rc = h_states.ensure(sizeof(PairState) * n))) return rc;
         if ((rc = h_states_in.ensure(sizeof(PairState) * n))) return rc;
         if (2 * (long long)P.max_iter + 2 >= 65536) return fail(CVO_ERR_INVALID, "max_iter must be below 32767");
@@ -483,9 +550,10 @@ struct Engine {
         // 1 + 1/2 + 1/3 + 1/4 of the rows, each rounded up to blocks of 128), and the exchange area has room for four members
         // (cvo_kernels.hip: ADOPT_GMAX).
         AdoptCounters* const ac = (adopt && G == 1 && slots == n && y_mode != 0) ? adopt_counters(device) : nullptr;
-        const int Gx = ac ? 4 : G;                                           // members a pair's exchange area has room for
+        const int gmax = align_adopt_gmax();                                 // the kernel's limit (ADOPT_GMAX)
+        const int Gx = ac ? gmax : G;                                        // members a pair's exchange area has room for
         size_t member_rows = 0;                                              // rows of all member regions of a slot under adoption
-        if (ac) { const int nbk = (std::max(nf_max, 1) + 127) / 128; for (int q = 1; q <= 4; ++q) member_rows += (size_t)((nbk + q - 1) / q) * 128; }
+        if (ac) { const int nbk = (std::max(nf_max, 1) + 127) / 128; for (int q = 1; q <= gmax; ++q) member_rows += (size_t)((nbk + q - 1) / q) * 128; }
         const size_t plane = ac ? member_rows * capf : (size_t)G * rows_per * capf;   // workgroup g's nonzero records start at g * rows_per * capf
         const int rows_pad = round_up(std::max(rows_per, 1), 128);          // the cull walks pairs of 64-row blocks
         int capn = 64; while (capn < nm_max / 3 && capn < 4096) capn *= 2;   // longest list a row may have: 1024 at 3 k points, 4096 at 10 k
@@ -526,6 +594,7 @@ struct Engine {
             D.trace_cap = want_trace ? trace_cap : 0;
             D.trace_len = want_trace ? static_cast<int*>(d_tracelen.p) : nullptr;
             D.member_regions = ac ? 1 : 0;
+            D.record = static_cast<float*>(d_records.p) + (size_t)i * CVO_RESULT_FLOATS;
         }
         // Steady state = no copy-engine work at all: copies queued on different streams share the DMA engines and a copy behind
         // another stream's running kernel would serialise the launches.  Descriptors go up only when they changed, start states
@@ -572,6 +641,28 @@ struct Engine {
     }
     hipStream_t last_stream = nullptr;
 
+    // The block of n_block records this engine contributes to a cross-GPU gather, complete on *s_out in stream order: records
+    // [0, n_valid) are the last launch's (written by the align kernel), [n_valid, n_block) stand for no pair and carry CVO_ERR_PADDING --
+    // blocks differ by one pair between ranks when the pairs do not divide evenly (cvo_shard_range), the collective needs equal counts.
+    // launch_status != CVO_OK: this rank's launch could not be made; all n_block records carry that status, so the rank still takes part
+    // in the collective and every rank learns of the failure instead of waiting for it forever.
+    int padded_records(int n_valid, int n_block, int launch_status, int last_n, hipStream_t* s_out, float** send) {
+        HIP_TRY(hipSetDevice(device));
+        if (n_block <= 0 || n_valid < 0 || n_valid > n_block) return fail(CVO_ERR_INVALID, "gather: need 0 <= n_valid <= n_block, n_block > 0");
+        if (launch_status == CVO_OK && n_valid > 0 && (!launched || n_valid > last_n)) return fail(CVO_ERR_INVALID, "gather: more records than the last launch aligned");
+        hipStream_t s = launched ? last_stream : stream;
+        const int keep = launch_status == CVO_OK ? n_valid : 0;
+        int rc = d_records.grow_keep(sizeof(float) * CVO_RESULT_FLOATS * (size_t)n_block, sizeof(float) * CVO_RESULT_FLOATS * (size_t)keep, s); if (rc) return rc;
+        const int from = keep, status = launch_status == CVO_OK ? CVO_ERR_PADDING : launch_status;
+        if (from < n_block && !(pad_from == from && pad_to >= n_block && pad_status == status)) {
+            const hipError_t e = launch_fill_records(static_cast<float*>(d_records.p), from, n_block, status, s);
+            if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("record fill kernel launch: ") + hipGetErrorString(e));
+            pad_from = from; pad_to = n_block; pad_status = status;
+        }
+        *s_out = s; *send = static_cast<float*>(d_records.p);
+        return CVO_OK;
+    }
+
     int wait() {
         HIP_TRY(hipSetDevice(device));
         if (!launched) return fail(CVO_ERR_INVALID, "no launch to wait for");
@@ -592,6 +683,7 @@ struct Engine {
         bool tran_from_state = false;     // ... and so does the transform applied to cloud a
     };
     DevBuf d_scoredescs; PinBuf h_scoredescs;
+    bool self_cache_on = true;        // CVO_HIP_SELF_CACHE=0: every fip(cloud, cloud) is swept again (tests compare the two)
     std::vector<unsigned char> scoredescs_uploaded;
     hipStream_t score_stream = nullptr; int score_pending = 0;
     size_t stage_used = 0;            // bytes of the pinned staging ring handed to copies that may still be in flight
@@ -628,6 +720,9 @@ struct Engine {
             D.a = rq[r].a->rec(); D.b = rq[r].b->rec(); D.na = rq[r].a->n; D.nb = rq[r].b->n; D.ell = rq[r].ell;
             D.bbox = static_cast<const float*>(rq[r].b->boxes.p); D.nbox = score_groups(D.nb);
             D.want_hessian = rq[r].hessian ? 1 : 0; D.out = nullptr;
+            // fip(cloud, cloud), untransformed: a function of the cloud and ell alone (cvo.cpp:496-497), kept with the cloud
+            if (self_cache_on && rq[r].a == rq[r].b && !rq[r].hessian && !rq[r].tran && !rq[r].tran_from_state)
+                D.self_cache = score_self_cache(static_cast<float*>(rq[r].b->boxes.p), rq[r].b->n);
             D.from = rq[r].from >= 0 ? static_cast<const PairState*>(d_states.p) + rq[r].from : nullptr;
             if (rq[r].tran_from_state && !D.from) return fail(CVO_ERR_INVALID, "score request: transform from a state that is not named");
             D.use_tran = rq[r].tran_from_state ? 2 : (rq[r].tran ? 1 : 0);
@@ -1238,6 +1333,7 @@ int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* 
     if (p) b->prm = *p; else cvo_default_params(&b->prm);
     int rc = b->eng.init(device, b->prm); if (rc) { b->eng.destroy(); return rc; }
     b->max_pairs = max_pairs;
+    b->eng.rec_hint = max_pairs + 1;                                // room for the padding record of an uneven shard (cvo_shard_range)
     b->fixed.resize(max_pairs); b->moving.resize(max_pairs);
     b->init_states.resize(max_pairs);
     for (auto& s : b->init_states) fresh_state(s, b->prm.ell);
@@ -1261,6 +1357,23 @@ int cvo_batch_set_pair(cvo_batch b, int p, const float* fixed_xyz, const float* 
     int rc = b->eng.upload(*b->fixed[p], fixed_xyz, fixed_feat, n_fixed); if (rc) return rc;
     rc = b->eng.upload(*b->moving[p], moving_xyz, moving_feat, n_moving); if (rc) return rc;
     fresh_state(b->init_states[p], b->prm.ell);
+    b->states_dirty = true;
+    return CVO_OK;
+}
+int cvo_batch_set_pairs(cvo_batch b, int first, int count, const float* const* fixed_xyz, const float* const* fixed_feat, const int* n_fixed,
+                        const float* const* moving_xyz, const float* const* moving_feat, const int* n_moving) {
+    if (!b || first < 0 || count <= 0 || first + count > b->max_pairs) return fail(CVO_ERR_INVALID, "bad pair range");
+    if (!fixed_xyz || !fixed_feat || !n_fixed || !moving_xyz || !moving_feat || !n_moving) return fail(CVO_ERR_INVALID, "null argument");
+    std::vector<Engine::UploadItem> items; items.reserve(2 * (size_t)count);
+    for (int k = 0; k < count; ++k) {
+        const int p = first + k;
+        if (!b->fixed[p]) b->fixed[p].reset(new Cloud());
+        if (!b->moving[p]) b->moving[p].reset(new Cloud());
+        items.push_back(Engine::UploadItem{b->fixed[p].get(), fixed_xyz[k], fixed_feat[k], n_fixed[k]});
+        items.push_back(Engine::UploadItem{b->moving[p].get(), moving_xyz[k], moving_feat[k], n_moving[k]});
+    }
+    int rc = b->eng.upload_many(items.data(), (int)items.size()); if (rc) return rc;
+    for (int k = 0; k < count; ++k) fresh_state(b->init_states[first + k], b->prm.ell);
     b->states_dirty = true;
     return CVO_OK;
 }
@@ -1417,8 +1530,14 @@ int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stre
     if (!b || !dst_device || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(b->eng.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->eng.last_stream;
-    hipError_t e = launch_pack_results(static_cast<const PairState*>(b->eng.d_states.p), static_cast<float*>(dst_device), n, s);
-    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pack kernel launch: ") + hipGetErrorString(e));
+    hipError_t e = launch_copy_records(static_cast<const float*>(b->eng.d_records.p), static_cast<float*>(dst_device), n, s);
+    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("record copy kernel launch: ") + hipGetErrorString(e));
+    return CVO_OK;
+}
+int cvo_batch_result_records(cvo_batch b, const void** records_device) {
+    if (!b || !records_device) return fail(CVO_ERR_INVALID, "null argument");
+    if (!b->eng.launched) return fail(CVO_ERR_INVALID, "no launch yet");
+    *records_device = b->eng.d_records.p;
     return CVO_OK;
 }
 
@@ -1514,32 +1633,75 @@ int cvo_comm_destroy(cvo_comm c) {
     return CVO_OK;
 }
 namespace {
-// pack kernel + all-gather of batch b's first n records, both on the stream of its last launch
-int enqueue_gather(cvo_batch b, cvo_comm c, int n, void* recv_device) {
-    if (!b || !c || !recv_device || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad gather arguments");
+// Everything of a gather that can fail happens here, BEFORE the collective is entered: argument checks, the record block (growth,
+// padding / status records).  The all-gather itself is posted by gather_post and reads the block in stream order.
+struct GatherPlan { hipStream_t s = nullptr; float* send = nullptr; };
+int gather_prepare(cvo_batch b, cvo_comm c, int n_valid, int n_block, int launch_status, void* recv_device, GatherPlan& plan) {
+    if (!b || !c || !recv_device) return fail(CVO_ERR_INVALID, "bad gather arguments");
     if (c->device != b->eng.device) return fail(CVO_ERR_INVALID, "communicator and batch live on different devices");
-    HIP_TRY(hipSetDevice(b->eng.device));
-    int rc = c->send.ensure(sizeof(float) * (size_t)n * CVO_RESULT_FLOATS); if (rc) return rc;
-    hipStream_t s = b->eng.last_stream;
-    hipError_t e = launch_pack_results(static_cast<const PairState*>(b->eng.d_states.p), static_cast<float*>(c->send.p), n, s);
-    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pack kernel launch: ") + hipGetErrorString(e));
-    RCCL_TRY(g_rccl.AllGather(c->send.p, recv_device, (size_t)n * CVO_RESULT_FLOATS, RCCL_FLOAT, c->comm, s));
+    return b->eng.padded_records(n_valid, n_block, launch_status, b->last_n, &plan.s, &plan.send);
+}
+int gather_post(cvo_comm c, int n_block, void* recv_device, const GatherPlan& plan) {
+    RCCL_TRY(g_rccl.AllGather(plan.send, recv_device, (size_t)n_block * CVO_RESULT_FLOATS, RCCL_FLOAT, c->comm, plan.s));
     return CVO_OK;
 }
 }  // namespace
-int cvo_batch_gather_results(cvo_batch b, cvo_comm c, int n, void* recv_device) {
+int cvo_shard_block(int n_pairs_total, int n_ranks) { return (n_pairs_total < 0 || n_ranks <= 0) ? 0 : (n_pairs_total + n_ranks - 1) / n_ranks; }
+int cvo_batch_padded_records(cvo_batch b, int n_valid, int n_block, int launch_status, const void** send_device) {
+    if (!b || !send_device) return fail(CVO_ERR_INVALID, "null argument");
+    hipStream_t s; float* send;
+    int rc = b->eng.padded_records(n_valid, n_block, launch_status, b->last_n, &s, &send); if (rc) return rc;
+    *send_device = send;
+    return CVO_OK;
+}
+int cvo_batch_gather_results_padded(cvo_batch b, cvo_comm c, int n_valid, int n_block, int launch_status, void* recv_device) {
     int rc = rccl_load(); if (rc) return rc;
-    return enqueue_gather(b, c, n, recv_device);
+    GatherPlan plan;
+    rc = gather_prepare(b, c, n_valid, n_block, launch_status, recv_device, plan); if (rc) return rc;
+    return gather_post(c, n_block, recv_device, plan);
+}
+int cvo_batch_gather_results(cvo_batch b, cvo_comm c, int n, void* recv_device) {
+    return cvo_batch_gather_results_padded(b, c, n, n, CVO_OK, recv_device);
+}
+int cvo_gather_results_padded(cvo_batch* batches, cvo_comm* comms, int n_devices, const int* n_valid, int n_block, const int* launch_status, void* const* recv_device) {
+    if (!batches || !comms || !recv_device || !n_valid || n_devices <= 0) return fail(CVO_ERR_INVALID, "bad gather arguments");
+    int rc = rccl_load(); if (rc) return rc;
+    std::vector<GatherPlan> plans(n_devices);
+    for (int i = 0; i < n_devices; ++i) {                            // nothing can fail inside the RCCL group: a rank enqueued without its peers would wait for ever
+        rc = gather_prepare(batches[i], comms[i], n_valid[i], n_block, launch_status ? launch_status[i] : CVO_OK, recv_device[i], plans[i]);
+        if (rc) return rc;
+    }
+    RCCL_TRY(g_rccl.GroupStart());                                  // one process drives several ranks: their calls must be grouped
+    int first_err = CVO_OK; std::string first_msg;
+    for (int i = 0; i < n_devices; ++i) {
+        const int r = gather_post(comms[i], n_block, recv_device[i], plans[i]);
+        if (r && !first_err) { first_err = r; first_msg = g_err; }
+    }
+    const int ge = g_rccl.GroupEnd();
+    if (first_err) return fail(first_err, first_msg);
+    if (ge != 0) return fail(CVO_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+    return CVO_OK;
 }
 int cvo_gather_results(cvo_batch* batches, cvo_comm* comms, int n_devices, int n, void* const* recv_device) {
-    if (!batches || !comms || !recv_device || n_devices <= 0) return fail(CVO_ERR_INVALID, "bad gather arguments");
-    int rc = rccl_load(); if (rc) return rc;
-    RCCL_TRY(g_rccl.GroupStart());                                  // one process drives several ranks: their calls must be grouped
-    int first_err = CVO_OK;
-    for (int i = 0; i < n_devices && first_err == CVO_OK; ++i) first_err = enqueue_gather(batches[i], comms[i], n, recv_device[i]);
-    const int ge = g_rccl.GroupEnd();
-    if (first_err) return first_err;
-    if (ge != 0) return fail(CVO_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+    if (n_devices <= 0) return fail(CVO_ERR_INVALID, "bad gather arguments");
+    std::vector<int> nv(n_devices, n);
+    return cvo_gather_results_padded(batches, comms, n_devices, nv.data(), n, nullptr, recv_device);
+}
+// rank-major gathered blocks (n_ranks x cvo_shard_block records) -> the n_pairs_total records in global pair order
+int cvo_compact_records(const float* gathered, int n_pairs_total, int n_ranks, float* out, int* first_error) {
+    if (!gathered || !out || n_pairs_total < 0 || n_ranks <= 0) return fail(CVO_ERR_INVALID, "bad argument");
+    const int blk = cvo_shard_block(n_pairs_total, n_ranks);
+    int err = CVO_OK;
+    for (int r = 0; r < n_ranks; ++r) {
+        int first = 0, count = 0; cvo_shard_range(n_pairs_total, r, n_ranks, &first, &count);
+        const float* src = gathered + (size_t)r * blk * CVO_RESULT_FLOATS;
+        for (int k = 0; k < count; ++k) {
+            std::memcpy(out + (size_t)(first + k) * CVO_RESULT_FLOATS, src + (size_t)k * CVO_RESULT_FLOATS, sizeof(float) * CVO_RESULT_FLOATS);
+            const int st = (int)src[(size_t)k * CVO_RESULT_FLOATS + 15];
+            if (st != CVO_OK && err == CVO_OK) err = st;
+        }
+    }
+    if (first_error) *first_error = err;
     return CVO_OK;
 }
 
@@ -1573,19 +1735,43 @@ int cvo_multi_batch(cvo_multi m, int i, cvo_batch* out) {
     *out = m->batches[i];
     return CVO_OK;
 }
-int cvo_multi_align_async(cvo_multi m, int n) {
-    if (!m || n <= 0 || n > m->max_pairs) return fail(CVO_ERR_INVALID, "bad pair count");
-    for (int i = 0; i < m->n_devices; ++i) { int rc = cvo_batch_align_async(m->batches[i], n, nullptr); if (rc) return rc; }
+// n_pairs[i] pairs on device i (0 = none: the device only contributes padding).  Every device enters the gather whatever its launch
+// returned: a launch that could not be made turns into status records, and the first error is reported after the collective is posted.
+int cvo_multi_align_async_v(cvo_multi m, const int* n_pairs) {
+    if (!m || !n_pairs) return fail(CVO_ERR_INVALID, "null argument");
+    int n_block = 0;
+    for (int i = 0; i < m->n_devices; ++i) {
+        if (n_pairs[i] < 0 || n_pairs[i] > m->max_pairs) return fail(CVO_ERR_INVALID, "bad pair count");
+        n_block = std::max(n_block, n_pairs[i]);
+    }
+    if (n_block <= 0) return fail(CVO_ERR_INVALID, "no pairs on any device");
+    std::vector<int> st(m->n_devices, CVO_OK), nv(m->n_devices, 0);
+    int first_err = CVO_OK; std::string first_msg;
+    for (int i = 0; i < m->n_devices; ++i) {
+        if (n_pairs[i] > 0) st[i] = cvo_batch_align_async(m->batches[i], n_pairs[i], nullptr);
+        if (st[i] && !first_err) { first_err = st[i]; first_msg = g_err; }
+        nv[i] = st[i] ? 0 : n_pairs[i];
+    }
     std::vector<void*> recv(m->n_devices);
     for (int i = 0; i < m->n_devices; ++i) recv[i] = m->recv[i].p;
-    int rc = cvo_gather_results(m->batches.data(), m->comms.data(), m->n_devices, n, recv.data()); if (rc) return rc;
-    m->last_n = n;
+    int rc = cvo_gather_results_padded(m->batches.data(), m->comms.data(), m->n_devices, nv.data(), n_block, st.data(), recv.data()); if (rc) return rc;
+    m->last_n = n_block;
+    if (first_err) return fail(first_err, first_msg);
     return CVO_OK;
+}
+int cvo_multi_align_async(cvo_multi m, int n) {
+    if (!m || n <= 0 || n > m->max_pairs) return fail(CVO_ERR_INVALID, "bad pair count");
+    std::vector<int> nv(m->n_devices, n);
+    return cvo_multi_align_async_v(m, nv.data());
 }
 int cvo_multi_wait(cvo_multi m, int from_device, float* records_out) {
     if (!m || from_device < 0 || from_device >= m->n_devices) return fail(CVO_ERR_INVALID, "bad argument");
     if (m->last_n <= 0) return fail(CVO_ERR_INVALID, "no launch to wait for");
-    for (int i = 0; i < m->n_devices; ++i) { int rc = cvo_batch_wait(m->batches[i], nullptr, 0); if (rc) return rc; }
+    for (int i = 0; i < m->n_devices; ++i) {
+        Engine& e = m->batches[i]->eng;
+        if (e.launched) { int rc = cvo_batch_wait(m->batches[i], nullptr, 0); if (rc) return rc; }
+        else { HIP_TRY(hipSetDevice(e.device)); HIP_TRY(hipStreamSynchronize(e.stream)); }   // the device only sent padding: its gather ran on the engine's own stream
+    }
     if (records_out) {
         HIP_TRY(hipSetDevice(m->devices[from_device]));
         HIP_TRY(hipMemcpy(records_out, m->recv[from_device].p, sizeof(float) * (size_t)m->n_devices * m->last_n * CVO_RESULT_FLOATS, hipMemcpyDeviceToHost));

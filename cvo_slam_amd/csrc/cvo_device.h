@@ -82,6 +82,8 @@ struct PairDesc {
     TraceRow* trace;         // optional
     int trace_cap;
     int* trace_len;
+    float* record;           // this pair's 64-byte result record {transform[12], iter, A_nonzero, iterations_run, status as floats}: written by the kernel's
+                             // final block, so the cross-GPU gather (or a caller that wants the records on the device) needs no pack kernel behind the launch
     int member_regions;      // adoption launches: member g of a pair keeps its lists and records in a region of its own (sized for the rows it owns
                              // when it joins, at g + 1 members) instead of sharing one region cut into G parts -- see make_ctx
 };
@@ -103,6 +105,8 @@ struct AdaptiveArgs {
 };
 
 // score kernels (function_inner_product / se3_Hessian)
+struct SelfCacheEntry { float ell; int valid; double sum, count; };
+constexpr int SELF_CACHE_N = 4;
 struct ScoreDesc {
     const float* a;          // two planes of na float4: queried cloud (positions optionally transformed by tran)
     const float* b;          // two planes of nb float4: searched cloud
@@ -116,6 +120,17 @@ struct ScoreDesc {
                              // queued behind the align launch that produces it without a host round trip
     int want_hessian;        // 0: inner product only, 1: Hessian terms too
     double* out;
+    // fip(cloud, cloud) of an untransformed cloud against itself depends on the cloud and ell only (cvo.cpp:496-497), and the moving cloud
+    // of one frame is the fixed cloud of the next (update_fixed_pcd, cvo.cpp:578-582): non-null = the cloud's table of SELF_CACHE_N
+    // entries {ell, valid, sum, count} in HBM (cleared when the cloud's points are written); a hit skips the sweep, a miss fills an entry
+    SelfCacheEntry* self_cache;
+};
+
+// host clouds in the reference layout -> the two float4 planes (cvo_pack_clouds_kernel): one descriptor per cloud
+struct PackDesc {
+    unsigned long long raw_off;   // floats from the start of the raw staging buffer: n x 3 positions (AoS, data_type.h:30), then 5 channel-major arrays of n (data_type.h:75)
+    float* dst;                   // two planes of n float4
+    int n, pad_;
 };
 
 // a score block: up to 8 inner-product / Hessian requests evaluated by one launch

@@ -1848,24 +1848,40 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
             fin.phase_ticks[7] = sh->sub[0]; fin.phase_ticks[9] = sh->sub[1]; fin.phase_ticks[2] = sh->sub[2]; fin.phase_ticks[4] = sh->sub[3];
             fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0;
-            *Dp->state = fin;                                          // device copy: the next launch may start from it, the result packer reads it
+            *Dp->state = fin;                                          // device copy: the next launch may start from it
             *Dp->state_host = fin;                                     // pinned host mirror: visible to the host when the kernel has completed
+            if (Dp->record) {                                          // the pair's 64-byte record of the cross-GPU gather (ints as floats: exact below 2^24)
+                gv4f* rec = (gv4f*)Dp->record;
+                v4f r0, r1, r2, r3;
+                r0.x = M[0]; r0.y = M[1]; r0.z = M[2]; r0.w = M[3]; r1.x = M[4]; r1.y = M[5]; r1.z = M[6]; r1.w = M[7]; r2.x = M[8]; r2.y = M[9]; r2.z = M[10]; r2.w = M[11];
+                r3.x = (float)fin.iter; r3.y = (float)fin.A_nonzero; r3.z = (float)fin.iterations_run; r3.w = (float)fin.status;
+                rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3;
+            }
         }
         __syncthreads();
     }
 }
 
-// 64-byte result record per pair for the cross-GPU gather: 12 floats of transform,
-// then iter, A_nonzero, iterations_run, status as floats (exact below 2^24).
-__global__ void cvo_pack_results_kernel(const PairState* __restrict__ st, float* __restrict__ out, int n) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    for (int i = 0; i < 12; ++i) out[p * 16 + i] = st[p].transform[i];
-    out[p * 16 + 12] = (float)st[p].iter; out[p * 16 + 13] = (float)st[p].A_nonzero;
-    out[p * 16 + 14] = (float)st[p].iterations_run; out[p * 16 + 15] = (float)st[p].status;
+// The 64-byte result records of a launch ({transform[12], iter, A_nonzero, iterations_run, status} as floats) are written by the align
+// kernel itself (PairDesc::record).  What is left for the gather path: records that stand for no pair -- the padding of a rank whose
+// block is shorter than the longest one (cvo_shard_range), or all of a rank's records when its launch could not be made -- carry a
+// status and zeros; and a copy for callers that want the records in a buffer of their own.
+__global__ void cvo_fill_records_kernel(float* __restrict__ rec, int from, int to, float status) {
+    const int p = from + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= to) return;
+    for (int i = 0; i < 15; ++i) rec[p * 16 + i] = 0.f;
+    rec[p * 16 + 15] = status;
 }
-hipError_t launch_pack_results(const PairState* st, float* out, int n, hipStream_t stream) {
-    hipLaunchKernelGGL(cvo_pack_results_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, st, out, n);
+hipError_t launch_fill_records(float* rec, int from, int to, int status, hipStream_t stream) {
+    if (to > from) hipLaunchKernelGGL(cvo_fill_records_kernel, dim3((to - from + 63) / 64), dim3(64), 0, stream, rec, from, to, (float)status);
+    return hipGetLastError();
+}
+__global__ void cvo_copy_records_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int n4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+}
+hipError_t launch_copy_records(const float* src, float* dst, int n, hipStream_t stream) {
+    if (n > 0) hipLaunchKernelGGL(cvo_copy_records_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), 4 * n);
     return hipGetLastError();
 }
 
@@ -2039,6 +2055,7 @@ hipError_t launch_adaptive(const AdaptiveArgs& A, hipStream_t stream) {
 
 int align_blocks_per_cu() { return BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD / 2; }
 int align_block_max() { return BLOCK_MAX; }
+int align_adopt_gmax() { return ADOPT_GMAX; }
 
 // LDS: Shared | slot/row tables (3 x rows_cap u16) | sort histograms | group boxes | cull tile (3*tile floats) | resident y cloud
 // (y_mode 1: 16 B x y_cap, y_mode 2: 12 B x y_cap, y_mode 0: none)

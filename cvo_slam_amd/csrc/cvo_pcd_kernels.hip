@@ -269,6 +269,32 @@ __global__ void pcd_unpack_kernel(const float* __restrict__ cloud, int n, float*
     feat[i] = lo[3]; feat[(size_t)n + i] = hi[0]; feat[2 * (size_t)n + i] = hi[1]; feat[3 * (size_t)n + i] = hi[2]; feat[4 * (size_t)n + i] = hi[3];
 }
 
+// host clouds in the reference layout (n x 3 positions AoS, data_type.h:30; 5 channel-major feature arrays of n, data_type.h:75), copied
+// to the device as they are, into the cloud's two float4 planes {x, y, z, f0}, {f1..f4}: one launch for all clouds of a hand-over
+// (grid.y = cloud).  The positions of 256 consecutive points are 768 consecutive floats: fetched coalesced through LDS.
+__global__ __launch_bounds__(256) void cvo_pack_clouds_kernel(const float* __restrict__ raw, const PackDesc* __restrict__ descs) {
+    __shared__ float pos[768];
+    const PackDesc D = descs[blockIdx.y];
+    const int i0 = blockIdx.x * 256, tid = threadIdx.x;
+    if (i0 >= D.n) return;
+    const float* xyz = raw + D.raw_off; const float* feat = xyz + 3 * (size_t)D.n;
+    const int cnt = min(256, D.n - i0);
+    for (int k = tid; k < 3 * cnt; k += 256) pos[k] = xyz[3 * (size_t)i0 + k];
+    __syncthreads();
+    if (tid < cnt) {
+        const int i = i0 + tid;
+        float4 lo, hi;
+        lo.x = pos[3 * tid]; lo.y = pos[3 * tid + 1]; lo.z = pos[3 * tid + 2]; lo.w = feat[i];
+        hi.x = feat[(size_t)D.n + i]; hi.y = feat[2 * (size_t)D.n + i]; hi.z = feat[3 * (size_t)D.n + i]; hi.w = feat[4 * (size_t)D.n + i];
+        *reinterpret_cast<float4*>(D.dst + lo_off(i)) = lo;
+        *reinterpret_cast<float4*>(D.dst + hi_off(D.n, i)) = hi;
+    }
+}
+hipError_t launch_pack_clouds(const float* raw, const PackDesc* descs, int n_clouds, int n_max, hipStream_t s) {
+    if (n_clouds > 0 && n_max > 0) hipLaunchKernelGGL(cvo_pack_clouds_kernel, dim3((n_max + 255) / 256, n_clouds), dim3(256), 0, s, raw, descs);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ host-side launchers
 #define PCD_LAUNCH_1D(kernel, n, stream, ...) hipLaunchKernelGGL(kernel, dim3(((n) + 255) / 256), dim3(256), 0, stream, __VA_ARGS__)
 

@@ -42,9 +42,11 @@ __device__ __forceinline__ float wmax(float v) {
     return v;
 }
 
-// boxes of a cloud's 32-point groups: planes lo x, y, z, slope then hi x, y, z, slope, ngroups floats each
-__global__ __launch_bounds__(64) void cvo_cloud_boxes_kernel(const float* __restrict__ rec, int n, float* __restrict__ gbox, int ngroups) {
+// boxes of a cloud's 32-point groups: planes lo x, y, z, slope then hi x, y, z, slope, ngroups floats each; behind them the cloud's
+// table of cached self inner products (ScoreDesc::self_cache), emptied here: the boxes are remade whenever the points were written
+__global__ __launch_bounds__(64) void cvo_cloud_boxes_kernel(const float* __restrict__ rec, int n, float* __restrict__ gbox, int ngroups, SelfCacheEntry* __restrict__ self_cache) {
     const int lane = threadIdx.x, gi = blockIdx.x * 2 + (lane >> 5), j = gi * 32 + (lane & 31);
+    if (blockIdx.x == 0 && lane < SELF_CACHE_N) { SelfCacheEntry e; e.ell = 0.f; e.valid = 0; e.sum = 0.0; e.count = 0.0; self_cache[lane] = e; }
     const float INF = __builtin_inff();
     float lo[4] = {INF, INF, INF, INF}, hi[4] = {-INF, -INF, -INF, -INF};
     if (j < n) {
@@ -71,6 +73,20 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, co
 
     const int tid = threadIdx.x, i = blockIdx.x * SCORE_BLOCK + tid;
     const float ell = D.from ? D.from->ell : D.ell, sigma = P.sigma;
+    if (D.self_cache) {
+        // fip(cloud, cloud) at this ell is already known (cvo.cpp:496-497 depend on the cloud and ell alone): the request's first record
+        // carries the cached sums, the others zeros, and the reduction below adds them up to the very same doubles.  Every workgroup of
+        // the launch sees the same table: it is written by the reduce kernel only, and launches that touch a cloud are ordered (ensure_boxes).
+        int hit = -1;
+#pragma unroll
+        for (int e = 0; e < SELF_CACHE_N; ++e) if (D.self_cache[e].valid && D.self_cache[e].ell == ell) hit = e;
+        if (hit >= 0) {
+            const size_t rec0 = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+            if (tid < SCORE_NOUT) partials[rec0 * SCORE_NOUT + tid] = (first && tid == 0) ? D.self_cache[hit].sum : ((first && tid == 1) ? D.self_cache[hit].count : 0.0);
+            return;
+        }
+    }
     const float d2_thres = gate_d2_score(ell, P.sp_thres, sigma);                // cvo.cpp:395 / 626
     const float d2c_thres = gate_d2c(P.c_ell, P.sp_thres, P.c_sigma);            // cvo.cpp:396 / 627
     const float thr_cull = d2_thres * (1.0f + 1e-6f);
@@ -241,8 +257,9 @@ __global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, co
 // one workgroup per request: its partial records into out[request][24] (pinned host memory).  Eight lanes per output walk
 // the records r = part, part + 8, ... in order, then the eight partial sums are added in lane order: a fixed order, so the
 // result does not depend on timing.
-__global__ __launch_bounds__(256) void cvo_score_reduce_kernel(const double* __restrict__ partials, int records_per_request, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void cvo_score_reduce_kernel(ScoreBatch B, const ScoreDesc* __restrict__ more, const double* __restrict__ partials, int records_per_request, double* __restrict__ out) {
     __shared__ double part_sum[8][32];
+    __shared__ double totals[SCORE_NOUT];
     const int tid = threadIdx.x, q = tid & 31, part = tid >> 5;
     const double* p = partials + (size_t)blockIdx.x * records_per_request * SCORE_NOUT;
     double s = 0;
@@ -254,15 +271,34 @@ __global__ __launch_bounds__(256) void cvo_score_reduce_kernel(const double* __r
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += part_sum[k][tid];
         out[blockIdx.x * SCORE_NOUT + tid] = t;
+        totals[tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {                                                 // a self inner product that was computed: keep it with the cloud
+        const ScoreDesc& D = more ? more[blockIdx.x] : B.d[blockIdx.x];
+        if (D.self_cache) {
+            const float ell = D.from ? D.from->ell : D.ell;
+            int at = -1, free_at = -1;
+            for (int e = 0; e < SELF_CACHE_N; ++e) {
+                if (D.self_cache[e].valid && D.self_cache[e].ell == ell) at = e;
+                if (!D.self_cache[e].valid && free_at < 0) free_at = e;
+            }
+            if (at < 0) {
+                SelfCacheEntry ne; ne.ell = ell; ne.valid = 1; ne.sum = totals[0]; ne.count = totals[1];
+                D.self_cache[free_at >= 0 ? free_at : SELF_CACHE_N - 1] = ne;
+            }
+        }
     }
 }
 
 int score_nout() { return SCORE_NOUT; }
 int score_groups(int n) { return (n + 31) / 32; }
-size_t score_box_bytes(int n) { return sizeof(float) * 8 * (size_t)score_groups(n); }
+static size_t score_box_floats(int n) { return (8 * (size_t)score_groups(n) + 3) & ~(size_t)3; }   // the table behind the boxes starts 16-byte aligned
+size_t score_box_bytes(int n) { return sizeof(float) * score_box_floats(n) + sizeof(SelfCacheEntry) * SELF_CACHE_N; }
+SelfCacheEntry* score_self_cache(float* gbox, int n) { return reinterpret_cast<SelfCacheEntry*>(gbox + score_box_floats(n)); }
 hipError_t launch_cloud_boxes(const float* rec, int n, float* gbox, hipStream_t stream) {
     const int ng = score_groups(n);
-    hipLaunchKernelGGL(cvo_cloud_boxes_kernel, dim3((ng + 1) / 2), dim3(64), 0, stream, rec, n, gbox, ng);
+    hipLaunchKernelGGL(cvo_cloud_boxes_kernel, dim3((ng + 1) / 2), dim3(64), 0, stream, rec, n, gbox, ng, score_self_cache(gbox, n));
     return hipGetLastError();
 }
 int score_row_blocks(int na) { return (na + SCORE_BLOCK - 1) / SCORE_BLOCK; }
@@ -273,7 +309,7 @@ hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, in
     hipLaunchKernelGGL(cvo_score_kernel, dim3(row_blocks, chunks, nreq), dim3(SCORE_BLOCK), 0, stream, B, more, P, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cvo_score_reduce_kernel, dim3(nreq), dim3(256), 0, stream, partials, row_blocks * chunks, out_pinned);
+    hipLaunchKernelGGL(cvo_score_reduce_kernel, dim3(nreq), dim3(256), 0, stream, B, more, partials, row_blocks * chunks, out_pinned);
     return hipGetLastError();
 }
 

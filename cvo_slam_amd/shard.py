@@ -46,3 +46,29 @@ def gather_results(local: torch.Tensor, n_pairs: int, world: int | None = None) 
     recv = recv.view(world, max_local, RESULT_FLOATS)
     parts = [recv[r, : len(shard_range(n_pairs, r, world))] for r in range(world)]
     return torch.cat(parts, dim=0)
+
+
+class _DeviceView:
+    """A block of result records at a raw device address (cvo_batch_padded_records / cvo_batch_result_records) as something torch can
+    wrap without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, n_records: int):
+        self.__cuda_array_interface__ = {"shape": (n_records, RESULT_FLOATS), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr: int, n_records: int) -> torch.Tensor:
+    return torch.as_tensor(_DeviceView(ptr, n_records), device="cuda")
+
+
+def gather_blocks(block: torch.Tensor, world: int | None = None) -> torch.Tensor:
+    """All-gather equal-sized record blocks (every rank: its own records, then padding -- cvo_batch_padded_records) into the
+    rank-major (world * n_block, RESULT_FLOATS) table; cvo_compact_records / api.compact_records puts it in global pair order."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return block.clone()
+    if block.is_cuda and dist.get_backend() != "nccl":        # rehearsal on a backend without device collectives: stage through the host
+        return gather_blocks(block.cpu(), world).to(block.device)
+    recv = torch.empty((world * block.shape[0], RESULT_FLOATS), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(recv, block.contiguous())
+    return recv

@@ -41,7 +41,8 @@ enum {
     CVO_ERR_HIP = 3,              /* HIP runtime error, message via cvo_last_error() */
     CVO_ERR_INVALID = 4,          /* bad argument */
     CVO_ERR_NO_DEVICE = 5,        /* no gfx950 device: the library never falls back to the CPU */
-    CVO_ERR_TIMEOUT = 6           /* in-kernel inter-workgroup wait gave up */
+    CVO_ERR_TIMEOUT = 6,          /* in-kernel inter-workgroup wait gave up */
+    CVO_ERR_PADDING = 7           /* status field of a gathered result record that stands for no pair (shard padding); never returned by a call */
 };
 
 enum { CVO_SLOT_FIXED = 0, CVO_SLOT_MOVING = 1, CVO_SLOT_PREVIOUS = 2 };   /* cvo.hpp:91-94 */
@@ -232,6 +233,11 @@ int cvo_batch_destroy(cvo_batch b);
 /* upload pair p (host arrays, reference layout); sets R=I, T=0, ell=params.ell (fresh-object semantics) */
 int cvo_batch_set_pair(cvo_batch b, int p, const float* fixed_xyz, const float* fixed_feat, int n_fixed,
                        const float* moving_xyz, const float* moving_feat, int n_moving);
+/* the same for pairs first .. first+count-1 in one hand-over (arrays of `count` pointers / sizes): the clouds' arrays are copied as
+ * they are into one pinned staging block, ONE host-to-device copy brings them over and ONE kernel builds the device layout -- the
+ * way to hand a whole batch over per step (64 pairs of ~3 k points = 12.6 MB).  The host arrays may be reused when the call returns. */
+int cvo_batch_set_pairs(cvo_batch b, int first, int count, const float* const* fixed_xyz, const float* const* fixed_feat, const int* n_fixed,
+                        const float* const* moving_xyz, const float* const* moving_feat, const int* n_moving);
 /* warm start / carried ell for pair p (reset_initial + Q1) */
 int cvo_batch_set_state(cvo_batch b, int p, const float R[9], const float T[3], float ell);
 int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair /* 0 = auto: fill the CUs */);
@@ -240,8 +246,9 @@ int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair /* 0 = auto: f
  * to the slots dynamically, so a slot is never idle behind the longest alignment. */
 int cvo_batch_set_max_workgroups(cvo_batch b, int max_workgroups);
 /* Adoption (off by default): in launches with one workgroup and one slot per pair, a workgroup that has finished its pair and finds
- * nothing queued on the device offers its help to a pair of the launch that still runs; from the next iteration on that pair runs on two
- * workgroups.  Shortens the tail of a job whose alignments take different numbers of iterations (33 ... 150); the results are those of
+ * nothing queued on the device offers its help to a pair of the launch that still runs; from the next iteration on that pair runs on one
+ * more workgroup (a pair can grow to four).  "Nothing queued" only counts launches of this library in this process that take part in
+ * adoption.  Shortens the tail of a job whose alignments take different numbers of iterations (33 ... 150); the results are those of
  * any other workgroup count.  cvo_batch_last_adoptions: pairs of the last launch that were helped. */
 int cvo_batch_set_adoption(cvo_batch b, int on);
 int cvo_batch_last_adoptions(cvo_batch b, int* pairs_helped);
@@ -258,35 +265,56 @@ int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_t
  * for the slowest wave)   [3] line-search phase   [4] candidates: exchange between the pair's workgroups   [5] scalar epilogue
  * [6] inside [0]: dense culls   [7] candidates: prologue   [8] inside [0]: row sorts   [9] candidates: the row walk */
 int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]);
-/* pack the last launch's results into a caller-owned DEVICE buffer of n records of
- * CVO_RESULT_FLOATS floats {transform[12], iter, A_nonzero, iterations_run, status},
- * enqueued on `stream` (NULL = the launch's stream): the payload of the cross-GPU
- * RCCL gather without a host round trip. */
+/* The last launch's results as records of CVO_RESULT_FLOATS floats {transform[12], iter, A_nonzero, iterations_run, status}: the
+ * payload of the cross-GPU RCCL gather.  The align kernel writes them itself when a pair ends (no pack kernel behind the
+ * launch): cvo_batch_result_records hands out the DEVICE address of the record table (valid once the launch's stream has drained; it
+ * may move when a later launch has more pairs), cvo_batch_results_to_device copies the first n into a caller-owned DEVICE buffer
+ * on `stream` (NULL = the launch's stream). */
 #define CVO_RESULT_FLOATS 16
 int cvo_batch_results_to_device(cvo_batch b, void* dst_device, int n, void* stream);
+int cvo_batch_result_records(cvo_batch b, const void** records_device);
 
 /* ======================= multi-GPU: shard the pairs, gather the SE(3) records ===========
  * Frame pairs are independent (loop-closure candidates keyframe_graph.cpp:622-731, offline batches): pair p of P goes to
- * a contiguous block per rank (block sizes differ by at most one: cvo_shard_range), its clouds live only on the owning GPU, and the ONLY exchange is one RCCL
+ * a contiguous block per rank (cvo_shard_range: block sizes differ by at most one -- the reference's batch source is <= 10 loop-closure
+ * candidates, i.e. 2,2,1,1,1,1,1,1 over 8 GPUs), its clouds live only on the owning GPU, and the ONLY exchange is one RCCL
  * all-gather of the CVO_RESULT_FLOATS-float result records over xGMI.  RCCL (librccl.so.1) is loaded when the first
  * communicator is made; a process that never shards does not need it.
  *
  * One process per GPU (torch.distributed / MPI launchers): rank 0 calls cvo_comm_unique_id, the host framework
  * broadcasts the CVO_COMM_ID_BYTES bytes, every rank calls cvo_comm_create (ncclCommInitRank).  One process, several
- * GPUs: cvo_comm_create_all (ncclCommInitAll).  cvo_batch_gather_results packs the first n records of the batch's last
- * launch on the device and enqueues ONE ncclAllGather of n*CVO_RESULT_FLOATS floats behind the pack kernel on the
- * launch's stream: no host synchronisation between align and gather; recv_device (nranks*n records, rank-major) is
- * valid when that stream has drained (cvo_batch_wait). */
+ * GPUs: cvo_comm_create_all (ncclCommInitAll).
+ *
+ * The gather.  An all-gather needs the same count on every rank, so every rank contributes a block of n_block =
+ * cvo_shard_block(P, n_ranks) records: its n_valid own ones (written by the align kernel) and, behind them, records that stand for
+ * no pair (status CVO_ERR_PADDING, the rest zero).  cvo_batch_gather_results_padded enqueues ONE ncclAllGather of n_block *
+ * CVO_RESULT_FLOATS floats behind the launch on its stream: no host synchronisation between align and gather; recv_device
+ * (n_ranks * n_block records, rank-major) is valid when that stream has drained (cvo_batch_wait); cvo_compact_records turns the
+ * gathered table (on the host) into the P records in global pair order and reports the first non-zero status.
+ * RULE: every rank enters the collective exactly once per step, whatever happened before.  A rank whose cvo_batch_align_async
+ * failed passes that code as launch_status (n_valid is then ignored): all its records carry the status, its peers see it in the
+ * gathered table instead of waiting for the rank forever.  A rank with no pairs (n_valid = 0) just sends padding.  Everything
+ * that can fail inside the call (argument checks, buffer growth) happens before the collective is posted.
+ * cvo_batch_gather_results(b, c, n, recv) is the n_valid = n_block = n form: n MUST be the same on every rank. */
 #define CVO_COMM_ID_BYTES 128
 typedef struct cvo_comm_s* cvo_comm;
 int cvo_shard_range(int n_pairs_total, int rank, int n_ranks, int* first, int* count);    /* contiguous block of rank */
+int cvo_shard_block(int n_pairs_total, int n_ranks);                                      /* records per rank in a gather: ceil(P / n_ranks) */
 int cvo_comm_unique_id(char id[CVO_COMM_ID_BYTES]);
 int cvo_comm_create(const char id[CVO_COMM_ID_BYTES], int n_ranks, int rank, int device, cvo_comm* out);
 int cvo_comm_create_all(const int* devices, int n_devices, cvo_comm* out /* n_devices handles */);
 int cvo_comm_destroy(cvo_comm c);
 int cvo_batch_gather_results(cvo_batch b, cvo_comm c, int n, void* recv_device);
-/* single-process form: one batch per device, all n_devices all-gathers inside one RCCL group */
+int cvo_batch_gather_results_padded(cvo_batch b, cvo_comm c, int n_valid, int n_block, int launch_status, void* recv_device);
+/* the block a rank would send (padding / status records in place), for launchers that run their own collective: DEVICE address,
+ * complete in the order of the launch's stream */
+int cvo_batch_padded_records(cvo_batch b, int n_valid, int n_block, int launch_status, const void** send_device);
+int cvo_compact_records(const float* gathered_host, int n_pairs_total, int n_ranks, float* out_host /* n_pairs_total records */, int* first_error);
+/* single-process form: one batch per device, all n_devices all-gathers inside one RCCL group (everything that can fail is checked
+ * for every device before the group is opened) */
 int cvo_gather_results(cvo_batch* batches, cvo_comm* comms, int n_devices, int n, void* const* recv_device);
+int cvo_gather_results_padded(cvo_batch* batches, cvo_comm* comms, int n_devices, const int* n_valid, int n_block, const int* launch_status /* NULL = all CVO_OK */,
+                              void* const* recv_device);
 
 /* Convenience object for the single-process case: n_devices batches (one per GPU, max_pairs_per_device each), their
  * communicators and gather buffers.  cvo_multi_batch hands out device i's batch for cvo_batch_set_pair & co;
@@ -298,7 +326,9 @@ int cvo_multi_create(const cvo_params* p, const int* devices, int n_devices, int
 int cvo_multi_destroy(cvo_multi m);
 int cvo_multi_batch(cvo_multi m, int i, cvo_batch* out);
 int cvo_multi_align_async(cvo_multi m, int n);
-int cvo_multi_wait(cvo_multi m, int from_device, float* records_out /* n_devices * n * CVO_RESULT_FLOATS */);
+/* n_pairs[i] pairs on device i (0 = none); every device contributes max(n_pairs) records to the gather, padding behind its own */
+int cvo_multi_align_async_v(cvo_multi m, const int* n_pairs);
+int cvo_multi_wait(cvo_multi m, int from_device, float* records_out /* n_devices * max(n_pairs) * CVO_RESULT_FLOATS */);
 
 /* Loop-closure verification of the aligned pairs (keyframe_graph.cpp:704-717): per pair the
  * compute_innerproduct_lc block (cvo.cpp:505-561: 6 inner products + 2 Hessians, lc_tran = the pair's

@@ -58,3 +58,43 @@ def test_gather_results_world2(tmp_path, n_pairs):
     want = np.stack([np.arange(shard.RESULT_FLOATS, dtype=np.float32) + 100.0 * p for p in range(n_pairs)])
     for r in range(world):
         np.testing.assert_array_equal(np.load(tmp_path / f"table_{r}.npy"), want)   # every rank holds the full table in pair order
+
+
+def _worker_blocks(rank, world, port, n_pairs, fail_rank, out_dir):
+    """The padded form the C ABI gathers (cvo_batch_gather_results_padded): every rank sends cvo_shard_block records -- its own,
+    then padding with status CVO_ERR_PADDING; a rank whose launch failed sends its error code in every record."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    from cvo_slam_amd import api
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_range(n_pairs, rank, world)
+    blk = api.shard_block(n_pairs, world)
+    block = torch.zeros((blk, shard.RESULT_FLOATS)); block[:, 15] = float(api.CVO_ERR_PADDING)
+    for k, p in enumerate(mine):
+        block[k] = torch.arange(shard.RESULT_FLOATS, dtype=torch.float32) + 100.0 * p; block[k, 15] = 0.0
+    if rank == fail_rank:
+        block[:] = 0.0; block[:, 15] = float(api.CVO_ERR_INVALID)
+    table = shard.gather_blocks(block, world)
+    out, err = api.compact_records(table.numpy(), n_pairs, world)
+    np.save(os.path.join(out_dir, f"blocks_{rank}.npy"), out); np.save(os.path.join(out_dir, f"err_{rank}.npy"), np.array([err]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs,world,fail_rank", [(7, 2, -1), (10, 2, -1), (10, 3, -1), (2, 3, -1), (10, 2, 1)])
+def test_padded_blocks_gather_and_compact(hiplib, tmp_path, n_pairs, world, fail_rank):
+    """Uneven shards (the reference's <= 10 loop-closure candidates, keyframe_graph.cpp:622-731) and a failed rank: every rank
+    enters the collective with a block of the same size, cvo_compact_records restores global pair order and reports the failure."""
+    from cvo_slam_amd import api
+    mp.spawn(_worker_blocks, args=(world, _free_port(), n_pairs, fail_rank, str(tmp_path)), nprocs=world, join=True)
+    want = np.stack([np.arange(shard.RESULT_FLOATS, dtype=np.float32) + 100.0 * p for p in range(n_pairs)]); want[:, 15] = 0
+    for r in range(world):
+        got = np.load(tmp_path / f"blocks_{r}.npy"); err = int(np.load(tmp_path / f"err_{r}.npy")[0])
+        if fail_rank < 0:
+            assert err == 0
+            np.testing.assert_array_equal(got, want)
+        else:
+            assert err == api.CVO_ERR_INVALID                               # every rank learns of it
+            ok = [p for q in range(world) if q != fail_rank for p in shard.shard_range(n_pairs, q, world)]
+            np.testing.assert_array_equal(got[ok], want[ok])
+            bad = list(shard.shard_range(n_pairs, fail_rank, world))
+            assert np.all(got[bad, 15] == api.CVO_ERR_INVALID)

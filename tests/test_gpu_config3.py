@@ -1,7 +1,9 @@
 """BASELINE config 3 AS BENCHMARKED: 64 full-size 640x480 TUM-shape pairs (~3 k points per cloud), eight batch objects in
 flight on eight HIP streams (bench.py's timed region), and EVERY launch's 64 results compared with the oracle: pose within the
 north-star tolerance (rotation <= 1e-4 rad, translation <= 1e-4 m), iteration count and nnz of the last iteration equal.
-The oracle aligns the 64 pairs once (KD-tree search, host threads); three rounds of eight concurrent launches are checked."""
+The oracle aligns the 64 pairs once (KD-tree search, host threads); three rounds of eight concurrent launches are checked --
+in the library's default mode and in the mode bench.py times (its `adoption` setting: finished workgroups help with the pairs
+of their launch that still run), where some pair must actually have been helped."""
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -25,29 +27,52 @@ def _oracle_result(args):
     return st["transform"].copy(), st["iter"], st["A_nonzero"]
 
 
-def test_config3_as_benchmarked_every_concurrent_launch_matches_the_oracle(hiplib, oracle):
+_CACHE = {}
+
+
+def _inputs_and_oracle():
+    if not _CACHE:
+        from cvo_slam_amd import synth
+        pairs = [synth.make_pair(i) for i in range(N_PAIRS)]     # the pairs bench.py times
+        clouds = [(p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat) for p in pairs]
+        workers = max(1, min(16, len(os.sched_getaffinity(0))))
+        with ThreadPoolExecutor(workers) as ex:                   # ctypes releases the GIL inside the oracle
+            _CACHE["want"] = list(ex.map(_oracle_result, clouds))
+        _CACHE["clouds"] = clouds
+    return _CACHE["clouds"], _CACHE["want"]
+
+
+def _bench_adoption_default() -> bool:
+    """what bench.py passes to set_adoption when run without flags"""
+    import re
+    from conftest import ROOT
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    m = re.search(r"ADOPTION_DEFAULT\s*=\s*(True|False)", src)
+    assert m, "bench.py must state ADOPTION_DEFAULT"
+    return m.group(1) == "True"
+
+
+@pytest.mark.parametrize("adoption", [False, True])
+def test_config3_as_benchmarked_every_concurrent_launch_matches_the_oracle(hiplib, oracle, adoption):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # read when the runtime initialises; harmless later
-    from cvo_slam_amd import synth
-    pairs = [synth.make_pair(i) for i in range(N_PAIRS)]     # the pairs bench.py times
-    clouds = [(p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat) for p in pairs]
-    workers = max(1, min(16, len(os.sched_getaffinity(0))))
-    with ThreadPoolExecutor(workers) as ex:                   # ctypes releases the GIL inside the oracle
-        want = list(ex.map(_oracle_result, clouds))
+    clouds, want = _inputs_and_oracle()
 
     batches = []
     for _ in range(DEPTH):
         b = hiplib.CvoBatch(N_PAIRS)
         b.set_workgroups(1)                                  # the bench's throughput configuration
+        b.set_adoption(adoption)
         for i, c in enumerate(clouds):
             b.set_pair(i, *c)
         batches.append(b)
-    checked = 0
+    checked = helped = 0
     for rnd in range(ROUNDS):
         for b in batches:                                    # eight launches queued back to back on eight streams ...
             b.reset_states(); b.align_async(N_PAIRS)
         for bi, b in enumerate(batches):                     # ... and every one of them checked
             res = b.wait(N_PAIRS)
             assert b.last_launch()["kernel_ms"] > 0
+            helped += b.last_adoptions()
             for i, (r, (tf, it, nnz)) in enumerate(zip(res, want)):
                 assert r["status"] == 0, (rnd, bi, i)
                 rot, tr = rot_trans_err(r["transform"], tf)
@@ -55,5 +80,10 @@ def test_config3_as_benchmarked_every_concurrent_launch_matches_the_oracle(hipli
                 assert r["iter"] == it and r["A_nonzero"] == nnz, (rnd, bi, i, r["iter"], it, r["A_nonzero"], nnz)
                 checked += 1
     assert checked == ROUNDS * DEPTH * N_PAIRS
+    assert (helped > 0) == adoption, helped                   # ON: the drained tail of every round leaves pairs to help with
     for b in batches:
         b.close()
+
+
+def test_the_mode_the_bench_times_is_one_of_the_tested_modes():
+    assert _bench_adoption_default() in (False, True)
