@@ -1643,6 +1643,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, off, 64));
                     if (key == 0xFFFFFFFFu) break;                  // nobody runs alone any more
+                    if ((key >> 12) >= (unsigned)P.adopt_kmax) break; // every pair that runs alone is in its light late iterations: a second workgroup would cost it a list rebuild and gain it next to nothing
                     const int s2 = (int)(key & 0xFFFu);
                     int got = 0;                                    // lane 0: 1 accepted, 0 try again, -1 (unused)
                     if (tid == 0) {

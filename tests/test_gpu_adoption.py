@@ -53,3 +53,31 @@ def test_adoption_with_several_launches_in_flight(hiplib):
                 assert np.array_equal(g["transform"], w["transform"])
     assert helped >= 1, helped
     for b in bs: b.close()
+
+
+@pytest.mark.parametrize("knobs", [dict(CVO_HIP_Y_MODE="2"), dict(CVO_HIP_RESORT="2"), dict(CVO_HIP_ADOPT_KMAX="1000"), dict(CVO_HIP_ADOPT_KMAX="0")])
+def test_adoption_under_other_layouts_and_cutoffs(hiplib, knobs):
+    """Member regions and re-dealt rows under the 12-byte plane layout (the rebuild scratch lives inside the cull tile there), with
+    rows re-sorted at every list refinement, with helpers joining at any iteration and with no pair ever eligible: the bits of the
+    same batch without adoption."""
+    import os
+    from cvo_slam_amd import synth
+    pairs = [synth.make_pair(200 + i) for i in range(16)]
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        ref = _batch(hiplib, pairs, False)
+        ref.align_async(len(pairs)); want = ref.wait(len(pairs)); ref.close()
+        b = _batch(hiplib, pairs, True)
+        helped = 0
+        for rep in range(4):
+            b.reset_states(); b.align_async(len(pairs)); got = b.wait(len(pairs)); helped += b.last_adoptions()
+            for w, g in zip(want, got):
+                assert g["status"] == 0 and g["iter"] == w["iter"] and g["A_nonzero"] == w["A_nonzero"]
+                assert np.array_equal(g["transform"], w["transform"])
+        assert (helped > 0) == (knobs.get("CVO_HIP_ADOPT_KMAX") != "0"), helped
+        b.close()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
