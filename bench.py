@@ -485,7 +485,7 @@ def main():
     if rank == 0 and os.environ.get("CVO_BENCH_PHASES"):
         ph = batch.last_phase_seconds(); its_all = sum(r["iterations_run"] for r in results)
         print("[bench] phase us/iteration under load (workgroup 0 of every pair of the last launch): " +
-              str({k: round(1e6 * v / its_all, 1) for k, v in ph.items()}), file=sys.stderr, flush=True)
+              str({k: round(1e6 * v / its_all, 1) for k, v in ph.items()}) + f"; culls per pair {np.mean([r['rebuilds'] for r in results]):.2f}, iterations {its_all / len(results):.1f}", file=sys.stderr, flush=True)
     bad = [r["status"] for r in results if r["status"] != 0]
     if bad:
         raise SystemExit(f"align kernel reported errors: {bad}")
