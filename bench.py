@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--gen-workers", type=int, default=0, help="host processes rendering the synthetic pairs (0 = one per host thread, 1 = no fork)")
     ap.add_argument("--no-adoption", action="store_true", help="do not let finished workgroups help with the pairs of their launch that still run (cvo_batch_set_adoption)")
     ap.add_argument("--adoption", action="store_true", help="force adoption on (whatever ADOPTION_DEFAULT says)")
+    ap.add_argument("--reuse", choices=("any", "oldest"), default="any", help="which batch object in flight the next step reuses: whichever has completed first (cvo_batch_done), or strictly the oldest")
     ap.add_argument("--total-pairs", type=int, default=0, help="pairs per step over ALL ranks, dealt in contiguous blocks (cvo_shard_range: blocks may differ by one, the gather pads); 0 = --pairs per rank")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
     args = ap.parse_args()
@@ -357,8 +358,22 @@ def main():
                 torch.cuda.synchronize()
                 gathered = shard.gather_blocks(shard.device_view(send_ptr[bi], n_block), world)
 
+    def pick():
+        """The batch object the next step goes to: a free one, else whichever launch in flight has completed (cvo_batch_done, oldest first:
+        alignments take data-dependent numbers of iterations, so launches do not finish in the order they were queued), else the oldest."""
+        for k in range(depth):
+            if k not in inflight:
+                return k
+        if args.reuse == "any":
+            t_poll = time.perf_counter()
+            while time.perf_counter() - t_poll < 0.05:
+                for k in inflight:
+                    if launch_status[k] or n == 0 or batches[k].done():
+                        return k
+        return inflight[0]
+
     def step(i):
-        bi = i % depth
+        bi = pick()
         if bi in inflight:                         # the object is reused: its previous step must be complete first
             inflight.remove(bi); finish(bi)
         b = batches[bi]
@@ -421,12 +436,18 @@ def main():
         k2 = max(depth, min(args.steps, 32))
         scored = []
 
+        tail = not os.environ.get("CVO_BENCH_SCORE_LAUNCH")      # default: the align launch answers the block in its tail (cvo_batch_set_tail_scores); else a score launch queued behind it
+        for b in batches:
+            b.set_tail_scores(tail)
+
         def step_scored(i):
             bi = i % depth
             if bi in scored:
                 scored.remove(bi); batches[bi].wait(); batches[bi].innerproduct_results(n)
             b = batches[bi]
-            b.reset_states(); b.align_async(n); b.enqueue_innerproduct(n)
+            b.reset_states(); b.align_async(n)
+            if not tail:
+                b.enqueue_innerproduct(n)
             scored.append(bi)
 
         def drain_scored():
@@ -443,9 +464,15 @@ def main():
             step_scored(i)
         last_scores = drain_scored(); torch.cuda.synchronize()
         el2 = time.perf_counter() - t2
+        answered = batches[0].last_tail_answers(n) if tail else []
+        for b in batches:
+            b.set_tail_scores(False)
         with_scores = {"value": n * k2 / el2, "unit": "alignments/s", "steps": k2, "ms_per_step": 1e3 * el2 / k2,
-                       "score_block": "compute_innerproduct per pair (4 inner products + 1 Hessian, dense all-pairs sweeps at the ell align() left behind), "
-                                      "one launch per step queued behind the align launch",
+                       "score_block": "compute_innerproduct per pair (4 inner products + 1 Hessian at the ell align() left behind): " +
+                                      ("answered by the pair's workgroup in the tail of the align launch (inn_post + Hessian from the resident lists, inn_pre from one "
+                                       "cull, the self products from the clouds' tables); the score kernel only for what a workgroup could not answer" if tail else
+                                       "one score launch per step queued behind the align launch"),
+                       "pairs_fully_answered_in_the_tail": int(sum(1 for m in answered if m == 31)),
                        "mean_cos_angle": float(np.mean([r["cos_angle"] for r in last_scores]))}
         batch.reset_states(); batch.align_async(n); batch.wait()       # leave batch 0 as the timed region left it
 
@@ -550,7 +577,7 @@ def main():
                                    f"full align() from R=I,T=0,ell=0.15 to convergence",
                        "pairs_per_gpu": n, "points_fixed_mean": float(np.mean(nfs)), "points_moving_mean": float(np.mean(nms)),
                        "iterations_mean": float(np.mean(its)), "iterations_max": int(np.max(its)),
-                       "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth, "adoption": adoption,
+                       "workgroups_per_pair": args.workgroups or "auto", "steps_in_flight": depth, "adoption": adoption, "reuse": args.reuse,
                        "single_step_ms_unpipelined": single_step_ms, "single_kernel_ms_unpipelined": single_kernel_ms, "collective": ((("RCCL ncclAllGather enqueued by the C ABI behind each align launch" if gather_mode == "abi" else ("RCCL" if backend == "nccl" else backend) + " all_gather via torch.distributed after the wait") + ", 64-byte result records") if world > 1 else "none (1 GPU)")},
             "roofline": {"bound": "valu_issue", "achieved": valu_rate, "peak": valu_peak, "unit": "wave-instructions/s",
                          "frac": (valu_rate / valu_peak) if valu_rate else None,

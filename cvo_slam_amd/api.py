@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
     "cvo_batch_set_pairs", "cvo_batch_result_records", "cvo_shard_block", "cvo_batch_gather_results_padded", "cvo_batch_padded_records",
-    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v",
+    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers",
 ]
 
 _lib = None
@@ -196,6 +196,9 @@ def load_library():
     L.cvo_compact_records.argtypes = [fp, C.c_int, C.c_int, fp, ip]
     L.cvo_gather_results_padded.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, ip, C.c_int, ip, C.POINTER(vp)]
     L.cvo_multi_align_async_v.argtypes = [vp, ip]
+    L.cvo_batch_done.argtypes = [vp, ip]
+    L.cvo_batch_set_tail_scores.argtypes = [vp, C.c_int]
+    L.cvo_batch_last_tail_answers.argtypes = [vp, C.c_int, ip]
     _lib = L
     return L
 
@@ -649,6 +652,15 @@ class CvoBatch:
         """finished workgroups help with the pairs of their launch that still run (cvo_hip.h: cvo_batch_set_adoption)"""
         _check(self.L.cvo_batch_set_adoption(self.h, int(bool(on))))
 
+    def set_tail_scores(self, on: bool):
+        """the tracker's score block answered by the align launch itself (cvo_hip.h: cvo_batch_set_tail_scores)"""
+        _check(self.L.cvo_batch_set_tail_scores(self.h, int(bool(on))))
+
+    def last_tail_answers(self, n: int):
+        m = (C.c_int * n)()
+        _check(self.L.cvo_batch_last_tail_answers(self.h, n, m))
+        return list(m)
+
     def last_adoptions(self) -> int:
         n = C.c_int(0)
         _check(self.L.cvo_batch_last_adoptions(self.h, C.byref(n)))
@@ -668,6 +680,12 @@ class CvoBatch:
         return [dict(transform=np.array(r.transform[:], np.float32).reshape(3, 4), R=np.array(r.R[:], np.float32).reshape(3, 3),
                      T=np.array(r.T[:], np.float32), ell=r.ell, iter=r.iter, A_nonzero=r.A_nonzero,
                      iterations_run=r.iterations_run, status=r.status, rebuilds=r.rebuilds, dense_fallbacks=r.dense_fallbacks) for r in res]
+
+    def done(self) -> bool:
+        """cvo_batch_done: has the last launch completed?  Never blocks."""
+        d = C.c_int(0)
+        _check(self.L.cvo_batch_done(self.h, C.byref(d)))
+        return bool(d.value)
 
     def align(self, n_pairs: int):
         self.align_async(n_pairs)

@@ -211,6 +211,9 @@ struct Engine {
     float last_ms = 0.f;
     bool launched = false;
     int last_G = 1;              // workgroups per pair of the last launch
+    bool tail_scores = false;    // align launches also answer the tracker's score block for every pair in the kernel's tail (PairDesc::score_out)
+    bool last_tail = false;      // ... and the last launch did
+    PinBuf h_tail;               // n x 5 x 24 doubles, written by the kernel
     bool adopt = false;          // finished workgroups help with the pairs of their launch that still run (one workgroup and one slot per pair; CVO_HIP_ADOPT)
 
     void release_slots() {
@@ -257,6 +260,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_SELF_CACHE")) self_cache_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("CVO_HIP_UPLOAD_COPY")) upload_copy = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_UPLOAD_THREADS")) upload_threads = std::max(1, std::min(16, std::atoi(e)));
         upload_threads = std::max(1, std::min(upload_threads, (int)std::thread::hardware_concurrency()));
         return CVO_OK;
@@ -269,7 +273,7 @@ struct Engine {
         d_scoredescs.release(); h_scoredescs.release(); h_counts.release();
         for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts, &d_tiles}) b->release();
         for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_queue, &d_trace, &d_tracelen, &d_partials, &d_raw, &d_records}) b->release();
-        for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials}) b->release();
+        for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials, &h_tail}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -283,6 +287,8 @@ struct Engine {
     struct UploadItem { Cloud* c; const float* xyz; const float* feat; int n; };
     DevBuf d_raw;
     int upload_threads = 4;
+    bool upload_copy = false;
+    long upload_calls = 0;
     int upload_many(const UploadItem* it, int count) {
         HIP_TRY(hipSetDevice(device));
         int live = 0, n_max = 0; size_t raw_floats = 0;
@@ -310,7 +316,7 @@ struct Engine {
             stage_used = 0;
         }
         if (stage_used + bytes > h_stage.bytes) { HIP_TRY(hipStreamSynchronize(stream)); stage_used = 0; }
-        if (d_raw.bytes < bytes) { HIP_TRY(hipStreamSynchronize(stream)); rc = d_raw.ensure(bytes); if (rc) return rc; }   // an earlier pack kernel may still read it
+        if (upload_copy && d_raw.bytes < bytes) { HIP_TRY(hipStreamSynchronize(stream)); rc = d_raw.ensure(bytes); if (rc) return rc; }   // an earlier pack kernel may still read it
         unsigned char* blk = static_cast<unsigned char*>(h_stage.p) + stage_used;
         stage_used += (bytes + 255) & ~(size_t)255;
         PackDesc* pd = reinterpret_cast<PackDesc*>(blk);
@@ -335,8 +341,22 @@ struct Engine {
             copy_range(0, std::min(pieces.size(), per));
             for (std::thread& t : th) t.join();
         }
-        HIP_TRY(hipMemcpyAsync(d_raw.p, blk, bytes, hipMemcpyHostToDevice, stream));
-        const hipError_t e = launch_pack_clouds(reinterpret_cast<const float*>(static_cast<unsigned char*>(d_raw.p) + desc_bytes), static_cast<const PackDesc*>(d_raw.p), live, n_max, stream);
+        // The pack kernel reads the staging block where it lies (pinned host memory is mapped into the device's address space): the points
+        // cross PCIe once, inside the kernel, and no copy-engine transfer is queued -- copies of different streams share the DMA engines and
+        // one of them behind another stream's long kernel holds up launches that have nothing to do with it (cf. launch_impl).
+        // CVO_HIP_UPLOAD_COPY=1: a host-to-device copy into a device block first, the kernel reads that.
+        const unsigned char* src = blk;
+        ++upload_calls;
+        const char* dbg = upload_calls > 1 ? std::getenv("CVO_HIP_UPLOAD_DEBUG") : nullptr;   // (the first hand-over of an engine is always real)
+        if (dbg) {   // timing experiments only: 1 = neither copy nor pack kernel (the clouds keep their earlier contents), 2 = pack kernel reading the earlier device block
+            if (std::atoi(dbg) == 1) return CVO_OK;
+            if (std::atoi(dbg) == 2 && d_raw.bytes >= bytes) { (void)launch_pack_clouds(reinterpret_cast<const float*>(static_cast<unsigned char*>(d_raw.p) + desc_bytes), static_cast<const PackDesc*>(d_raw.p), live, n_max, stream); return CVO_OK; }
+        }
+        if (upload_copy) {
+            HIP_TRY(hipMemcpyAsync(d_raw.p, blk, bytes, hipMemcpyHostToDevice, stream));
+            src = static_cast<const unsigned char*>(d_raw.p);
+        }
+        const hipError_t e = launch_pack_clouds(reinterpret_cast<const float*>(src + desc_bytes), reinterpret_cast<const PackDesc*>(src), live, n_max, stream);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("cloud pack kernel launch: ") + hipGetErrorString(e));
         return CVO_OK;
     }
@@ -572,6 +592,13 @@ struct Engine {
             if ((rc = d_tracelen.ensure(sizeof(int) * 4))) return rc;
             HIP_TRY(hipMemsetAsync(d_tracelen.p, 0, sizeof(int) * 4, s));
         }
+        // the tracker's score block in the kernel's tail: the clouds' tables of cached self inner products live behind their group boxes
+        bool tails = tail_scores && !want_trace;
+        for (int i = 0; i < n && tails; ++i) tails = pairs[i].fixed && pairs[i].moving && pairs[i].fixed->n > 0 && pairs[i].moving->n > 0;
+        if (tails) {
+            if ((rc = h_tail.ensure(sizeof(double) * (size_t)n * 5 * 24))) return rc;
+            for (int i = 0; i < n; ++i) { if ((rc = ensure_boxes(*pairs[i].fixed, s))) return rc; if ((rc = ensure_boxes(*pairs[i].moving, s))) return rc; }
+        }
         std::vector<PairDesc> hdv(n);
         std::memset(hdv.data(), 0, sizeof(PairDesc) * n);            // padding bytes take part in the comparison below
         PairDesc* hd = hdv.data();
@@ -597,6 +624,11 @@ struct Engine {
             D.trace_len = want_trace ? static_cast<int*>(d_tracelen.p) : nullptr;
             D.member_regions = ac ? 1 : 0;
             D.record = static_cast<float*>(d_records.p) + (size_t)i * CVO_RESULT_FLOATS;
+            if (tails) {
+                D.score_out = static_cast<double*>(h_tail.p) + (size_t)i * 5 * 24;
+                D.self_fixed = score_self_cache(static_cast<float*>(pairs[i].fixed->boxes.p), pairs[i].fixed->n);
+                D.self_moving = score_self_cache(static_cast<float*>(pairs[i].moving->boxes.p), pairs[i].moving->n);
+            }
         }
         // Steady state = no copy-engine work at all: copies queued on different streams share the DMA engines and a copy behind
         // another stream's running kernel would serialise the launches.  Descriptors go up only when they changed, start states
@@ -639,6 +671,7 @@ struct Engine {
         HIP_TRY(hipEventRecord(ev1, s));
         launched = true;
         last_stream = s;
+        last_tail = tails;
         return CVO_OK;
     }
     hipStream_t last_stream = nullptr;
@@ -1430,6 +1463,16 @@ int cvo_batch_wait(cvo_batch b, cvo_pair_result* results, int n) {
     }
     return CVO_OK;
 }
+int cvo_batch_done(cvo_batch b, int* done) {
+    if (!b || !done) return fail(CVO_ERR_INVALID, "null argument");
+    *done = 1;
+    if (!b->eng.launched) return CVO_OK;
+    HIP_TRY(hipSetDevice(b->eng.device));
+    const hipError_t e = hipEventQuery(b->eng.ev1);                 // recorded right behind the launch on its stream
+    if (e == hipErrorNotReady) { *done = 0; (void)hipGetLastError(); return CVO_OK; }
+    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+    return CVO_OK;
+}
 int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_total, long long* candidates_total) {
     if (!b) return fail(CVO_ERR_INVALID, "null batch");
     if (kernel_ms) *kernel_ms = b->eng.last_ms;
@@ -1510,10 +1553,44 @@ int cvo_batch_enqueue_innerproduct(cvo_batch b, int n) {
     }
     return b->eng.score_enqueue(rq.data(), n * 5, b->eng.last_stream);
 }
+int cvo_batch_set_tail_scores(cvo_batch b, int on) { if (!b) return fail(CVO_ERR_INVALID, "null batch"); b->eng.tail_scores = on != 0; return CVO_OK; }
+namespace {
+// the score blocks the last launch answered in its tail; whatever a pair's workgroup could not answer (PairDesc::score_out[23]) is
+// computed by the score kernel now, all missing requests of the batch in one launch
+int collect_tail_scores(cvo_batch b, int n, double* r /* n x 5 x 24 */) {
+    if (n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "more pairs than the last launch aligned");
+    int rc = b->eng.wait(); if (rc) return rc;
+    std::memcpy(r, b->eng.h_tail.p, sizeof(double) * (size_t)n * 5 * 24);
+    static const int bit_of[5] = {TAIL_PRE, TAIL_POST, TAIL_FIXED, TAIL_MOVING, TAIL_HESSIAN};
+    std::vector<Engine::ScoreReq> rq; std::vector<int> where;
+    for (int i = 0; i < n; ++i) {
+        const int mask = (int)r[(size_t)i * 120 + 23];
+        const Cloud* fx = b->fixed[i].get(); const Cloud* mv = b->moving[i].get();
+        const Engine::ScoreReq all[5] = {{mv, nullptr, fx, false, 0.f, i, false}, {mv, nullptr, fx, false, 0.f, i, true}, {fx, nullptr, fx, false, 0.f, i, false},
+                                         {mv, nullptr, mv, false, 0.f, i, false}, {mv, nullptr, fx, true, 0.f, i, true}};   // cvo.cpp:489, 491, 496, 497, 500
+        for (int q = 0; q < 5; ++q) if (!(mask & bit_of[q])) { rq.push_back(all[q]); where.push_back(i * 5 + q); }
+    }
+    if (!rq.empty()) {
+        std::vector<double> extra(rq.size() * 24);
+        rc = b->eng.score_many(rq.data(), (int)rq.size(), reinterpret_cast<double (*)[24]>(extra.data())); if (rc) return rc;
+        for (size_t k = 0; k < rq.size(); ++k) std::memcpy(r + (size_t)where[k] * 24, extra.data() + k * 24, sizeof(double) * 24);
+    }
+    for (int i = 0; i < n; ++i) r[(size_t)i * 120 + 23] = 0.0;
+    return CVO_OK;
+}
+}  // namespace
+int cvo_batch_last_tail_answers(cvo_batch b, int n, int* masks) {
+    if (!b || !masks || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad argument");
+    int rc = b->eng.wait(); if (rc) return rc;
+    for (int i = 0; i < n; ++i) masks[i] = b->eng.last_tail ? (int)static_cast<const double*>(b->eng.h_tail.p)[(size_t)i * 120 + 23] : 0;
+    return CVO_OK;
+}
 int cvo_batch_innerproduct_results(cvo_batch b, int n, cvo_track_scores* out) {
     if (!b || !out) return fail(CVO_ERR_INVALID, "null argument");
     std::vector<double> r((size_t)std::max(n, 1) * 5 * 24);
-    int rc = b->eng.score_collect(n * 5, reinterpret_cast<double (*)[24]>(r.data())); if (rc) return rc;
+    int rc = (b->eng.last_tail && b->eng.score_pending == 0) ? collect_tail_scores(b, n, r.data())
+                                                             : b->eng.score_collect(n * 5, reinterpret_cast<double (*)[24]>(r.data()));
+    if (rc) return rc;
     for (int i = 0; i < n; ++i) {
         const double (*ri)[24] = reinterpret_cast<const double (*)[24]>(r.data() + (size_t)i * 5 * 24);
         cvo_track_scores& o = out[i];

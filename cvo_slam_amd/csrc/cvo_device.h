@@ -56,6 +56,8 @@ struct TraceRow {        // == cvo_trace_row (include/cvo_hip.h)
     int pad_;
 };
 
+constexpr int TAIL_PRE = 1, TAIL_POST = 2, TAIL_FIXED = 4, TAIL_MOVING = 8, TAIL_HESSIAN = 16;   // PairDesc::score_out[23]
+
 // exchange area for the G workgroups that cooperate on one pair: two buffers
 // (alternating by phase), G slots of XCH_WORDS 8-byte {tag, payload} granules.
 constexpr int XCH_WORDS = 16;
@@ -84,6 +86,13 @@ struct PairDesc {
     TraceRow* trace;         // optional
     int trace_cap;
     int* trace_len;
+    // Tracker score block in the kernel's tail (cvo::compute_innerproduct, cvo.cpp:475-503, with tran = this alignment's own result and the
+    // ell it left behind): non-null = 5 x 24 doubles in pinned host memory, request r at [24 r]: {sum_A, count, 21 Hessian terms}
+    // for r = 0 fip(moving, fixed), 1 fip(T moving, fixed), 2 fip(fixed, fixed), 3 fip(moving, moving), 4 se3_Hessian(T moving, fixed);
+    // [23] of request 0 = bit mask of the requests the kernel has answered (TAIL_*), the host's score kernel answers the others
+    double* score_out;
+    const struct SelfCacheEntry* self_fixed;    // the clouds' tables of cached self inner products (ScoreDesc::self_cache)
+    const struct SelfCacheEntry* self_moving;
     float* record;           // this pair's 64-byte result record {transform[12], iter, A_nonzero, iterations_run, status as floats}: written by the kernel's
                              // final block, so the cross-GPU gather (or a caller that wants the records on the device) needs no pack kernel behind the launch
     int member_regions;      // adoption launches: member g of a pair keeps its lists and records in a region of its own (sized for the rows it owns

@@ -1590,6 +1590,198 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 #endif
 }
 
+// ---- Tail: the tracker's score block (cvo::compute_innerproduct, cvo.cpp:475-503) for the pair this workgroup has just aligned, from
+// what is resident anyway.  inn_post = fip(T moving, fixed) and se3_Hessian(T moving, fixed) (cvo.cpp:491, 500) are sums over the pairs
+// within the radius at the ell the alignment left behind (Q1) -- a subset of the candidate lists, once the cloud has been transformed
+// with the FINAL transform (cvo.cpp:485-487, 817) and the lists are still valid for it; no a > sp_thres test here (Q6).  inn_pre =
+// fip(moving, fixed) (cvo.cpp:489) takes one cull of the untransformed cloud at that radius.  fip(fixed, fixed), fip(moving, moving)
+// (cvo.cpp:496-497) come from the clouds' tables when they are there.  The pair arithmetic is the score kernel's (cvo_score_kernels.hip:
+// un-fused d2, double exp with the division as written).  Whatever cannot be answered here (lists stale, a helped pair, a cloud not
+// resident in LDS as float4, a cold table) is left to the host, which runs the score kernel for it.  One workgroup per pair only.
+__device__ __forceinline__ void score_pair_terms(const float (&pa)[3], const float (&fa)[5], const float (&pb)[3], const float (&fb)[5], float d2, float d2c_thres,
+                                                 float sig2, float csig2, double den_l, double den_c, float il2, double& sumA, int& count, float (&H)[21], int& hcount) {
+    float t[5];
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) { const float e = fa[cc] - fb[cc]; t[cc] = e * e; }
+    const float d2c = (t[0] + t[1]) + (t[2] + (t[3] + t[4]));
+    if (!(d2c < d2c_thres)) return;                                                     // cvo.cpp:428 / 659
+    const float k = (float)((double)sig2 * exp((double)(-d2) / den_l));                // cvo.cpp:429 / 661
+    const float ck = (float)((double)csig2 * exp((double)(-d2c) / den_c));             // cvo.cpp:430
+    sumA += ck * k; count += 1;                                                        // cvo.cpp:432-435
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) t[cc] = fa[cc] * fb[cc];
+    const float cdot = (t[0] + t[1]) + (t[2] + (t[3] + t[4]));                          // cvo.cpp:662
+    float cr[3]; cross3(pa, pb, cr);
+    const float dot1 = pa[1] * pb[1] + pa[2] * pb[2], dot2 = pa[0] * pb[0] + pa[2] * pb[2], dot3 = pa[0] * pb[0] + pa[1] * pb[1];
+    const float db[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    float Bq[21];
+    Bq[0] = il2 * cr[0] * cr[0] - dot1;                                                // block A, cvo.cpp:670-675
+    Bq[1] = (float)(il2 * cr[0] * cr[1] + 0.5 * (pa[0] * pb[1] + pa[1] * pb[0]));
+    Bq[2] = (float)(il2 * cr[0] * cr[2] + 0.5 * (pa[0] * pb[2] + pa[2] * pb[0]));
+    Bq[3] = il2 * cr[1] * cr[1] - dot2;
+    Bq[4] = (float)(il2 * cr[1] * cr[2] + 0.5 * (pa[1] * pb[2] + pa[2] * pb[1]));
+    Bq[5] = il2 * cr[2] * cr[2] - dot3;
+    Bq[6] = il2 * cr[0] * db[0];          Bq[7] = -pa[2] + il2 * db[0] * cr[1];  Bq[8] = pa[1] + il2 * db[0] * cr[2];    // block C, cvo.cpp:680-688
+    Bq[9] = pa[2] + il2 * db[1] * cr[0];  Bq[10] = il2 * cr[1] * db[1];          Bq[11] = -pa[0] + il2 * db[1] * cr[2];
+    Bq[12] = -pa[1] + il2 * db[2] * cr[0]; Bq[13] = pa[0] + il2 * db[2] * cr[1]; Bq[14] = il2 * cr[2] * db[2];
+    Bq[15] = il2 * db[0] * db[0] - 1; Bq[16] = il2 * db[0] * db[1]; Bq[17] = il2 * db[0] * db[2];                        // block D, cvo.cpp:692-697
+    Bq[18] = il2 * db[1] * db[1] - 1; Bq[19] = il2 * db[1] * db[2]; Bq[20] = il2 * db[2] * db[2] - 1;
+    const float wgt = il2 * cdot * k;                                                  // cvo.cpp:707
+#pragma unroll
+    for (int q2 = 0; q2 < 21; ++q2) H[q2] += wgt * Bq[q2];
+    hcount += 1;
+}
+static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
+    CVO_GLOBAL double* out = (CVO_GLOBAL double*)Dp->score_out;
+    int answered = 0;
+    const DevParams P = sh->P;
+    const float ell = sh->ell;                                                          // what align() left behind (Q1): cvo.cpp:395, 626
+    const float d2_thres = gate_d2_score(ell, P.sp_thres, P.sigma), d2c_thres = gate_d2c(P.c_ell, P.sp_thres, P.c_sigma);
+    const double den_l = 2.0 * ell * ell, den_c = 2.0 * P.c_ell * P.c_ell;
+    const float sig2 = P.sigma * P.sigma, csig2 = P.c_sigma * P.c_sigma, il2 = 1 / (ell * ell);
+    float4 none[PRE_T];
+#pragma unroll
+    for (int u = 0; u < PRE_T; ++u) none[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float Ms[12];                                                                       // cvo::transform of the last executed iteration (cvo.cpp:815): the transforms below overwrite it
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Ms[i] = sh->M[i];
+    }
+    const bool can = (G == 1) && (y_lds == 1) && (sh->status == 0) && !sh->dense_mode && sh->list_valid;
+    // ---- fip(T moving, fixed) and the Hessian terms from the candidate lists
+    if (can) {
+        transform_body_t<1>(c, L, sh, none, false);                                     // y = FINAL transform * p (cvo.cpp:485-487 with cvo.cpp:817); are the lists still valid for it?
+        if (sh->rebuild == 0) {
+            double sumA = 0; int count = 0, hcount = 0; float H[21];
+#pragma unroll
+            for (int q = 0; q < 21; ++q) H[q] = 0.f;
+            const bool x_lds = sh->x_lds != 0;
+            const int nb = sh->wnb[wave];
+            for (int bi = 0; bi < nb; ++bi) {
+                const int blk = wave_block(bi, wave, nwaves);
+                const int slot = blk * 64 + lane;
+                const int len = L.lenS[slot];
+                const int lw = uni((int)sh->blk_lmax[blk]);
+                float xi[3]; load_x(c, L, x_lds, slot, xi);
+                const int gi = global_row(c, (int)L.row_of[slot]);
+                const float4 flo = ld4(c.fixed + lo_off(gi)), fhi = ld4(c.fixed + hi_off(c.nf, gi));
+                const float fb[5] = {flo.w, fhi.x, fhi.y, fhi.z, fhi.w};
+                const gv2u* ep = c.ent + slot;
+                for (int n0 = 0; n0 < lw; n0 += PF) {
+                    v2u en[PF];
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) en[u] = ep[(size_t)min(n0 + u, c.capn - 1) * c.rows_pad];   // the step's entries in one round trip (stale beyond the row's end)
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        const bool act = n0 + u < len;
+                        const int j = act ? (int)(en[u].y & 0xFFFFu) : 0;
+                        const float4 y = L.ylds[j];
+                        const float pa[3] = {y.x, y.y, y.z};
+                        const float e0 = pa[0] - xi[0], e1 = pa[1] - xi[1], e2 = pa[2] - xi[2];
+                        float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;       // nanoflann.hpp:403-406
+                        if (act && d2 < d2_thres) {                                     // cvo.cpp:423 / 654
+                            const float4 ghi = ld4(c.moving + hi_off(c.nm, j));
+                            const float fa[5] = {y.w, ghi.x, ghi.y, ghi.z, ghi.w};
+                            score_pair_terms(pa, fa, xi, fb, d2, d2c_thres, sig2, csig2, den_l, den_c, il2, sumA, count, H, hcount);
+                        }
+                    }
+                }
+            }
+            double v[8];
+            v[0] = sumA; v[1] = (double)count;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v[2 + q] = (double)H[q];
+            double r0 = block_reduce<8>(v, sh, tid, nwaves);
+            if (tid < 2) { out[24 + tid] = r0; out[4 * 24 + tid] = (tid == 1) ? r0 : 0.0; }
+            if (tid >= 2 && tid < 8) out[4 * 24 + tid] = r0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (double)H[6 + q];
+            r0 = block_reduce<8>(v, sh, tid, nwaves);
+            if (tid < 8) out[4 * 24 + 8 + tid] = r0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = q < 7 ? (double)H[14 + q] : 0.0;
+            r0 = block_reduce<8>(v, sh, tid, nwaves);
+            if (tid < 7) out[4 * 24 + 16 + tid] = r0;
+            answered |= TAIL_POST | TAIL_HESSIAN;
+        }
+        // ---- fip(moving, fixed): the untransformed cloud against the fixed one, one cull at this radius
+        float Rs[9], Ts[3];
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { Rs[i] = sh->R[i]; sh->R[i] = (i % 4 == 0) ? 1.f : 0.f; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { Ts[i] = sh->T[i]; sh->T[i] = 0.f; }
+            sh->list_valid = 0;
+        }
+        __syncthreads();
+        transform_body_t<1>(c, L, sh, none, false);                                     // y = p
+        const int rebuilds_before = sh->rebuilds;
+        phase_cull(Dp, g, G, tgeo, y_lds);                                              // the rows' neighbours within (1 + skin) r_c of the untransformed cloud, by row
+        {
+            double sumA = 0; int count = 0, hcount = 0; float H[21];
+#pragma unroll
+            for (int q = 0; q < 21; ++q) H[q] = 0.f;
+            int overflow = 0;
+            for (int li = tid; li < c.nrows; li += nthreads) {
+                const int len = L.rowlen[li];
+                if (len > c.capn) { overflow = 1; continue; }
+                const int gi = global_row(c, li);
+                const float4 flo = ld4(c.fixed + lo_off(gi)), fhi = ld4(c.fixed + hi_off(c.nf, gi));
+                const float xi[3] = {flo.x, flo.y, flo.z};
+                const float fb[5] = {flo.w, fhi.x, fhi.y, fhi.z, fhi.w};
+                const gv2u* jp = c.jT4 + li;
+                for (int n = 0; n < len; ++n) {
+                    const v2u w = jp[(size_t)(n >> 2) * c.rows_pad];
+                    const unsigned half = (n & 2) ? w.y : w.x;
+                    const int j = (int)((n & 1) ? (half >> 16) : (half & 0xFFFFu));
+                    const float4 y = L.ylds[j];
+                    const float pa[3] = {y.x, y.y, y.z};
+                    const float e0 = pa[0] - xi[0], e1 = pa[1] - xi[1], e2 = pa[2] - xi[2];
+                    float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;
+                    if (d2 < d2_thres) {
+                        const float4 ghi = ld4(c.moving + hi_off(c.nm, j));
+                        const float fa[5] = {y.w, ghi.x, ghi.y, ghi.z, ghi.w};
+                        score_pair_terms(pa, fa, xi, fb, d2, d2c_thres, sig2, csig2, den_l, den_c, il2, sumA, count, H, hcount);
+                    }
+                }
+            }
+            double v[8] = {sumA, (double)count, (double)overflow, 0, 0, 0, 0, 0};
+            const double r0 = block_reduce<8>(v, sh, tid, nwaves);
+            if (tid < 2) out[tid] = r0;
+            if (sh->vals[2] == 0.0) answered |= TAIL_PRE;
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) sh->R[i] = Rs[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sh->T[i] = Ts[i];
+            sh->rebuilds = rebuilds_before;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) sh->M[i] = Ms[i];
+    }
+    // ---- fip(fixed, fixed), fip(moving, moving) from the clouds' tables
+    if (tid == 0) {
+        const SelfCacheEntry* tabs[2] = {Dp->self_fixed, Dp->self_moving};
+        for (int q = 0; q < 2; ++q) {
+            if (!tabs[q]) continue;
+            for (int e = 0; e < SELF_CACHE_N; ++e) {
+                if (tabs[q][e].valid && tabs[q][e].ell == ell) { out[(2 + q) * 24] = tabs[q][e].sum; out[(2 + q) * 24 + 1] = tabs[q][e].count; answered |= (q == 0 ? TAIL_FIXED : TAIL_MOVING); }
+            }
+        }
+        out[23] = (double)answered;
+    }
+    __syncthreads();
+}
+
 // ---- Adoption: finished workgroups help with the pairs that are still running (one workgroup per pair, a slot per pair).
 // Alignments take 33 ... 150 iterations: when a job runs out of queued work the last pairs drag on with most CUs idle.  A workgroup
 // that has finished its pair, and finds nothing queued on the device, offers itself to a pair of its launch that is still running:
@@ -1827,7 +2019,13 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             }
         }
 
-        // ---- after the loop (cvo.cpp:815-817): write the pair's state back
+        // ---- after the loop: the tracker's score block for this pair, when asked for (one workgroup per pair; a helped pair is left to the host)
+        __syncthreads();
+        if (Dp->score_out && ok_pair) {
+            if (Ge == 1 && ge == 0 && !k_join) phase_tail_scores(Dp, ge, Ge, tgeo, y_lds);
+            else if (tid == 0 && ge == 0) ((CVO_GLOBAL double*)Dp->score_out)[23] = 0.0;
+        }
+        // ---- (cvo.cpp:815-817): write the pair's state back
         __syncthreads();
         if (tid == 0 && ge == 0) {
             if (adopt_launch) __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_CLOSED) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody joins any more

@@ -258,6 +258,9 @@ int cvo_batch_reset_states(cvo_batch b);
 int cvo_batch_align_async(cvo_batch b, int n_pairs, void* stream);
 /* wait for the launch and fetch results (n entries) */
 int cvo_batch_wait(cvo_batch b, cvo_pair_result* results, int n);
+/* has the last launch completed?  (never blocks; a caller that keeps several batches in flight can reuse whichever is done first --
+ * alignments take data-dependent numbers of iterations, the oldest launch is not always the first to finish) */
+int cvo_batch_done(cvo_batch b, int* done);
 /* device time of the last launch in ms (HIP events on the launch stream), total loop trips it executed */
 int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_total, long long* candidates_total);
 /* where the last launch spent its time: seconds summed over pairs, as seen by workgroup 0 of each pair:
@@ -358,6 +361,16 @@ typedef struct cvo_track_scores {
     float  cos_angle;                  /* cvo.cpp:498 */
 } cvo_track_scores;
 int cvo_batch_enqueue_innerproduct(cvo_batch b, int n);
+/* The same block answered by the align launch itself (off by default): when a pair's workgroup has finished the alignment it computes
+ * inn_post and the Hessian terms from its resident candidate lists (the cloud re-transformed with the FINAL transform, cvo.cpp:485-487),
+ * inn_pre from one cull of the untransformed cloud, and takes fip(fixed, fixed) / fip(moving, moving) from the clouds' tables of cached
+ * self inner products -- no score launch has to find room beside the persistent align workgroups.  cvo_batch_innerproduct_results then
+ * returns these; anything a workgroup could not answer (lists stale for the final transform, a pair run by several workgroups, a cloud
+ * whose self product has not been computed yet) is computed by the score kernel at that point. */
+int cvo_batch_set_tail_scores(cvo_batch b, int on);
+/* which requests the last launch's workgroups answered themselves, per pair: bit 0 inn_pre, 1 inn_post, 2 inn_fixed_pcd, 3 inn_moving_pcd,
+ * 4 the Hessian (diagnostics / tests; call before cvo_batch_innerproduct_results) */
+int cvo_batch_last_tail_answers(cvo_batch b, int n, int* masks);
 int cvo_batch_innerproduct_results(cvo_batch b, int n, cvo_track_scores* out);
 int cvo_batch_compute_innerproduct(cvo_batch b, int n, cvo_track_scores* out);
 
