@@ -433,7 +433,7 @@ def main():
     # block (4 inner products + 1 Hessian per pair, cvo.cpp:475-503) behind its align launch and collects it with the results.
     with_scores = None
     if world == 1 and not args.no_latency_probe:
-        k2 = max(depth, min(args.steps, 32))
+        k2 = max(depth, args.steps)                        # as many steps as the timed region: the same share of start-up and drain
         scored = []
 
         tail = not os.environ.get("CVO_BENCH_SCORE_LAUNCH")      # default: the align launch answers the block in its tail (cvo_batch_set_tail_scores); else a score launch queued behind it
@@ -480,7 +480,7 @@ def main():
     # reference layout (cvo_batch_set_pair: packing + host-to-device copies), then aligns them.
     with_upload = None
     if world == 1 and not args.no_latency_probe:
-        k3 = max(depth, min(args.steps, 32))
+        k3 = max(depth, args.steps)
         busy = []
 
         def step_upload(i):

@@ -565,7 +565,7 @@ struct Engine {
         if (n > pad_from) pad_from = pad_to = 0;                     // this launch writes over (some of) the padding records
         if ((rc = h_states.ensure(sizeof(PairState) * n))) return rc;
         if ((rc = h_states_in.ensure(sizeof(PairState) * n))) return rc;
-        if (2 * (long long)P.max_iter + 2 >= 65536) return fail(CVO_ERR_INVALID, "max_iter must be below 32767");
+        if (2 * (long long)P.max_iter + 8 >= 65536) return fail(CVO_ERR_INVALID, "max_iter must be below 32764");
         if ((rc = d_ybuf.ensure(sizeof(float4) * (size_t)slots * G * nm_pad))) return rc;   // work buffers: per pair SLOT of the launch
         // Adoption (a pair can grow to four workgroups while it runs): only for one workgroup and one slot per pair with the cloud resident
         // in LDS.  Every member keeps its lists and records in a region of its own, sized for the rows it owns when it joins (make_ctx:

@@ -1597,7 +1597,8 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 // fip(moving, fixed) (cvo.cpp:489) takes one cull of the untransformed cloud at that radius.  fip(fixed, fixed), fip(moving, moving)
 // (cvo.cpp:496-497) come from the clouds' tables when they are there.  The pair arithmetic is the score kernel's (cvo_score_kernels.hip:
 // un-fused d2, double exp with the division as written).  Whatever cannot be answered here (lists stale, a helped pair, a cloud not
-// resident in LDS as float4, a cold table) is left to the host, which runs the score kernel for it.  One workgroup per pair only.
+// resident in LDS as float4, a cold table) is left to the host, which runs the score kernel for it.  A pair run by several workgroups
+// (cooperative launch, helped pair) adds its members' sums up through the pair's exchange area.
 __device__ __forceinline__ void score_pair_terms(const float (&pa)[3], const float (&fa)[5], const float (&pb)[3], const float (&fb)[5], float d2, float d2c_thres,
                                                  float sig2, float csig2, double den_l, double den_c, float il2, double& sumA, int& count, float (&H)[21], int& hcount) {
     float t[5];
@@ -1631,12 +1632,24 @@ __device__ __forceinline__ void score_pair_terms(const float (&pa)[3], const flo
     for (int q2 = 0; q2 < 21; ++q2) H[q2] += wgt * Bq[q2];
     hcount += 1;
 }
-static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
-    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
+// eight partial sums over the workgroup and, for a pair run by several workgroups (a cooperative launch, a helped pair), over its members
+__device__ __forceinline__ double tail_reduce8(double (&v)[8], Shared* sh, const Ctx& c, int G, int g, unsigned epoch, int tid, int nwaves) {
+    double r = block_reduce<8>(v, sh, tid, nwaves);
+    if (G > 1) {
+        if (tid < 64) { if (!group_exchange<8>(sh, c.xch, G, g, epoch, tid & 63)) sh->status = 6; }
+        __syncthreads();
+        r = tid < 8 ? sh->vals[tid] : 0.0;
+        __syncthreads();
+    }
+    return r;
+}
+static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k_done = uni(k_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     CVO_GLOBAL double* out = (CVO_GLOBAL double*)Dp->score_out;
+    const unsigned ep0 = sh->launch_tag | (2u * (unsigned)k_done + 3u);                 // exchange epochs behind the loop's (2k+1, 2k+2 of its last iteration)
     int answered = 0;
     const DevParams P = sh->P;
     const float ell = sh->ell;                                                          // what align() left behind (Q1): cvo.cpp:395, 626
@@ -1651,7 +1664,11 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 #pragma unroll
         for (int i = 0; i < 12; ++i) Ms[i] = sh->M[i];
     }
-    const bool can = (G == 1) && (y_lds == 1) && (sh->status == 0) && !sh->dense_mode && sh->list_valid;
+    // (the same decision on every workgroup of the pair: they exchange partial sums below.  A member in dense mode -- its rows' candidates did
+    //  not fit its lists -- has no lists to walk and says so through the last reduction's spare slot)
+    const bool can = (y_lds == 1) && sh->list_valid && (G > 1 || sh->status == 0);
+    const bool dense = sh->dense_mode != 0;
+    const bool own = g == 0;                                                            // the pair's first workgroup writes the answers
     // ---- fip(T moving, fixed) and the Hessian terms from the candidate lists
     if (can) {
         transform_body_t<1>(c, L, sh, none, false);                                     // y = FINAL transform * p (cvo.cpp:485-487 with cvo.cpp:817); are the lists still valid for it?
@@ -1660,7 +1677,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 #pragma unroll
             for (int q = 0; q < 21; ++q) H[q] = 0.f;
             const bool x_lds = sh->x_lds != 0;
-            const int nb = sh->wnb[wave];
+            const int nb = dense ? 0 : sh->wnb[wave];
             for (int bi = 0; bi < nb; ++bi) {
                 const int blk = wave_block(bi, wave, nwaves);
                 const int slot = blk * 64 + lane;
@@ -1695,18 +1712,19 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
             v[0] = sumA; v[1] = (double)count;
 #pragma unroll
             for (int q = 0; q < 6; ++q) v[2 + q] = (double)H[q];
-            double r0 = block_reduce<8>(v, sh, tid, nwaves);
-            if (tid < 2) { out[24 + tid] = r0; out[4 * 24 + tid] = (tid == 1) ? r0 : 0.0; }
-            if (tid >= 2 && tid < 8) out[4 * 24 + tid] = r0;
+            double r0 = tail_reduce8(v, sh, c, G, g, ep0, tid, nwaves);
+            if (own && tid < 2) { out[24 + tid] = r0; out[4 * 24 + tid] = (tid == 1) ? r0 : 0.0; }
+            if (own && tid >= 2 && tid < 8) out[4 * 24 + tid] = r0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (double)H[6 + q];
-            r0 = block_reduce<8>(v, sh, tid, nwaves);
-            if (tid < 8) out[4 * 24 + 8 + tid] = r0;
+            r0 = tail_reduce8(v, sh, c, G, g, ep0 + 1u, tid, nwaves);
+            if (own && tid < 8) out[4 * 24 + 8 + tid] = r0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = q < 7 ? (double)H[14 + q] : 0.0;
-            r0 = block_reduce<8>(v, sh, tid, nwaves);
-            if (tid < 7) out[4 * 24 + 16 + tid] = r0;
-            answered |= TAIL_POST | TAIL_HESSIAN;
+            for (int q = 0; q < 8; ++q) v[q] = q < 7 ? (double)H[14 + q] : ((dense && tid == 0) ? 1.0 : 0.0);
+            r0 = tail_reduce8(v, sh, c, G, g, ep0 + 2u, tid, nwaves);
+            if (own && tid < 7) out[4 * 24 + 16 + tid] = r0;
+            const double no_lists = __shfl(r0, 7, 64);                                  // (wave 0 holds the totals; thread 0 decides)
+            if (tid == 0 && no_lists == 0.0) answered |= TAIL_POST | TAIL_HESSIAN;
         }
         // ---- fip(moving, fixed): the untransformed cloud against the fixed one, one cull at this radius
         float Rs[9], Ts[3];
@@ -1716,6 +1734,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 #pragma unroll
             for (int i = 0; i < 3; ++i) { Ts[i] = sh->T[i]; sh->T[i] = 0.f; }
             sh->list_valid = 0;
+            sh->P.skin = 0.f;                                                           // nothing moves any more: the cull's radius is r_c itself (restored below)
         }
         __syncthreads();
         transform_body_t<1>(c, L, sh, none, false);                                     // y = p
@@ -1750,9 +1769,10 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
                 }
             }
             double v[8] = {sumA, (double)count, (double)overflow, 0, 0, 0, 0, 0};
-            const double r0 = block_reduce<8>(v, sh, tid, nwaves);
-            if (tid < 2) out[tid] = r0;
-            if (sh->vals[2] == 0.0) answered |= TAIL_PRE;
+            const double r0 = tail_reduce8(v, sh, c, G, g, ep0 + 3u, tid, nwaves);     // (with or without the lists of the first part: the members all take the same branches)
+            if (own && tid < 2) out[tid] = r0;
+            const double ovf = __shfl(r0, 2, 64);                                       // lanes 0..7 of wave 0 hold the totals; thread 0 decides
+            if (tid == 0 && ovf == 0.0) answered |= TAIL_PRE;
         }
         __syncthreads();
         if (tid == 0) {
@@ -1761,6 +1781,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 #pragma unroll
             for (int i = 0; i < 3; ++i) sh->T[i] = Ts[i];
             sh->rebuilds = rebuilds_before;
+            sh->P.skin = P.skin;
         }
         __syncthreads();
     }
@@ -1769,7 +1790,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
         for (int i = 0; i < 12; ++i) sh->M[i] = Ms[i];
     }
     // ---- fip(fixed, fixed), fip(moving, moving) from the clouds' tables
-    if (tid == 0) {
+    if (tid == 0 && own) {
         const SelfCacheEntry* tabs[2] = {Dp->self_fixed, Dp->self_moving};
         for (int q = 0; q < 2; ++q) {
             if (!tabs[q]) continue;
@@ -2021,10 +2042,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
 
         // ---- after the loop: the tracker's score block for this pair, when asked for (one workgroup per pair; a helped pair is left to the host)
         __syncthreads();
-        if (Dp->score_out && ok_pair) {
-            if (Ge == 1 && ge == 0 && !k_join) phase_tail_scores(Dp, ge, Ge, tgeo, y_lds);
-            else if (tid == 0 && ge == 0) ((CVO_GLOBAL double*)Dp->score_out)[23] = 0.0;
-        }
+        if (Dp->score_out && ok_pair) phase_tail_scores(Dp, ge, Ge, tgeo, y_lds, k);   // every workgroup of the pair: each holds the lists of its own rows
         // ---- (cvo.cpp:815-817): write the pair's state back
         __syncthreads();
         if (tid == 0 && ge == 0) {

@@ -45,8 +45,8 @@ def test_tail_scores_match_the_oracle_and_the_score_kernel(hiplib, oracle):
 
 
 def test_tail_scores_fall_back_when_a_workgroup_cannot_answer(hiplib, oracle):
-    """Pairs run by several workgroups, and a launch cut short by max_iter right after an ell change (the lists are for the old ell): the
-    host's score kernel answers, the numbers are the same."""
+    """Pairs run by several workgroups (their partial sums go through the pair's exchange area), and a launch cut short by max_iter right
+    after an ell change (the lists are for the old ell: the host's score kernel answers): the numbers are the same."""
     from cvo_slam_amd import synth
     pairs = [synth.make_small_pair(1400 + i, n=700) for i in range(4)]
     clouds = [(p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat) for p in pairs]
@@ -57,7 +57,26 @@ def test_tail_scores_fall_back_when_a_workgroup_cannot_answer(hiplib, oracle):
         ref.align_async(len(clouds)); ref.enqueue_innerproduct(len(clouds)); ref.wait(); want = ref.innerproduct_results(len(clouds))
         B.align_async(len(clouds)); B.wait(); masks = B.last_tail_answers(len(clouds)); got = B.innerproduct_results(len(clouds))
         if wgs > 1:
-            assert all(m & 0b10011 == 0 for m in masks), masks
+            assert all(m & 0b10011 == 0b10011 for m in masks), masks                  # the pair's workgroups add their sums up through the exchange area
         for g, w in zip(got, want):
             _check(g, w, 1e-6)
         ref.close(); B.close()
+
+
+def test_tail_scores_under_adoption(hiplib):
+    """Helped pairs (cvo_batch_set_adoption) answer their score block too: every member holds the lists of its own rows."""
+    from cvo_slam_amd import synth
+    pairs = [synth.make_pair(i) for i in range(24)]
+    clouds = [(p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat) for p in pairs]
+    ref = hiplib.CvoBatch(len(clouds)); ref.set_workgroups(1); ref.set_pairs(clouds)
+    ref.align_async(len(clouds)); ref.enqueue_innerproduct(len(clouds)); ref.wait(); want = ref.innerproduct_results(len(clouds)); ref.close()
+    B = hiplib.CvoBatch(len(clouds)); B.set_workgroups(1); B.set_adoption(True); B.set_pairs(clouds); B.set_tail_scores(True)
+    helped = 0
+    for rnd in range(4):
+        B.reset_states(); B.align_async(len(clouds)); B.wait(); helped += B.last_adoptions()
+        masks = B.last_tail_answers(len(clouds)); got = B.innerproduct_results(len(clouds))
+        assert all(m & 0b10011 == 0b10011 for m in masks), masks
+        for g, w in zip(got, want):
+            _check(g, w, 1e-6)
+    assert helped > 0
+    B.close()
