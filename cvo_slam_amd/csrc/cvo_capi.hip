@@ -33,7 +33,7 @@ int align_tile_granule();
 int align_blocks_per_cu();
 int align_block_max();
 hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
-                        unsigned launch_tag, unsigned long long* queue, const DevParams& P, const unsigned* wgs_submitted, unsigned* wgs_started);
+                        unsigned launch_tag, unsigned long long* queue, const DevParams& P, const unsigned* wgs_submitted, unsigned* wgs_started, const float* const* raw_table);
 int align_adopt_gmax();
 hipError_t launch_fill_records(float* rec, int from, int to, int status, hipStream_t stream);
 hipError_t launch_copy_records(const float* src, float* dst, int n, hipStream_t stream);
@@ -122,6 +122,9 @@ struct Cloud {
     DevBuf px; int n_px = 0;        // selected pixel (x, y) per point, when the cloud was generated from images
     // boxes of the 32-point groups for the score kernels, made on first use after the points were written
     mutable DevBuf boxes; mutable bool boxes_valid = false; mutable hipStream_t boxes_stream = nullptr;
+    // a hand-over the device has not packed yet: the cloud's arrays as they came (n x 3 positions, then 5 channel-major feature arrays) in
+    // the engine's pinned staging ring; the next align launch packs them itself, any other consumer runs the pack kernel first
+    mutable const float* raw = nullptr;
     float* rec() const { return static_cast<float*>(buf.p); }
     ~Cloud() { buf.release(); px.release(); boxes.release(); }
 };
@@ -261,6 +264,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_SELF_CACHE")) self_cache_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_UPLOAD_COPY")) upload_copy = std::atoi(e) != 0;
+        if (const char* e = std::getenv("CVO_HIP_INKERNEL_PACK")) inkernel_pack = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_UPLOAD_THREADS")) upload_threads = std::max(1, std::min(16, std::atoi(e)));
         upload_threads = std::max(1, std::min(upload_threads, (int)std::thread::hardware_concurrency()));
         return CVO_OK;
@@ -273,7 +277,7 @@ struct Engine {
         d_scoredescs.release(); h_scoredescs.release(); h_counts.release();
         for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts, &d_tiles}) b->release();
         for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_queue, &d_trace, &d_tracelen, &d_partials, &d_raw, &d_records}) b->release();
-        for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials, &h_tail}) b->release();
+        for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials, &h_tail, &h_packdesc, &h_rawtab}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -287,8 +291,40 @@ struct Engine {
     struct UploadItem { Cloud* c; const float* xyz; const float* feat; int n; };
     DevBuf d_raw;
     int upload_threads = 4;
-    bool upload_copy = false;
-    long upload_calls = 0;
+    bool upload_copy = true;
+    bool defer_pack = false;          // batches (cvo_batch_create)
+    bool inkernel_pack = true;        // CVO_HIP_INKERNEL_PACK=0: deferred clouds always go through the pack kernel
+    std::vector<Cloud*> pending;      // clouds with a hand-over not packed yet (Cloud::raw)
+    PinBuf h_packdesc, h_rawtab;
+    hipStream_t packdesc_stream = nullptr, ring_reader = nullptr;
+    // pack kernel over every pending cloud, on stream s (zero-copy from the ring)
+    int flush_pending(hipStream_t s) {
+        if (pending.empty()) return CVO_OK;
+        if (packdesc_stream) { HIP_TRY(hipStreamSynchronize(packdesc_stream)); packdesc_stream = nullptr; }   // an earlier flush may still read the table
+        int rc = h_packdesc.ensure(sizeof(PackDesc) * pending.size()); if (rc) return rc;
+        PackDesc* pd = static_cast<PackDesc*>(h_packdesc.p);
+        const float* base = static_cast<const float*>(h_stage.p);
+        int n_max = 0, q = 0;
+        for (Cloud* c : pending) {
+            if (!c->raw || c->n <= 0) { c->raw = nullptr; continue; }
+            pd[q].raw_off = (unsigned long long)(c->raw - base); pd[q].dst = c->rec(); pd[q].n = c->n; pd[q].pad_ = 0; ++q;
+            n_max = std::max(n_max, c->n); c->raw = nullptr;
+        }
+        pending.clear();
+        if (q == 0) return CVO_OK;
+        const hipError_t e = launch_pack_clouds(base, pd, q, n_max, s);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("cloud pack kernel launch: ") + hipGetErrorString(e));
+        packdesc_stream = s; ring_reader = s;
+        return CVO_OK;
+    }
+    // before the ring is written over: nothing may still have to read it
+    int drain_ring() {
+        int rc = flush_pending(stream); if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (ring_reader && ring_reader != stream) HIP_TRY(hipStreamSynchronize(ring_reader));
+        ring_reader = nullptr;
+        return CVO_OK;
+    }
     int upload_many(const UploadItem* it, int count) {
         HIP_TRY(hipSetDevice(device));
         int live = 0, n_max = 0; size_t raw_floats = 0;
@@ -311,11 +347,11 @@ struct Engine {
         const size_t want = std::max(bytes, (size_t)16 << 20);
         int rc;
         if (h_stage.bytes < want) {
-            HIP_TRY(hipStreamSynchronize(stream));                   // the old buffer may still feed a copy
+            rc = drain_ring(); if (rc) return rc;                    // the old buffer may still feed a copy or a kernel
             rc = h_stage.ensure(want); if (rc) return rc;
             stage_used = 0;
         }
-        if (stage_used + bytes > h_stage.bytes) { HIP_TRY(hipStreamSynchronize(stream)); stage_used = 0; }
+        if (stage_used + bytes > h_stage.bytes) { rc = drain_ring(); if (rc) return rc; stage_used = 0; }
         if (upload_copy && d_raw.bytes < bytes) { HIP_TRY(hipStreamSynchronize(stream)); rc = d_raw.ensure(bytes); if (rc) return rc; }   // an earlier pack kernel may still read it
         unsigned char* blk = static_cast<unsigned char*>(h_stage.p) + stage_used;
         stage_used += (bytes + 255) & ~(size_t)255;
@@ -341,17 +377,22 @@ struct Engine {
             copy_range(0, std::min(pieces.size(), per));
             for (std::thread& t : th) t.join();
         }
-        // The pack kernel reads the staging block where it lies (pinned host memory is mapped into the device's address space): the points
-        // cross PCIe once, inside the kernel, and no copy-engine transfer is queued -- copies of different streams share the DMA engines and
-        // one of them behind another stream's long kernel holds up launches that have nothing to do with it (cf. launch_impl).
-        // CVO_HIP_UPLOAD_COPY=1: a host-to-device copy into a device block first, the kernel reads that.
-        const unsigned char* src = blk;
-        ++upload_calls;
-        const char* dbg = upload_calls > 1 ? std::getenv("CVO_HIP_UPLOAD_DEBUG") : nullptr;   // (the first hand-over of an engine is always real)
-        if (dbg) {   // timing experiments only: 1 = neither copy nor pack kernel (the clouds keep their earlier contents), 2 = pack kernel reading the earlier device block
-            if (std::atoi(dbg) == 1) return CVO_OK;
-            if (std::atoi(dbg) == 2 && d_raw.bytes >= bytes) { (void)launch_pack_clouds(reinterpret_cast<const float*>(static_cast<unsigned char*>(d_raw.p) + desc_bytes), static_cast<const PackDesc*>(d_raw.p), live, n_max, stream); return CVO_OK; }
+        // Batches: the clouds stay in the ring as they came; the next align launch packs each pair's clouds itself, reading the ring where
+        // it lies (pinned host memory is mapped into the device's address space): no copy-engine transfer and no kernel of its own between
+        // the hand-over and the launch -- both cost a tenth of the throughput beside eight persistent launches (copies of different streams
+        // share the DMA engines, small kernels wait for a compute unit no persistent workgroup occupies).  Anything else that wants the
+        // clouds first (a score block, a cooperative launch) runs the pack kernel on them (flush_pending).
+        if (defer_pack) {
+            size_t o2 = 0;
+            for (int k = 0; k < count; ++k) {
+                const int n = it[k].n; if (n <= 0) continue;
+                if (!it[k].c->raw) pending.push_back(it[k].c);
+                it[k].c->raw = raw + o2; o2 += (size_t)n * REC;
+            }
+            return CVO_OK;
         }
+        // Single objects: one host-to-device copy of the block, one pack kernel.  (CVO_HIP_UPLOAD_COPY=0: the kernel reads the ring itself.)
+        const unsigned char* src = blk;
         if (upload_copy) {
             HIP_TRY(hipMemcpyAsync(d_raw.p, blk, bytes, hipMemcpyHostToDevice, stream));
             src = static_cast<const unsigned char*>(d_raw.p);
@@ -402,7 +443,7 @@ struct Engine {
         if ((rc = d_map.ensure(n))) return rc;
         if ((rc = d_counts.ensure(sizeof(int) * 8))) return rc;
         if ((rc = h_counts.ensure(sizeof(int) * 8))) return rc;
-        HIP_TRY(hipStreamSynchronize(stream));                          // nothing reads the staging ring any more
+        if ((rc = drain_ring())) return rc;                             // nothing reads the staging ring any more
         if ((rc = h_stage.ensure(5 * n))) return rc;
         stage_used = (5 * n + 255) & ~(size_t)255;                      // the images are staged at the start of the ring
         if (pattern_len != (int)n) {                                    // the byte pattern only depends on w*h: made once
@@ -595,6 +636,17 @@ struct Engine {
         // the tracker's score block in the kernel's tail: the clouds' tables of cached self inner products live behind their group boxes
         bool tails = tail_scores && !want_trace;
         for (int i = 0; i < n && tails; ++i) tails = pairs[i].fixed && pairs[i].moving && pairs[i].fixed->n > 0 && pairs[i].moving->n > 0;
+        // clouds handed over since the last launch: packed by this launch's workgroups (one per pair, nothing that needs the clouds before the
+        // kernel runs), else by the pack kernel now
+        const float** rawtab = nullptr;
+        if (!pending.empty()) {
+            if (inkernel_pack && G == 1 && !tails) {
+                if (launched && last_stream) HIP_TRY(hipStreamSynchronize(last_stream));   // an earlier launch of this engine may still read the table
+                if ((rc = h_rawtab.ensure(sizeof(const float*) * 2 * (size_t)n))) return rc;
+                rawtab = static_cast<const float**>(h_rawtab.p);
+                for (int i = 0; i < n; ++i) { rawtab[2 * i] = pairs[i].fixed ? pairs[i].fixed->raw : nullptr; rawtab[2 * i + 1] = pairs[i].moving ? pairs[i].moving->raw : nullptr; }
+            } else if ((rc = flush_pending(s))) return rc;
+        }
         if (tails) {
             if ((rc = h_tail.ensure(sizeof(double) * (size_t)n * 5 * 24))) return rc;
             for (int i = 0; i < n; ++i) { if ((rc = ensure_boxes(*pairs[i].fixed, s))) return rc; if ((rc = ensure_boxes(*pairs[i].moving, s))) return rc; }
@@ -662,16 +714,21 @@ struct Engine {
             std::lock_guard<std::mutex> lk(adopt_submit_mutex());
             *ac->submitted_host += (unsigned)grid;
             e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P,
-                             ac->submitted_dev, ac->started_dev);
+                             ac->submitted_dev, ac->started_dev, rawtab);
             if (e != hipSuccess) *ac->submitted_host -= (unsigned)grid;
         } else {
-            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P, nullptr, nullptr);
+            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P, nullptr, nullptr, rawtab);
         }
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));
         launched = true;
         last_stream = s;
         last_tail = tails;
+        if (rawtab) {                                                 // those clouds are the kernel's now; the ring has to stay as it is until the launch is over
+            for (int i = 0; i < n; ++i) { if (pairs[i].fixed) pairs[i].fixed->raw = nullptr; if (pairs[i].moving) pairs[i].moving->raw = nullptr; }
+            pending.erase(std::remove_if(pending.begin(), pending.end(), [](Cloud* c) { return c->raw == nullptr; }), pending.end());
+            ring_reader = s;
+        }
         return CVO_OK;
     }
     hipStream_t last_stream = nullptr;
@@ -744,6 +801,7 @@ struct Engine {
     int score_enqueue(const ScoreReq* rq, int n, hipStream_t s) {
         HIP_TRY(hipSetDevice(device));
         if (n <= 0) return fail(CVO_ERR_INVALID, "bad score request count");
+        { int rcs = flush_pending(s); if (rcs) return rcs; }
         { int rcs = settle_uploads(s); if (rcs) return rcs; }
         std::vector<ScoreDesc> descs(n);
         int row_blocks = 1;
@@ -1368,6 +1426,7 @@ int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* 
     if (p) b->prm = *p; else cvo_default_params(&b->prm);
     int rc = b->eng.init(device, b->prm); if (rc) { b->eng.destroy(); return rc; }
     b->max_pairs = max_pairs;
+    b->eng.defer_pack = true;                                       // hand-overs are packed by the next align launch (Engine::upload_many)
     b->eng.rec_hint = max_pairs + 1;                                // room for the padding record of an uneven shard (cvo_shard_range)
     b->fixed.resize(max_pairs); b->moving.resize(max_pairs);
     b->init_states.resize(max_pairs);

@@ -1814,7 +1814,8 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 
 __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
                                                                          unsigned launch_tag, int tab_cols, unsigned long long* __restrict__ queue_in, DevParams P,
-                                                                         const unsigned* wgs_submitted /* host-mapped */, unsigned* wgs_started) {
+                                                                         const unsigned* wgs_submitted /* host-mapped */, unsigned* wgs_started,
+                                                                         const float* const* __restrict__ raw_table /* pinned host memory, or null */) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
     const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
@@ -1917,6 +1918,28 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
         }
         const PairDesc* Dp = descs + p;
         const int nf = Dp->nf, nm = Dp->nm;
+        if (raw_table && !k_join) {
+            // The pair's clouds as the caller handed them over (cvo_batch_set_pair(s): n x 3 positions AoS, data_type.h:30, then 5 channel-major
+            // feature arrays, data_type.h:75), still in the host's pinned staging ring: this workgroup builds the two float4 planes itself --
+            // the points cross PCIe here, once.  (A helper that joins later sees the planes behind the owner's release, like the pair's state.)
+            const float* const raws[2] = {raw_table[2 * p], raw_table[2 * p + 1]};
+            float* const dsts[2] = {const_cast<float*>(Dp->fixed), const_cast<float*>(Dp->moving)};
+            const int ns[2] = {nf, nm};
+            for (int q = 0; q < 2; ++q) {
+                const float* xyz = raws[q]; if (!xyz) continue;
+                const int n = ns[q]; const float* feat = xyz + 3 * (size_t)n;
+                for (int i = tid; i < n; i += blockDim.x) {
+                    float4 lo, hi;
+                    lo.x = xyz[3 * (size_t)i]; lo.y = xyz[3 * (size_t)i + 1]; lo.z = xyz[3 * (size_t)i + 2]; lo.w = feat[i];
+                    hi.x = feat[(size_t)n + i]; hi.y = feat[2 * (size_t)n + i]; hi.z = feat[3 * (size_t)n + i]; hi.w = feat[4 * (size_t)n + i];
+                    *reinterpret_cast<float4*>(dsts[q] + lo_off(i)) = lo;
+                    *reinterpret_cast<float4*>(dsts[q] + hi_off(n, i)) = hi;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         const int rows_per = ((((nf + ROW_DEAL - 1) / ROW_DEAL) + Ge - 1) / Ge) * ROW_DEAL;
         const PairState* st_from = k_join ? (const PairState*)Dp->state : Dp->state_in;   // a helper starts from what the pair's owner published
         if (tid < 25) {                                               // R[9], T[3], ell, transform[12]: the head of PairState, one lane per word
@@ -2295,12 +2318,12 @@ size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab
 int align_tile_granule() { return 128; }                            // keeps every LDS section 16-byte aligned
 
 hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
-                        unsigned launch_tag, unsigned long long* queue, const DevParams& P, const unsigned* wgs_submitted, unsigned* wgs_started) {
+                        unsigned launch_tag, unsigned long long* queue, const DevParams& P, const unsigned* wgs_submitted, unsigned* wgs_started, const float* const* raw_table) {
     const size_t shmem = align_shared_bytes(tile, rows_cap, y_mode, y_cap, tab_cols);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cvo_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(cvo_align_kernel, dim3(grid), dim3(block), shmem, stream, descs, n_pairs, G, tile, y_mode, rows_cap, y_cap, launch_tag, tab_cols, queue, P,
-                       wgs_submitted, wgs_started);
+                       wgs_submitted, wgs_started, raw_table);
     return hipGetLastError();
 }
 
