@@ -54,7 +54,8 @@ int score_row_blocks(int na);
 int score_groups(int n);
 size_t score_box_bytes(int n);
 hipError_t launch_cloud_boxes(const float* rec, int n, float* gbox, hipStream_t stream);
-hipError_t launch_adaptive(const AdaptiveArgs& A, hipStream_t stream);
+hipError_t launch_adaptive(const AdaptiveArgs& A, int iterations, hipStream_t stream);
+int adaptive_partial_records(int nf, int nm);
 hipError_t launch_selftest(int kind, const float* in, float* out, int n, hipStream_t s);
 hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
                         double* out_pinned, hipStream_t stream);
@@ -1380,11 +1381,12 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
     Cloud fx, mv;
     if ((rc = eng.upload(fx, fixed_xyz, fixed_feat, n_fixed))) return rc;
     if ((rc = eng.upload(mv, moving_xyz, moving_feat, n_moving))) return rc;
-    DevBuf d_y, d_state, d_trace, d_len;
-    struct Bufs { DevBuf *a, *b, *c, *d; ~Bufs() { a->release(); b->release(); c->release(); d->release(); } } bufs{&d_y, &d_state, &d_trace, &d_len};
+    DevBuf d_y, d_state, d_trace, d_len, d_part;
+    struct Bufs { DevBuf *a, *b, *c, *d, *e; ~Bufs() { a->release(); b->release(); c->release(); d->release(); e->release(); } } bufs{&d_y, &d_state, &d_trace, &d_len, &d_part};
     const bool want_trace = trace && trace_cap > 0;
     if ((rc = d_y.ensure(sizeof(float4) * (size_t)n_moving)) || (rc = d_state.ensure(sizeof(AdaptiveState))) ||
-        (rc = d_trace.ensure(sizeof(AdaptiveRow) * (size_t)std::max(1, trace_cap))) || (rc = d_len.ensure(sizeof(int) * 4))) return rc;
+        (rc = d_trace.ensure(sizeof(AdaptiveRow) * (size_t)std::max(1, trace_cap))) || (rc = d_len.ensure(sizeof(int) * 4)) ||
+        (rc = d_part.ensure(sizeof(double) * 16 * (size_t)adaptive_partial_records(n_fixed, n_moving)))) return rc;
     AdaptiveState st; std::memset(&st, 0, sizeof(st));
     std::memcpy(st.R, R_inout, sizeof(st.R)); std::memcpy(st.T, T_inout, sizeof(st.T));
     st.ell = ap.ell_init; st.ell_max = ap.ell_max; st.iter = iter ? *iter : 0; st.status = -1;
@@ -1397,9 +1399,20 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
     A.ell_min = ap.ell_min; A.dl_step = ap.dl_step;
     A.P.sigma = ap.sigma; A.P.sp_thres = ap.sp_thres; A.P.c = ap.c; A.P.d = ap.d; A.P.c_ell = ap.c_ell; A.P.c_sigma = ap.c_sigma;
     A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0;
-    hipError_t e = launch_adaptive(A, eng.stream);
-    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("adaptive kernel launch: ") + hipGetErrorString(e));
-    HIP_TRY(hipStreamSynchronize(eng.stream));
+    A.partials = static_cast<double*>(d_part.p);
+    // a few iterations are queued at a time (five small kernels each, the rows of the sweeps spread over the device); kernels queued behind a
+    // stop return at once, and the host looks at the stop flag between the chunks
+    if (ap.max_iter <= 0) { st.status = 0; st.stop = 1; HIP_TRY(hipMemcpy(d_state.p, &st, sizeof(st), hipMemcpyHostToDevice)); }
+    for (int done = 0; done < std::max(ap.max_iter, 0);) {
+        const int chunk = std::min(8, ap.max_iter - done);
+        hipError_t e = launch_adaptive(A, chunk, eng.stream);
+        if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("adaptive kernel launch: ") + hipGetErrorString(e));
+        int stop = 0;
+        HIP_TRY(hipMemcpyAsync(&stop, &static_cast<AdaptiveState*>(d_state.p)->stop, sizeof(int), hipMemcpyDeviceToHost, eng.stream));
+        HIP_TRY(hipStreamSynchronize(eng.stream));
+        done += chunk;
+        if (stop) break;
+    }
     HIP_TRY(hipMemcpy(&st, d_state.p, sizeof(st), hipMemcpyDeviceToHost));
     if (st.status != 0) return fail(CVO_ERR_HIP, "adaptive kernel did not complete");
     std::memcpy(R_inout, st.R, sizeof(st.R)); std::memcpy(T_inout, st.T, sizeof(st.T));

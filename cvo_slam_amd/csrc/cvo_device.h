@@ -104,12 +104,19 @@ struct AdaptiveRow { float omega[3], v[3], dl, ell, step; int nnz_xy, nnz_xx, nn
 struct AdaptiveState {
     float R[9], T[3], ell, ell_max, transform[12];
     int iter, iterations_run, status;
+    // between the kernels of one iteration
+    int stop;                // a stop test fired (or max_iter reached): the kernels still queued return at once
+    float M[12];             // this iteration's transform (update_tf)
+    float omega[3], v[3], step;
+    double dl;
+    int nnz_xy, nnz_xx, nnz_yy;
 };
 struct AdaptiveArgs {
     const float* fixed; const float* moving;   // two planes of float4 each (lo_off / hi_off)
     int nf, nm;
     float4* ybuf;            // nm transformed moving points
     AdaptiveState* state;    // in/out
+    double* partials;        // [row blocks][16]: per-workgroup partial sums of a sweep
     AdaptiveRow* trace; int trace_cap; int* trace_len;
     float ell_min, dl_step;
     DevParams P;

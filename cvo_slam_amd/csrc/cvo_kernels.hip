@@ -2127,55 +2127,51 @@ hipError_t launch_copy_records(const float* src, float* dst, int n, hipStream_t 
 
 // ---------------------------------------------------------------- adaptive-ell variant
 // acvo::align of thirdparty/cvo/src/adaptive_cvo.cpp:490-555, behind cvo_adaptive_align.  The reference does not build that file and
-// ships no caller (thirdparty/cvo/CMakeLists.txt:66,77-81); this is a plain, dense evaluation of it -- one workgroup per alignment,
-// a thread per row, every column visited -- with the pair arithmetic, the row sums and the epilogue of the main kernel (same device
-// functions), not a tuned path.  Per iteration (compute_flow, :154-272): Axy gives omega, v and -2 sum(a d2)/ell^3; Axx (the fixed
-// cloud against itself) +sum(a d2)/ell^3; of Ayy (the transformed moving cloud against itself) only the rows from num_fixed on add their
-// sum -- the reference never fills sum_diff_yy_2 for the rows below (:218-226 against :246-262) -- while all of its nonzeros count
-// in the denominator (:271).  Then compute_step_size (:275-365, the base sequence), the stop tests (:509, :531), the pose update and
-// ell += dl_step*dl inside [ell_min, ell_max], ell_max shrinking by 0.7 when hit (:538-545).
-__global__ __launch_bounds__(512) void cvo_adaptive_kernel(AdaptiveArgs A) {
-    __shared__ double red[8 * 16];
-    __shared__ double tot[16];
-    __shared__ float sM[12], s_omega[3], s_v[3], s_ell, s_ellmax, sR[9], sT[3], s_step;
-    __shared__ int s_stop, s_iter;
-    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+// ships no caller (thirdparty/cvo/CMakeLists.txt:66,77-81); this is a plain, dense evaluation of it -- a thread per row, every column
+// visited, with the pair arithmetic, the row sums and the scalar epilogue of the main kernel (same device functions) -- spread over the
+// device: the rows of a sweep are dealt to one-wave workgroups (grid over rows), each iteration is five small kernels on one stream
+//   transform | sweep 1 (rows of Axy + Axx, then the rows of Ayy) | sums -> omega, v, dl | sweep 2 (step-size terms) | sums -> step, pose, ell
+// and the host queues a few iterations at a time, looking at the stop flag in between (kernels queued behind a stop return at once).
+// Per iteration (compute_flow, :154-272): Axy gives omega, v and -2 sum(a d2)/ell^3; Axx (the fixed cloud against itself) +sum(a d2)/ell^3;
+// of Ayy (the transformed moving cloud against itself) only the rows from num_fixed on add their sum -- the reference never fills
+// sum_diff_yy_2 for the rows below (:218-226 against :246-262) -- while all of its nonzeros count in the denominator (:271).  Then
+// compute_step_size (:275-365, the base sequence), the stop tests (:509, :531), the pose update and ell += dl_step*dl inside
+// [ell_min, ell_max], ell_max shrinking by 0.7 when hit (:538-545).  Partial sums are added in a fixed order: reproducible run to run.
+constexpr int ADP_ROWS = 64;       // rows (threads) per workgroup of a sweep
+__device__ __forceinline__ void adp_block_partials(double (&v)[16], int K, double* __restrict__ out) {
+    for (int k = 0; k < K; ++k) v[k] = wave_sum_all(v[k]);
+    if (threadIdx.x == 0) for (int k = 0; k < 16; ++k) out[k] = k < K ? v[k] : 0.0;
+}
+__global__ __launch_bounds__(256) void cvo_adaptive_transform_kernel(AdaptiveArgs A) {
+    if (A.state->stop) return;
+    __shared__ float sM[12];
+    if (threadIdx.x == 0) {
+        float Mx[12]; make_transform(A.state->R, A.state->T, Mx);                       // update_tf, :497
+        for (int i = 0; i < 12; ++i) sM[i] = Mx[i];
+        if (blockIdx.x == 0) for (int i = 0; i < 12; ++i) A.state->M[i] = Mx[i];
+    }
+    __syncthreads();
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < A.nm) {                                                                     // transform_pcd, :500
+        const float4 p = ld4((const gfloat*)A.moving + lo_off(j));
+        float y0, y1, y2; apply_transform(sM, p.x, p.y, p.z, y0, y1, y2);
+        GF4 ybuf{(gv4f*)A.ybuf}; ybuf.set(j, make_float4(y0, y1, y2, p.w));
+    }
+}
+// blocks [0, nbx): rows of Axy and Axx; blocks [nbx, nbx + nby): rows of Ayy
+__global__ __launch_bounds__(ADP_ROWS) void cvo_adaptive_sweep1_kernel(AdaptiveArgs A, int nbx) {
+    if (A.state->stop) return;
     const gfloat* fixed = (const gfloat*)A.fixed; const gfloat* moving = (const gfloat*)A.moving;
     GF4 ybuf{(gv4f*)A.ybuf};
     const int N = A.nf, M = A.nm;
-    const DevParams P = A.P;
-    if (tid == 0) {
-        for (int i = 0; i < 9; ++i) sR[i] = A.state->R[i];
-        for (int i = 0; i < 3; ++i) sT[i] = A.state->T[i];
-        s_ell = A.state->ell; s_ellmax = A.state->ell_max; s_stop = 0; s_iter = A.state->iter;
-    }
-    __syncthreads();
-    auto reduce = [&](double (&v)[16], int K) {                     // workgroup totals of K doubles into tot[]
-        for (int k = 0; k < K; ++k) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-        }
-        if (lane == 0) for (int k = 0; k < K; ++k) red[wave * 16 + k] = v[k];
-        __syncthreads();
-        if (tid < K) { double s = 0; for (int w = 0; w < nwaves; ++w) s += red[w * 16 + tid]; tot[tid] = s; }
-        __syncthreads();
-    };
-    int k = 0;
-    for (; k < P.max_iter; ++k) {
-        if (tid == 0) { float Mx[12]; make_transform(sR, sT, Mx); for (int i = 0; i < 12; ++i) sM[i] = Mx[i]; }   // update_tf, :497
-        __syncthreads();
-        for (int j = tid; j < M; j += nthreads) {                   // transform_pcd, :500
-            const float4 p = ld4(moving + lo_off(j));
-            float y0, y1, y2; apply_transform(sM, p.x, p.y, p.z, y0, y1, y2);
-            ybuf.set(j, make_float4(y0, y1, y2, p.w));
-        }
-        __syncthreads();
-        const float ell = s_ell;
-        const Gates gates = make_gates(ell, P);
-        const float inv_c = 1 / P.c, inv_d = 1 / P.d;
-        const float ell_3 = ell * ell * ell, inv_l3 = 1 / ell_3;    // :172
-        double acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // omega[3], v[3], dl, nnz_xy, nnz_xx, nnz_yy
-        for (int i = tid; i < N; i += nthreads) {                   // rows of Axy and Axx, :175-240
+    const float ell = A.state->ell;
+    const Gates gates = make_gates(ell, A.P);
+    const float inv_c = 1 / A.P.c, inv_d = 1 / A.P.d;
+    const float ell_3 = ell * ell * ell, inv_l3 = 1 / ell_3;                            // :172
+    double acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                  // omega[3], v[3], dl, nnz_xy, nnz_xx, nnz_yy
+    if ((int)blockIdx.x < nbx) {
+        const int i = blockIdx.x * ADP_ROWS + threadIdx.x;
+        if (i < N) {                                                                    // rows of Axy and Axx, :175-240
             const float4 lo = ld4(fixed + lo_off(i)), hi = ld4(fixed + hi_off(N, i));
             const float xi[3] = {lo.x, lo.y, lo.z}; const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
             float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0}, s_yx = 0.f, s_xx = 0.f; int nxy = 0, nxx = 0;
@@ -2202,11 +2198,13 @@ __global__ __launch_bounds__(512) void cvo_adaptive_kernel(AdaptiveArgs A) {
                 }
             }
             for (int q = 0; q < 3; ++q) { acc[q] += (double)(inv_c * sw[q]); acc[3 + q] += (double)(inv_d * sv[q]); }   // :227-228
-            acc[6] -= double(2 * s_yx);                             // :231
-            acc[6] += double(s_xx);                                 // :234
+            acc[6] -= double(2 * s_yx);                                                 // :231
+            acc[6] += double(s_xx);                                                     // :234
             acc[7] += nxy; acc[8] += nxx;
         }
-        for (int i = tid; i < M; i += nthreads) {                   // rows of Ayy: all of them count, those from num_fixed on add to dl (:243-266)
+    } else {
+        const int i = ((int)blockIdx.x - nbx) * ADP_ROWS + threadIdx.x;
+        if (i < M) {                                                                    // rows of Ayy: all of them count, those from num_fixed on add to dl (:243-266)
             const float4 yi4 = ybuf[i]; const float4 gi = ld4(moving + hi_off(M, i));
             const float yi[3] = {yi4.x, yi4.y, yi4.z}; const float fi[5] = {yi4.w, gi.x, gi.y, gi.z, gi.w};
             float s_yy = 0.f; int nyy = 0;
@@ -2222,76 +2220,122 @@ __global__ __launch_bounds__(512) void cvo_adaptive_kernel(AdaptiveArgs A) {
             if (i >= N) acc[6] += double(s_yy);
             acc[9] += nyy;
         }
-        reduce(acc, 10);
-        if (tid == 0) { for (int q = 0; q < 3; ++q) { s_omega[q] = (float)tot[q]; s_v[q] = (float)tot[3 + q]; } }   // :269-270
-        __syncthreads();
-        const double dl = tot[6] / (double)((long long)tot[8] + (long long)tot[9] - 2ll * (long long)tot[7]);       // :271
-        const int nnz_xy = (int)tot[7], nnz_xx = (int)tot[8], nnz_yy = (int)tot[9];
-        // compute_step_size, :275-365 (the base sequence): the nonzeros of Axy once more
-        float omega[3], v[3];
-        for (int q = 0; q < 3; ++q) { omega[q] = s_omega[q]; v[q] = s_v[q]; }
-        const LsConsts ls = make_ls(omega, v, ell);
-        double b4[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = tid; i < N; i += nthreads) {
-            const float4 lo = ld4(fixed + lo_off(i)), hi = ld4(fixed + hi_off(N, i));
-            const float xi[3] = {lo.x, lo.y, lo.z}; const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
-            double Bi = 0, Ci = 0, Di = 0, Ei = 0;
-            for (int j = 0; j < M; ++j) {
-                const float4 yj = ybuf[j];
-                const float a = se_kernel_value(xi, fi, yj, ld4(moving + hi_off(M, j)), gates);
-                if (a > 0.f) ls_terms(xi, yj, a, ls, Bi, Ci, Di, Ei);
-            }
-            b4[0] += Bi; b4[1] += Ci; b4[2] += Di; b4[3] += Ei;
-        }
-        reduce(b4, 4);
-        if (tid == 0) {
-            const float c3 = (float)(4.0 * float(tot[3])), c2 = (float)(3.0 * float(tot[2])), c1 = (float)(2.0 * float(tot[1])), c0 = float(tot[0]);
-            const float step = cubic_step(c3, c2, c1, c0, P.min_step);
-            s_step = step;
-            if (A.trace && k < A.trace_cap) {
-                AdaptiveRow& tr = A.trace[k];
-                for (int q = 0; q < 3; ++q) { tr.omega[q] = omega[q]; tr.v[q] = v[q]; }
-                tr.dl = (float)dl; tr.ell = ell; tr.step = step; tr.nnz_xy = nnz_xy; tr.nnz_xx = nnz_xx; tr.nnz_yy = nnz_yy;
-                *A.trace_len = k + 1;
-            }
-            const double nw = sqrt((double)omega[0] * omega[0] + (double)omega[1] * omega[1] + (double)omega[2] * omega[2]);
-            const double nv = sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]);
-            int stop = 0;
-            if (nw < P.eps && nv < P.eps) stop = 1;                 // :509
-            else {
-                float dR[9], dT[3], RdT[3], Rn[9];
-                exp_sek3(omega, v, step, dR, dT);                   // :520
-                mat3_vec(sR, dT, RdT);
-                for (int q = 0; q < 3; ++q) sT[q] = RdT[q] + sT[q];  // :527
-                mat3_mul(sR, dR, Rn);
-                for (int i = 0; i < 9; ++i) sR[i] = Rn[i];           // :528
-                if (dist_se3(dR, dT) < P.eps_2) stop = 1;           // :531
-                else {
-                    float l = (float)((double)ell + (double)A.dl_step * dl);                          // :538
-                    if (l >= s_ellmax) { l = (float)(s_ellmax * 0.7); s_ellmax = (float)(s_ellmax * 0.7); }   // :541-544
-                    l = (l < A.ell_min) ? A.ell_min : l;             // :545
-                    s_ell = l;
-                }
-            }
-            if (stop) s_iter = k;
-            s_stop = stop;
-        }
-        __syncthreads();
-        if (s_stop) { ++k; break; }
     }
-    if (tid == 0) {
+    adp_block_partials(acc, 10, A.partials + (size_t)blockIdx.x * 16);
+}
+// one workgroup: the sums of K values over nb partial records, in record order
+__device__ __forceinline__ void adp_sum_partials(const double* __restrict__ partials, int nb, int K, double* tot /* shared, 16 */) {
+    __shared__ double part[4][16];
+    const int tid = threadIdx.x, q = tid & 15, sub = tid >> 4;                           // 64 threads: four strided sub-sums per value
+    double s = 0;
+    if (q < K) for (int r = sub; r < nb; r += 4) s += partials[(size_t)r * 16 + q];
+    part[sub][q] = s;
+    __syncthreads();
+    if (tid < 16) tot[tid] = tid < K ? ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) : 0.0;
+    __syncthreads();
+}
+__global__ __launch_bounds__(64) void cvo_adaptive_mid_kernel(AdaptiveArgs A, int nb) {
+    if (A.state->stop) return;
+    __shared__ double tot[16];
+    adp_sum_partials(A.partials, nb, 10, tot);
+    if (threadIdx.x == 0) {
         AdaptiveState& st = *A.state;
-        float Mx[12]; make_transform(sR, sT, Mx);                   // the final update_tf, :550
-        for (int i = 0; i < 9; ++i) st.R[i] = sR[i];
-        for (int i = 0; i < 3; ++i) st.T[i] = sT[i];
-        for (int i = 0; i < 12; ++i) st.transform[i] = Mx[i];
-        st.ell = s_ell; st.ell_max = s_ellmax; st.iter = s_iter; st.iterations_run = k; st.status = 0;
+        for (int q = 0; q < 3; ++q) { st.omega[q] = (float)tot[q]; st.v[q] = (float)tot[3 + q]; }            // :269-270
+        st.dl = tot[6] / (double)((long long)tot[8] + (long long)tot[9] - 2ll * (long long)tot[7]);          // :271
+        st.nnz_xy = (int)tot[7]; st.nnz_xx = (int)tot[8]; st.nnz_yy = (int)tot[9];
     }
 }
-hipError_t launch_adaptive(const AdaptiveArgs& A, hipStream_t stream) {
-    hipLaunchKernelGGL(cvo_adaptive_kernel, dim3(1), dim3(512), 0, stream, A);
+// compute_step_size, :275-365 (the base sequence): the nonzeros of Axy once more
+__global__ __launch_bounds__(ADP_ROWS) void cvo_adaptive_sweep2_kernel(AdaptiveArgs A) {
+    if (A.state->stop) return;
+    const gfloat* fixed = (const gfloat*)A.fixed; const gfloat* moving = (const gfloat*)A.moving;
+    GF4 ybuf{(gv4f*)A.ybuf};
+    const int N = A.nf, M = A.nm;
+    const float ell = A.state->ell;
+    const Gates gates = make_gates(ell, A.P);
+    float omega[3], v[3];
+    for (int q = 0; q < 3; ++q) { omega[q] = A.state->omega[q]; v[q] = A.state->v[q]; }
+    const LsConsts ls = make_ls(omega, v, ell);
+    double b4[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int i = blockIdx.x * ADP_ROWS + threadIdx.x;
+    if (i < N) {
+        const float4 lo = ld4(fixed + lo_off(i)), hi = ld4(fixed + hi_off(N, i));
+        const float xi[3] = {lo.x, lo.y, lo.z}; const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
+        double Bi = 0, Ci = 0, Di = 0, Ei = 0;
+        for (int j = 0; j < M; ++j) {
+            const float4 yj = ybuf[j];
+            const float a = se_kernel_value(xi, fi, yj, ld4(moving + hi_off(M, j)), gates);
+            if (a > 0.f) ls_terms(xi, yj, a, ls, Bi, Ci, Di, Ei);
+        }
+        b4[0] = Bi; b4[1] = Ci; b4[2] = Di; b4[3] = Ei;
+    }
+    adp_block_partials(b4, 4, A.partials + (size_t)blockIdx.x * 16);
+}
+__global__ __launch_bounds__(64) void cvo_adaptive_end_kernel(AdaptiveArgs A, int nb) {
+    if (A.state->stop) return;
+    __shared__ double tot[16];
+    adp_sum_partials(A.partials, nb, 4, tot);
+    if (threadIdx.x != 0) return;
+    AdaptiveState& st = *A.state;
+    const DevParams P = A.P;
+    const int k = st.iterations_run;
+    const float ell = st.ell;
+    float omega[3], v[3];
+    for (int q = 0; q < 3; ++q) { omega[q] = st.omega[q]; v[q] = st.v[q]; }
+    const float c3 = (float)(4.0 * float(tot[3])), c2 = (float)(3.0 * float(tot[2])), c1 = (float)(2.0 * float(tot[1])), c0 = float(tot[0]);
+    const float step = cubic_step(c3, c2, c1, c0, P.min_step);
+    st.step = step;
+    if (A.trace && k < A.trace_cap) {
+        AdaptiveRow& tr = A.trace[k];
+        for (int q = 0; q < 3; ++q) { tr.omega[q] = omega[q]; tr.v[q] = v[q]; }
+        tr.dl = (float)st.dl; tr.ell = ell; tr.step = step; tr.nnz_xy = st.nnz_xy; tr.nnz_xx = st.nnz_xx; tr.nnz_yy = st.nnz_yy;
+        *A.trace_len = k + 1;
+    }
+    const double nw = sqrt((double)omega[0] * omega[0] + (double)omega[1] * omega[1] + (double)omega[2] * omega[2]);
+    const double nv = sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]);
+    int stop = 0;
+    if (nw < P.eps && nv < P.eps) stop = 1;                                             // :509
+    else {
+        float dR[9], dT[3], RdT[3], Rn[9], sR[9], sT[3];
+        for (int i = 0; i < 9; ++i) sR[i] = st.R[i];
+        for (int i = 0; i < 3; ++i) sT[i] = st.T[i];
+        exp_sek3(omega, v, step, dR, dT);                                               // :520
+        mat3_vec(sR, dT, RdT);
+        for (int q = 0; q < 3; ++q) st.T[q] = RdT[q] + sT[q];                            // :527
+        mat3_mul(sR, dR, Rn);
+        for (int i = 0; i < 9; ++i) st.R[i] = Rn[i];                                     // :528
+        if (dist_se3(dR, dT) < P.eps_2) stop = 1;                                       // :531
+        else {
+            float l = (float)((double)ell + (double)A.dl_step * st.dl);                 // :538
+            if (l >= st.ell_max) { l = (float)(st.ell_max * 0.7); st.ell_max = (float)(st.ell_max * 0.7); }   // :541-544
+            l = (l < A.ell_min) ? A.ell_min : l;                                        // :545
+            st.ell = l;
+        }
+    }
+    if (stop) st.iter = k;
+    st.iterations_run = k + 1;
+    if (stop || k + 1 >= P.max_iter) {
+        float Rf[9], Tf[3], Mx[12];
+        for (int i = 0; i < 9; ++i) Rf[i] = st.R[i];
+        for (int i = 0; i < 3; ++i) Tf[i] = st.T[i];
+        make_transform(Rf, Tf, Mx);                                                     // the final update_tf, :550
+        for (int i = 0; i < 12; ++i) st.transform[i] = Mx[i];
+        st.status = 0; st.stop = 1;
+    }
+}
+// `iterations` iterations of the variant queued on `stream`; A.state->stop tells the host afterwards whether more are wanted
+hipError_t launch_adaptive(const AdaptiveArgs& A, int iterations, hipStream_t stream) {
+    const int nbx = (A.nf + ADP_ROWS - 1) / ADP_ROWS, nby = (A.nm + ADP_ROWS - 1) / ADP_ROWS;
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(cvo_adaptive_transform_kernel, dim3((A.nm + 255) / 256), dim3(256), 0, stream, A);
+        hipLaunchKernelGGL(cvo_adaptive_sweep1_kernel, dim3(nbx + nby), dim3(ADP_ROWS), 0, stream, A, nbx);
+        hipLaunchKernelGGL(cvo_adaptive_mid_kernel, dim3(1), dim3(64), 0, stream, A, nbx + nby);
+        hipLaunchKernelGGL(cvo_adaptive_sweep2_kernel, dim3(nbx), dim3(ADP_ROWS), 0, stream, A);
+        hipLaunchKernelGGL(cvo_adaptive_end_kernel, dim3(1), dim3(64), 0, stream, A, nbx);
+    }
     return hipGetLastError();
 }
+int adaptive_partial_records(int nf, int nm) { return (nf + ADP_ROWS - 1) / ADP_ROWS + (nm + ADP_ROWS - 1) / ADP_ROWS; }
 
 int align_blocks_per_cu() { return BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD / 2; }
 int align_block_max() { return BLOCK_MAX; }

@@ -67,6 +67,30 @@ def test_hip_adaptive_align_matches_the_oracle(hiplib, oracle, seed, n, drop):
 
 
 @pytest.mark.gpu
+def test_hip_adaptive_align_full_size_pair(hiplib, oracle):
+    """BASELINE-size clouds (640x480 TUM shape, ~3 k points, colours scaled to [0, 1]): the rows of every sweep are spread over the
+    device (one-wave workgroups, grid over rows), the iteration trace is the oracle's."""
+    import time
+    from cvo_slam_amd import synth, api
+    p = synth.make_pair(0)
+    assert p.fixed.n > 2500 and p.moving.n > 2500
+    fx, ff, mx, mf = _normalised(p)
+    rc, want = oracle.adaptive_align(fx, ff, mx, mf, trace_cap=400)
+    api.adaptive_align(fx, ff, mx, mf, trace_cap=4)                     # (first call: module load)
+    t0 = time.perf_counter(); got = api.adaptive_align(fx, ff, mx, mf, trace_cap=400); dt = time.perf_counter() - t0
+    assert rc == 0 and got["iter"] == want["iter"] and len(got["trace"]) == len(want["trace"]) and len(want["trace"]) > 10
+    for k, (g, w) in enumerate(zip(got["trace"], want["trace"])):
+        assert (g["nnz_xy"], g["nnz_xx"], g["nnz_yy"]) == (w["nnz_xy"], w["nnz_xx"], w["nnz_yy"]), k
+        np.testing.assert_allclose(g["omega"], w["omega"], rtol=1e-5, atol=1e-9); np.testing.assert_allclose(g["v"], w["v"], rtol=1e-5, atol=1e-9)
+        assert g["ell"] == pytest.approx(w["ell"], rel=1e-6) and g["step"] == pytest.approx(w["step"], rel=1e-5)
+        assert g["dl"] == pytest.approx(w["dl"], rel=1e-5, abs=1e-9), k
+    rot, tr = rot_trans_err(got["transform"], want["transform"])
+    assert rot <= 1e-4 and tr <= 1e-4
+    print(f"adaptive align, {p.fixed.n} x {p.moving.n} points, {len(got['trace'])} iterations: {1e3 * dt:.1f} ms")
+    assert dt < 1.0                                                    # (one workgroup took ~3 ms per iteration)
+
+
+@pytest.mark.gpu
 def test_hip_adaptive_raw_features_stop_at_once(hiplib):
     from cvo_slam_amd import synth, api
     p = synth.make_small_pair(14, n=300)
