@@ -855,32 +855,43 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                     uint32_t w[SWEEP_R];
                     sweep_group(colx, coly, colz, gi * 32, x, nthr, w);
                     const uint32_t col0 = (uint32_t)(t0 + gi * 32);
+                    // bit 31 = first column of the group: ascending columns.  Up to four hits per row leave the words per trip (the loop runs as
+                    // long as the fullest row of the wave needs: a trip per hit was more than half of the cull) and go into the rows' 8-byte
+                    // words of four columns; a full word is stored (a 2-byte store per hit was the cull's first bottleneck).  The lane's rows take
+                    // their trips together: the bit extraction is a chain of dependent operations, two rows = two chains side by side, and the
+                    // loop runs max(trips) instead of their sum.
+                    static_assert(SWEEP_R == 2, "the hit words of a lane's two rows are unpacked side by side");
+                    uint32_t wq[SWEEP_R] = {w[0], w[1]};
+                    while (wq[0] | wq[1]) {
+                        int nn[SWEEP_R]; unsigned long long four[SWEEP_R];
 #pragma unroll
-                    for (int r = 0; r < SWEEP_R; ++r) {
-                        uint32_t ww = w[r];
-                        // bit 31 = first column of the group: ascending columns.  Up to four hits leave the word per trip (the loop runs
-                        // as long as the fullest row of the wave needs: a trip per hit was more than half of the cull) and go into the row's
-                        // 8-byte word of four columns; a full word is stored (a 2-byte store per hit was the cull's first bottleneck)
-                        while (ww) {
-                            const int n = min(__popc(ww), 4);
-                            const int k0 = __clz(ww);      const uint32_t w1 = ww & ~(0x80000000u >> k0);
+                        for (int r = 0; r < SWEEP_R; ++r) {
+                            const uint32_t ww = wq[r];
+                            nn[r] = min(__popc(ww), 4);
+                            const int k0 = __clz(ww) & 31; const uint32_t w1 = ww & ~(0x80000000u >> k0);
                             const int k1 = __clz(w1) & 31; const uint32_t w2 = w1 & ~(0x80000000u >> k1);
                             const int k2 = __clz(w2) & 31; const uint32_t w3 = w2 & ~(0x80000000u >> k2);
                             const int k3 = __clz(w3) & 31;
-                            ww = w3 & ~(0x80000000u >> k3);
-                            const uint32_t lo = (col0 + (uint32_t)k0) | (n > 1 ? (col0 + (uint32_t)k1) << 16 : 0u);
-                            const uint32_t hi = (n > 2 ? col0 + (uint32_t)k2 : 0u) | (n > 3 ? (col0 + (uint32_t)k3) << 16 : 0u);
-                            const unsigned long long four = ((unsigned long long)hi << 32) | lo;
-                            const int fill = cnt[r] & 3;
-                            if (cnt[r] < c.capn) {                  // capn is a multiple of 4: a word that starts below it ends at or below it
-                                buf[r] |= four << (16 * fill);
-                                if (fill + n >= 4) {
-                                    v2u wv; wv.x = (unsigned)buf[r]; wv.y = (unsigned)(buf[r] >> 32);
-                                    c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]] = wv;
-                                    buf[r] = fill ? (four >> (16 * (4 - fill))) : 0ull;
+                            wq[r] = w3 & ~(0x80000000u >> k3);
+                            const uint32_t lo = (col0 + (uint32_t)k0) | (nn[r] > 1 ? (col0 + (uint32_t)k1) << 16 : 0u);
+                            const uint32_t hi = (nn[r] > 2 ? col0 + (uint32_t)k2 : 0u) | (nn[r] > 3 ? (col0 + (uint32_t)k3) << 16 : 0u);
+                            four[r] = ((unsigned long long)hi << 32) | lo;
+                        }
+#pragma unroll
+                        for (int r = 0; r < SWEEP_R; ++r) {
+                            const int n = nn[r];
+                            if (n > 0) {
+                                const int fill = cnt[r] & 3;
+                                if (cnt[r] < c.capn) {              // capn is a multiple of 4: a word that starts below it ends at or below it
+                                    buf[r] |= four[r] << (16 * fill);
+                                    if (fill + n >= 4) {
+                                        v2u wv; wv.x = (unsigned)buf[r]; wv.y = (unsigned)(buf[r] >> 32);
+                                        c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]] = wv;
+                                        buf[r] = fill ? (four[r] >> (16 * (4 - fill))) : 0ull;
+                                    }
                                 }
+                                cnt[r] += n;
                             }
-                            cnt[r] += n;
                         }
                     }
                 }
