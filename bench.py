@@ -507,7 +507,7 @@ def main():
         mb = sum(fx.nbytes + ff.nbytes + mx.nbytes + mf.nbytes for (_, fx, ff, mx, mf) in pairs) / 1e6
         with_upload = {"value": n * k3 / el3, "unit": "alignments/s", "steps": k3, "ms_per_step": 1e3 * el3 / k3, "host_MB_per_step": mb,
                        "note": "clouds cross the boundary as host buffers every step (cvo_batch_set_pairs: the arrays are copied as they are into a pinned block, "
-                               "one host-to-device copy, one kernel builds the device layout)"}
+                               "the align launch that follows builds the device layout itself, reading the block over PCIe)"}
         batch.reset_states(); batch.align_async(n); batch.wait()
     if rank == 0 and os.environ.get("CVO_BENCH_PHASES"):
         ph = batch.last_phase_seconds(); its_all = sum(r["iterations_run"] for r in results)

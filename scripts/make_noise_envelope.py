@@ -49,7 +49,7 @@ def one_pair(args):
     import pyoracle as po
     from cvo_slam_amd import synth
     from helpers import rot_trans_err
-    pair = synth.make_pair(idx) if kind == "tum" else synth.make_small_pair(idx, n=600)
+    pair = synth.make_pair(idx) if kind == "tum" else (synth.make_pair(idx, cam=synth.ETH3D) if kind == "eth3d" else synth.make_small_pair(idx, n=600))
     base_tf, base_it = _run(po, pair, "parity", 0, 0)
     out = {"pair": idx, "base_iter": base_it, "variants": {}}
     for name, flavor, flags, seed in VARIANTS:
@@ -78,10 +78,24 @@ def main():
     ap.add_argument("--small", type=int, default=8)
     ap.add_argument("--threads", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "noise_envelope.json"))
+    ap.add_argument("--add-eth3d", type=int, default=0, help="only add the section for N ETH3D-shape pairs (BASELINE config 5) to the existing file")
     a = ap.parse_args()
     import pyoracle as po
     po.build()
     t0 = time.time()
+    if a.add_eth3d:
+        with mp.get_context("fork").Pool(a.threads) as pool:
+            eth = pool.map(one_pair, [("eth3d", i) for i in range(a.add_eth3d)], chunksize=1)
+        doc = json.load(open(a.out))
+        doc[f"eth3d{a.add_eth3d}"] = {"workload": f"synth.make_pair(0..{a.add_eth3d - 1}, cam=ETH3D): the {a.add_eth3d} ETH3D-shape pairs of bench.py --shape eth3d (BASELINE config 5)",
+                                      "fast_build_flags": "-O3 -march=native -ffp-contract=fast, host CPU tag " + po._cpu_tag(), **summarize(eth)}
+        with open(a.out, "w") as f:
+            json.dump(doc, f, indent=1)
+        e = doc[f"eth3d{a.add_eth3d}"]
+        print(f"added eth3d{a.add_eth3d} in {time.time() - t0:.0f} s: max {e['max_rot_rad']:.3e} rad / {e['max_trans_m']:.3e} m, {e['pairs_beyond_1e-4']} pairs beyond 1e-4")
+        for n, v in e["per_variant"].items():
+            print(f"  {n:24s} {v['max_rot_rad']:.3e} rad  {v['max_trans_m']:.3e} m  other iteration count on {v['pairs_with_other_iteration_count']} pairs")
+        return
     with mp.get_context("fork").Pool(a.threads) as pool:
         tum = pool.map(one_pair, [("tum", i) for i in range(a.pairs)], chunksize=1)
         small = pool.map(one_pair, [("small", 11 + i) for i in range(a.small)], chunksize=1)
