@@ -631,7 +631,7 @@ def main():
             env = None
             try:
                 with open(os.path.join(ROOT, "tests", "golden", "noise_envelope.json")) as f:
-                    ej = json.load(f)["tum64"]
+                    ej = json.load(f)["tum64" if args.shape == "tum" else "eth3d64"]
                 env = {"max_rot_rad": ej["max_rot_rad"], "max_trans_m": ej["max_trans_m"], "pairs_beyond_1e-4": ej["pairs_beyond_1e-4"],
                        "per_variant": {k: [v["max_rot_rad"], v["max_trans_m"]] for k, v in ej["per_variant"].items()},
                        "source": "tests/golden/noise_envelope.json (scripts/make_noise_envelope.py): distance of the oracle's reference-noise variants from the base oracle on these 64 pairs"}
@@ -640,7 +640,7 @@ def main():
             out["parity"] = {"pairs_checked": len(errs), "against": "oracle, un-fused parity build (every pair of the timed batch)",
                              "max_rot_err_rad": max(e[0] for e in errs), "max_trans_err_m": max(e[1] for e in errs),
                              "iterations_equal": bool(all(a == b for a, b in zip(its, cpu_its))), "tolerance": "1e-4 rad / 1e-4 m",
-                             "reference_noise_envelope": env if args.shape == "tum" else None}
+                             "reference_noise_envelope": env}
             out["speedup_vs_cpu_baseline"] = value / cpu_rate
         print(json.dumps(out), flush=True)
 

@@ -114,6 +114,9 @@ struct __attribute__((aligned(16))) Shared {
     float v[3];
     float dist;
     DevParams P;
+    // this workgroup's view of the current pair (struct Ctx), worked out once per pair (and again when the pair gains a member): every phase is a
+    // function of its own and would otherwise fetch the descriptor's fields from global memory first thing, a round trip per phase call
+    unsigned long long ctx_store[16];
 };
 
 // Pointers read out of a PairDesc are generic to the compiler, which then emits FLAT loads/stores
@@ -603,6 +606,7 @@ struct Ctx {
     GF4 ybuf; gv2u* surv;
     gv2u* jT4; gv2u* ent; gu64* xch;
     size_t fbase;
+    TraceRow* trace; int* trace_len; int trace_cap;                 // optional per-iteration trace (PairDesc)
 };
 __device__ __forceinline__ void pair_rows(int nf, int g, int G, int& rows_per, int& nrows) {
     const int nblocks = (nf + ROW_DEAL - 1) / ROW_DEAL;
@@ -610,7 +614,7 @@ __device__ __forceinline__ void pair_rows(int nf, int g, int G, int& rows_per, i
     const int mine = (g < nblocks) ? (nblocks - g + G - 1) / G : 0; // blocks g, g + G, g + 2G, ...; only the cloud's last block may be short
     nrows = mine * ROW_DEAL - ((mine > 0 && (nblocks - 1) % G == g) ? nblocks * ROW_DEAL - nf : 0);
 }
-__device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
+__device__ __forceinline__ Ctx build_ctx(const PairDesc* Dp, int g, int G) {
     const PairDesc& D = *Dp;
     Ctx c;
     c.g = g; c.G = G;
@@ -641,8 +645,18 @@ __device__ __forceinline__ Ctx make_ctx(const PairDesc* Dp, int g, int G) {
     c.xch = (gu64*)D.xch;
     c.fbase = off_recs * D.capf;
     c.flat_cap = c.rows_per * D.capf;
+    c.trace = D.trace; c.trace_len = D.trace_len; c.trace_cap = D.trace_cap;
     return c;
 }
+
+static_assert(sizeof(Ctx) <= sizeof(((Shared*)nullptr)->ctx_store), "Shared::ctx_store holds a Ctx");
+// one thread, after Shared::ctx_rows_per / ctx_nrows / ws_slot are set for the pair (or changed); a workgroup barrier follows at the call sites
+__device__ __forceinline__ void store_ctx(const PairDesc* Dp, int g, int G) {
+    Shared* shc = reinterpret_cast<Shared*>(cvo_smem);
+    const Ctx c = build_ctx(Dp, g, G);
+    *reinterpret_cast<Ctx*>(shc->ctx_store) = c;
+}
+__device__ __forceinline__ Ctx make_ctx(const PairDesc*, int, int) { return *reinterpret_cast<const Ctx*>(reinterpret_cast<const Shared*>(cvo_smem)->ctx_store); }
 
 // fixed-cloud row of a workgroup's local row
 __device__ __forceinline__ int global_row(const Ctx& c, int li) { return (c.g + c.G * (li / ROW_DEAL)) * ROW_DEAL + (li % ROW_DEAL); }
@@ -1580,13 +1594,12 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
             (void)__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e, ((unsigned long long)(sh->launch_tag | ADOPT_FREE) << 32) | (unsigned)(k + 1),
                                                        __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const PairDesc& D = *Dp;
-        if (g == 0 && D.trace && k < D.trace_cap) {
-            TraceRow& tr = D.trace[k];
+        if (g == 0 && c.trace && k < c.trace_cap) {
+            TraceRow& tr = c.trace[k];
             for (int q = 0; q < 3; ++q) { tr.omega[q] = omega[q]; tr.v[q] = v[q]; }
             tr.nnz = sh->nnz; tr.candidates = sh->cand; tr.B = B; tr.C = C; tr.D = Dd; tr.E = E;
             tr.step = step; tr.ell = ell; tr.dist = dist; tr.pad_ = 0;
-            *D.trace_len = k + 1;
+            *c.trace_len = k + 1;
         }
     }
     __syncthreads();
@@ -1961,6 +1974,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             const PairState* st = st_from;
             int rp, nr; pair_rows(nf, ge, Ge, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
             sh->ws_slot = k_join ? p : slot;                          // (one slot per pair when workgroups help each other)
+            store_ctx(Dp, ge, Ge);
             sh->adopt_req = 0; sh->adopt_word = nullptr; sh->joined_at = 0;
             if (adopt_launch && !k_join) {                            // this pair may be helped: its word says so from now on
                 __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_FREE) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2064,6 +2078,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                     sh->adopt_req = g_next;
                     if (g_next != Ge) {
                         int rp, nr; pair_rows(nf, ge, g_next, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
+                        store_ctx(Dp, ge, g_next);
                         sh->list_valid = 0; sh->rebuild = 1; sh->dense_mode = 0;
                     }
                 }

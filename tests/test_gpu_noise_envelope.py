@@ -20,6 +20,7 @@ def test_hip_result_lies_inside_the_reference_noise_envelope(hiplib, oracle):
         env = json.load(f)
     cases = [("small", row, synth.make_small_pair(row["pair"], n=600)) for row in env["small"]["per_pair"]]
     cases += [("tum64", row, synth.make_pair(row["pair"])) for row in env["tum64"]["per_pair"][:12]]
+    cases += [("eth3d64", row, synth.make_pair(row["pair"], cam=synth.ETH3D)) for row in env["eth3d64"]["per_pair"][:3]]      # BASELINE config 5 shape
     B = ca.CvoBatch(len(cases), device=0)
     for i, (_, _, p) in enumerate(cases):
         B.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
