@@ -133,3 +133,28 @@ def test_batch_score_block_with_cached_self_products(hiplib):
             assert a["cos_angle"] == b["cos_angle"] and a["inliers"] == b["inliers"]
             np.testing.assert_array_equal(a["post_hessian"], b["post_hessian"])
     B.close()
+
+
+def test_done_polls_without_blocking_and_the_record_table_is_on_the_device(hiplib):
+    """cvo_batch_done (a caller with several batches in flight reuses whichever finished) and cvo_batch_result_records (the 64-byte
+    records the align kernel writes, where a launcher's own collective can pick them up)."""
+    import time
+    import torch
+    from cvo_slam_amd import shard, synth
+    pairs = [synth.make_pair(i) for i in range(8)]
+    b = hiplib.CvoBatch(len(pairs)); b.set_workgroups(1)
+    assert b.done()                                                   # nothing launched yet
+    b.set_pairs([(p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat) for p in pairs])
+    b.align_async(len(pairs))
+    polls = 0
+    t0 = time.perf_counter()
+    while not b.done():
+        polls += 1
+        assert time.perf_counter() - t0 < 10.0
+    res = b.wait(len(pairs))
+    assert polls > 0 and b.done()                                     # full-size pairs take milliseconds: the first poll came back before they were done
+    rec = shard.device_view(b.result_records(), len(pairs)).cpu().numpy()
+    for i, r in enumerate(res):
+        np.testing.assert_array_equal(rec[i, :12].reshape(3, 4), r["transform"])
+        assert (int(rec[i, 12]), int(rec[i, 13]), int(rec[i, 14]), int(rec[i, 15])) == (r["iter"], r["A_nonzero"], r["iterations_run"], r["status"])
+    b.close()
