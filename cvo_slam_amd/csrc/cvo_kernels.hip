@@ -44,6 +44,13 @@
 
 namespace cvohip {
 
+// phase timers (PairState::phase_ticks): a read of the 100 MHz clock is a scalar memory instruction every wave waits for
+#ifdef CVO_NO_TIMERS
+#define CVO_NOW() 0ull
+#else
+#define CVO_NOW() __builtin_amdgcn_s_memrealtime()
+#endif
+
 #ifndef CVO_WAVES_PER_SIMD
 #define CVO_WAVES_PER_SIMD 2      // 2: 256 VGPRs, one 512-thread workgroup per CU (measured faster); 4: 128 VGPRs, two per CU
 #endif
@@ -1361,12 +1368,12 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
     const Ctx c = make_ctx(Dp, g, G);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
-    const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ts0 = CVO_NOW();
     const Gates gates = make_gates(sh->ell, sh->P);
     const bool dense_mode = sh->dense_mode != 0, fresh_list = sh->rebuild == 1;
     const float inv_c = 1 / sh->P.c, inv_d = 1 / sh->P.d;
     double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // omega[3], v[3], nnz, candidates
-    const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ts1 = CVO_NOW();
     if (!dense_mode) {
 #define CVO_CAND(fn, flat) do { if (y_lds == 1) fn<1, flat>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8); \
                                 else if (y_lds == 2) fn<2, flat>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8); \
@@ -1401,10 +1408,10 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
             acc8[7] += (double)(y_lds == 2 ? c.nm : (int)L.rowlen[li]);   // statistics only (in the plane layout the row lengths have been overwritten by now)
         }
     }
-    const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ts2 = CVO_NOW();
     // (no barrier before the reduction: its own barrier is the one every wave reaches after its walk)
     const double mine = dense_mode ? block_reduce<8, 8, false>(acc8, sh, tid, nwaves) : block_reduce<8, 6, false>(acc8, sh, tid, nwaves);   // list mode: nnz and candidates are per-wave counts in lane 0
-    const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ts3 = CVO_NOW();
     if (G > 1) {
         if (tid < 64) { if (!group_exchange<8>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 1u), lane)) sh->status = 6; }   // wave 0: reads the totals its own lanes wrote
         __builtin_amdgcn_wave_barrier();
@@ -1419,7 +1426,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
         else if (tid == 7) sh->cand = (int)mine;
     }
     if (tid == 0) {
-        const unsigned long long ts4 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long ts4 = CVO_NOW();
         sh->sub[0] += ts1 - ts0; sh->sub[1] += ts2 - ts1; sh->sub[2] += ts3 - ts2; sh->sub[3] += ts4 - ts3;
     }
     __syncthreads();
@@ -1442,7 +1449,7 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
     }
     double acc4[4] = {0, 0, 0, 0};
 #ifdef CVO_KTRACE
-    const unsigned long long kt0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long kt0 = CVO_NOW();
 #endif
     if (!sh->dense_mode) {
         // every wave walks the nonzeros it compacted itself: the candidate phase deals the rows so that the waves' shares are
@@ -1522,14 +1529,14 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
         }
     }
 #ifdef CVO_KTRACE
-    const unsigned long long kt1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long kt1 = CVO_NOW();
 #endif
     // no barrier before the reduction (its own is the one every wave reaches after its walk: the epilogue's transform may overwrite the
     // resident cloud only behind it) and none after it: the totals are read by thread 0 of wave 0 alone (exchange, epilogue), whose
     // own lanes wrote them; the next workgroup barrier is the epilogue's
     block_reduce<4, 4, false>(acc4, sh, tid, nwaves);
 #ifdef CVO_KTRACE
-    if (tid == 0) { sh->ksub[0] = kt1 - kt0; sh->ksub[1] = __builtin_amdgcn_s_memrealtime() - kt1; }
+    if (tid == 0) { sh->ksub[0] = kt1 - kt0; sh->ksub[1] = CVO_NOW() - kt1; }
 #endif
     if (G > 1) {
         if (tid < 64) { if (!group_exchange<4>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 2u), lane)) sh->status = 6; }
@@ -1550,7 +1557,7 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         for (int u = 0; u < PRE_T; ++u) { pre[u] = (j < c.nm) ? ld4(c.moving + lo_off(j)) : make_float4(0.f, 0.f, 0.f, 0.f); j += blockDim.x; }
     }
 #ifdef CVO_KTRACE
-    const unsigned long long ke0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ke0 = CVO_NOW();
 #endif
     if (threadIdx.x == 0) {
         const DevParams& P = sh->P;
@@ -1604,13 +1611,13 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
     }
     __syncthreads();
 #ifdef CVO_KTRACE
-    const unsigned long long ke1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ke1 = CVO_NOW();
 #endif
     if (!sh->stop && k + 1 < max_iter) {                             // T of iteration k+1 (cvo.cpp:770-771)
         if (y_lds == 1) transform_body_t<1>(c, L, sh, pre, true); else transform_large(Dp, g, G, tgeo, y_lds);
     }
 #ifdef CVO_KTRACE
-    if (threadIdx.x == 0) { sh->ksub[2] = ke1 - ke0; sh->ksub[3] = __builtin_amdgcn_s_memrealtime() - ke1; }
+    if (threadIdx.x == 0) { sh->ksub[2] = ke1 - ke0; sh->ksub[3] = CVO_NOW() - ke1; }
 #endif
 }
 
@@ -1996,23 +2003,23 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
         int k = (int)k_join;
         // phase timers and counters live in LDS, bumped by thread 0 with fire-and-forget ds_add: as registers of this function they were
         // saved and restored around every phase call (the phases are out of line), ~1 us of lane moves per iteration
-        unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+        unsigned long long t_prev = CVO_NOW();
 #ifdef CVO_KTRACE
         unsigned long long kt_prev[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ksub_prev[4] = {0, 0, 0, 0};
 #endif
         const unsigned long long clk_t0 = t_prev, clk_c0 = __builtin_amdgcn_s_memtime();
-#define CVO_PHASE(idx) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); if (tid == 0) atomicAdd(&sh->ticks[idx], t_now - t_prev); t_prev = t_now; } while (0)
+#define CVO_PHASE(idx) do { const unsigned long long t_now = CVO_NOW(); if (tid == 0) atomicAdd(&sh->ticks[idx], t_now - t_prev); t_prev = t_now; } while (0)
         const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
         if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
 
         if (ok_pair && k < P.max_iter) phase_transform(Dp, ge, Ge, tgeo, y_lds);   // later iterations: done by the epilogue before them
         for (; ok_pair && k < P.max_iter; ++k) {
             if (sh->rebuild == 1) {
-                const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
+                const unsigned long long t_a = CVO_NOW();
                 phase_cull(Dp, ge, Ge, tgeo, y_lds);
-                const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
+                const unsigned long long t_b = CVO_NOW();
                 phase_sort(Dp, ge, Ge, tgeo, y_lds);
-                if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], __builtin_amdgcn_s_memrealtime() - t_b); }
+                if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], CVO_NOW() - t_b); }
             } else if (sh->rebuild == 2) {
                 phase_refine(Dp, ge, Ge, tgeo, y_lds, k);
             }
