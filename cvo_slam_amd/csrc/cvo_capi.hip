@@ -353,10 +353,10 @@ struct Engine {
             stage_used = 0;
         }
         if (stage_used + bytes > h_stage.bytes) { rc = drain_ring(); if (rc) return rc; stage_used = 0; }
-        if (upload_copy && d_raw.bytes < bytes) { HIP_TRY(hipStreamSynchronize(stream)); rc = d_raw.ensure(bytes); if (rc) return rc; }   // an earlier pack kernel may still read it
+        if (!defer_pack && upload_copy && d_raw.bytes < bytes) { HIP_TRY(hipStreamSynchronize(stream)); rc = d_raw.ensure(bytes); if (rc) return rc; }   // an earlier pack kernel may still read it
         unsigned char* blk = static_cast<unsigned char*>(h_stage.p) + stage_used;
         stage_used += (bytes + 255) & ~(size_t)255;
-        PackDesc* pd = reinterpret_cast<PackDesc*>(blk);
+        PackDesc* pd = reinterpret_cast<PackDesc*>(blk);             // (read by the pack kernel of the single-object path below; a batch's table is made by flush_pending)
         float* raw = reinterpret_cast<float*>(blk + desc_bytes);
         struct Piece { const float* src; float* dst; size_t bytes; };
         std::vector<Piece> pieces; pieces.reserve(2 * (size_t)live);
