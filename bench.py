@@ -255,6 +255,8 @@ def main():
     base, rem = divmod(total_pairs, world)
     first_pair, n_mine = rank * base + min(rank, rem), base + (1 if rank < rem else 0)
     n_block = (total_pairs + world - 1) // world
+    first_shard = first_pair
+    first_pair += int(os.environ.get("CVO_BENCH_PAIR_OFFSET", "0"))      # experiments: another set of synthetic pairs (the metric's set starts at 0)
     # host-side input generation first (forks; no GPU state yet)
     pairs = generate_pairs(first_pair, n_mine, args.gen_workers) if n_mine else []
     if rank == 0:
@@ -297,7 +299,7 @@ def main():
 
     from cvo_slam_amd import shard, api
     n = n_mine
-    assert list(api.shard_range(total_pairs, rank, world)) == list(range(first_pair, first_pair + n)) and api.shard_block(total_pairs, world) == n_block   # cvo_shard_range: contiguous blocks
+    assert list(api.shard_range(total_pairs, rank, world)) == list(range(first_shard, first_shard + n)) and api.shard_block(total_pairs, world) == n_block   # cvo_shard_range: contiguous blocks
     recvs = [torch.zeros((world * n_block, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda") for _ in range(depth)] if world > 1 else []
     gathered = None
     inflight = []                                  # batch objects with a launch not yet waited for

@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
     "cvo_batch_set_pairs", "cvo_batch_result_records", "cvo_shard_block", "cvo_batch_gather_results_padded", "cvo_batch_padded_records",
-    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers",
+    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds",
 ]
 
 _lib = None
@@ -199,6 +199,7 @@ def load_library():
     L.cvo_batch_done.argtypes = [vp, ip]
     L.cvo_batch_set_tail_scores.argtypes = [vp, C.c_int]
     L.cvo_batch_last_tail_answers.argtypes = [vp, C.c_int, ip]
+    L.cvo_batch_last_pair_seconds.argtypes = [vp, C.c_int, dp]
     _lib = L
     return L
 
@@ -655,6 +656,9 @@ class CvoBatch:
     def set_tail_scores(self, on: bool):
         """the tracker's score block answered by the align launch itself (cvo_hip.h: cvo_batch_set_tail_scores)"""
         _check(self.L.cvo_batch_set_tail_scores(self.h, int(bool(on))))
+
+    def last_pair_seconds(self, n: int):
+        out = np.zeros(n); _check(self.L.cvo_batch_last_pair_seconds(self.h, n, out.ctypes.data_as(C.POINTER(C.c_double)))); return out
 
     def last_tail_answers(self, n: int):
         m = (C.c_int * n)()

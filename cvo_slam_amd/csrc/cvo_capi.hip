@@ -126,6 +126,7 @@ struct Cloud {
     // a hand-over the device has not packed yet: the cloud's arrays as they came (n x 3 positions, then 5 channel-major feature arrays) in
     // the engine's pinned staging ring; the next align launch packs them itself, any other consumer runs the pack kernel first
     mutable const float* raw = nullptr;
+    float cost_hint = 0.f;          // mean 1/z^2 of a sample of the points (0 = unknown): what a pair costs per iteration follows the density of its clouds
     float* rec() const { return static_cast<float*>(buf.p); }
     ~Cloud() { buf.release(); px.release(); boxes.release(); }
 };
@@ -265,6 +266,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_SELF_CACHE")) self_cache_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_UPLOAD_COPY")) upload_copy = std::atoi(e) != 0;
+        if (const char* e = std::getenv("CVO_HIP_ORDER_PAIRS")) { order_mode = std::atoi(e); order_pairs = order_mode != 0; }
         if (const char* e = std::getenv("CVO_HIP_INKERNEL_PACK")) inkernel_pack = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_UPLOAD_THREADS")) upload_threads = std::max(1, std::min(16, std::atoi(e)));
         upload_threads = std::max(1, std::min(upload_threads, (int)std::thread::hardware_concurrency()));
@@ -294,6 +296,8 @@ struct Engine {
     int upload_threads = 4;
     bool upload_copy = true;
     bool defer_pack = false;          // batches (cvo_batch_create)
+    bool order_pairs = true;          // CVO_HIP_ORDER_PAIRS=0: positions take the pairs in index order
+    int order_mode = 1;
     bool inkernel_pack = true;        // CVO_HIP_INKERNEL_PACK=0: deferred clouds always go through the pack kernel
     std::vector<Cloud*> pending;      // clouds with a hand-over not packed yet (Cloud::raw)
     PinBuf h_packdesc, h_rawtab;
@@ -338,8 +342,13 @@ struct Engine {
         }
         for (int k = 0; k < count; ++k) {
             Cloud& c = *it[k].c;
-            c.n = it[k].n; c.boxes_valid = false;
+            c.n = it[k].n; c.boxes_valid = false; c.cost_hint = 0.f;
             if (c.n > 0) { int rc = c.buf.ensure((size_t)c.n * REC * sizeof(float)); if (rc) return rc; }
+            if (c.n > 0) {                                          // every 16th point: enough to rank the pairs of a batch (launch_impl)
+                double acc = 0; int m = 0;
+                for (int i = 0; i < c.n; i += 16) { const float z = it[k].xyz[(size_t)i * 3 + 2]; if (z > 1e-3f) { acc += 1.0 / ((double)z * z); ++m; } }
+                c.cost_hint = m ? (float)(acc / m) : 0.f;
+            }
         }
         uploads_pending = true;
         if (live == 0) return CVO_OK;
@@ -655,6 +664,38 @@ struct Engine {
         std::vector<PairDesc> hdv(n);
         std::memset(hdv.data(), 0, sizeof(PairDesc) * n);            // padding bytes take part in the comparison below
         PairDesc* hd = hdv.data();
+        // Which pair a position of the launch (a slot; a pull from the pair queue) works on.  A pair's time is its cost per iteration -- which
+        // follows the number of neighbours, i.e. the density of its clouds: mean 1/z^2 explains 0.9 of it on the bench's pairs, the iteration
+        // count next to nothing -- so the pairs are ranked by that (Cloud::cost_hint, a sample of the points taken at the hand-over), and
+        //  * a launch with a slot per pair gives the positions b, b + 8, b + 16, ... -- workgroups that share an XCD and its 4 MiB L2 (blocks are
+        //    dealt round-robin over the 8 XCDs; which XCD block 0 gets changes from launch to launch) -- pairs of SIMILAR density: the c-th
+        //    eighth of the ranking goes to the positions = c (mod 8).  The lists and nonzero records of a dense pair stream through L2 every
+        //    iteration (2-3 MB), those of a sparse pair or of a late iteration fit into a CU's share of it (100-200 KB): mixed evenly, the
+        //    streams evict everybody's lists in every XCD.  Measured on four sets of 64 pairs, default run: +5.3 ... +6.4 % over index order,
+        //    while the evenly mixed orders (densest first, eight heavy / eight light) lose 2 ... 13 % (profiles/r03_pair_order_*.txt);
+        //  * a launch with fewer slots than pairs hands them out densest first: the long pairs start first and the launch's last ones are
+        //    short (+5 ... 13 % on the config-5 shape, 64 pairs on 10 slots).
+        // Results stay indexed by pair.  CVO_HIP_ORDER_PAIRS: 0 index order, 1 this rule (default); 2 ... experiment orders (below).
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        if (order_pairs && n > 1) {
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                const float ca = (pairs[a].fixed ? pairs[a].fixed->cost_hint : 0.f) + (pairs[a].moving ? pairs[a].moving->cost_hint : 0.f);
+                const float cb = (pairs[b].fixed ? pairs[b].fixed->cost_hint : 0.f) + (pairs[b].moving ? pairs[b].moving->cost_hint : 0.f);
+                return ca > cb; });
+            const bool queue_launch = slots < n;
+            const int mode = order_mode == 1 ? (queue_launch ? 2 : 5) : order_mode;      // 2 densest first, 5 eighths of the ranking per XCD class
+            if (mode == 3) std::reverse(order.begin(), order.end());                      // lightest first
+            if (mode == 4) { std::vector<int> o2; for (int i = 0, j = n - 1; i <= j; ++i, --j) { o2.push_back(order[i]); if (i != j) o2.push_back(order[j]); } order = o2; }   // heavy, light, heavy, ...
+            if (mode == 5) {                                                               // position p <- chunk p % 8 of the ranking, its (p / 8)-th pair
+                std::vector<int> first(9, 0), o2(n);
+                for (int c = 0; c < 8; ++c) first[c + 1] = first[c] + n / 8 + (c < n % 8 ? 1 : 0);
+                for (int p = 0; p < n; ++p) o2[p] = order[first[p % 8] + p / 8];
+                order = o2;
+            }
+            if (mode == 6) { std::vector<int> o2; const int nb8 = (n + 7) / 8; for (int i = 0, j = nb8 - 1; i <= j; ++i, --j) { for (int q = 8 * i; q < std::min(n, 8 * i + 8); ++q) o2.push_back(order[q]); if (i != j) for (int q = 8 * j; q < std::min(n, 8 * j + 8); ++q) o2.push_back(order[q]); } order = o2; }   // eight heavy, eight light, ...
+            if (mode >= 7) { unsigned st = 12345u * (unsigned)mode; for (int i = n - 1; i > 0; --i) { st = st * 1664525u + 1013904223u; std::swap(order[i], order[(st >> 8) % (unsigned)(i + 1)]); } }   // shuffles
+        }
         for (int i = 0; i < n; ++i) {
             PairDesc& D = hd[i];
             D.fixed = pairs[i].fixed ? pairs[i].fixed->rec() : nullptr;
@@ -676,6 +717,7 @@ struct Engine {
             D.trace_cap = want_trace ? trace_cap : 0;
             D.trace_len = want_trace ? static_cast<int*>(d_tracelen.p) : nullptr;
             D.member_regions = ac ? 1 : 0;
+            D.run_pair = order[i];
             D.record = static_cast<float*>(d_records.p) + (size_t)i * CVO_RESULT_FLOATS;
             if (tails) {
                 D.score_out = static_cast<double*>(h_tail.p) + (size_t)i * 5 * 24;
@@ -1553,6 +1595,12 @@ int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_t
     for (int i = 0; i < b->last_n; ++i) { it += r[i].iterations_run; ca += r[i].candidates_total; }
     if (iterations_total) *iterations_total = it;
     if (candidates_total) *candidates_total = ca;
+    return CVO_OK;
+}
+int cvo_batch_last_pair_seconds(cvo_batch b, int n, double* seconds) {
+    if (!b || !seconds || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad argument");
+    const PairState* r = b->eng.results();
+    for (int i = 0; i < n; ++i) seconds[i] = 1e-8 * (double)r[i].clk_ticks;      // 100 MHz ticks workgroup 0 spent on the pair
     return CVO_OK;
 }
 int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]) {

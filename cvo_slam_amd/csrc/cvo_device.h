@@ -93,6 +93,9 @@ struct PairDesc {
     double* score_out;
     const struct SelfCacheEntry* self_fixed;    // the clouds' tables of cached self inner products (ScoreDesc::self_cache)
     const struct SelfCacheEntry* self_moving;
+    int run_pair;            // NOT a property of this pair: the pair the launch's position `index of this descriptor` works on (slot s of a launch with a slot per
+                             // pair, the s-th pull from the pair queue otherwise).  The host ranks the pairs by the density of their clouds and deals them so
+                             // that workgroups sharing an XCD's L2 run pairs of similar density (Engine::launch_impl)
     float* record;           // this pair's 64-byte result record {transform[12], iter, A_nonzero, iterations_run, status as floats}: written by the kernel's
                              // final block, so the cross-GPU gather (or a caller that wants the records on the device) needs no pack kernel behind the launch
     int member_regions;      // adoption launches: member g of a pair keeps its lists and records in a region of its own (sized for the rows it owns

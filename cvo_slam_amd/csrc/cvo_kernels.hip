@@ -1947,6 +1947,9 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             __syncthreads();
             if (p >= n_pairs) break;
         }
+        // `p` so far is a position of the launch (a slot, or a pull from the queue): the pair it stands for is the host's choice (densest clouds first)
+        const int ps = p;
+        p = descs[ps].run_pair;
         const PairDesc* Dp = descs + p;
         const int nf = Dp->nf, nm = Dp->nm;
         if (raw_table && !k_join) {
@@ -1980,7 +1983,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
         if (tid == 32) {
             const PairState* st = st_from;
             int rp, nr; pair_rows(nf, ge, Ge, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
-            sh->ws_slot = k_join ? p : slot;                          // (one slot per pair when workgroups help each other)
+            sh->ws_slot = k_join ? ps : slot;                         // (one slot per pair when workgroups help each other)
             store_ctx(Dp, ge, Ge);
             sh->adopt_req = 0; sh->adopt_word = nullptr; sh->joined_at = 0;
             if (adopt_launch && !k_join) {                            // this pair may be helped: its word says so from now on
@@ -1998,7 +2001,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
         // a helper has read what the owner published for it: if the pair may grow further, its word takes offers again (not earlier --
         // the owner publishes the next newcomer's state in the same place)
         if (k_join && Ge < ADOPT_GMAX && tid == 0)
-            __hip_atomic_store(&queue[1 + p], ((unsigned long long)(launch_tag | ADOPT_FREE) << 32) | k_join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&queue[1 + ps], ((unsigned long long)(launch_tag | ADOPT_FREE) << 32) | k_join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         int k = (int)k_join;
         // phase timers and counters live in LDS, bumped by thread 0 with fire-and-forget ds_add: as registers of this function they were

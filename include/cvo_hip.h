@@ -268,6 +268,8 @@ int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_t
  * for the slowest wave)   [3] line-search phase   [4] candidates: exchange between the pair's workgroups   [5] scalar epilogue
  * [6] inside [0]: dense culls   [7] candidates: prologue   [8] inside [0]: row sorts   [9] candidates: the row walk */
 int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]);
+/* seconds the first workgroup of each pair of the last launch spent on it (diagnostics: alignments take 33 ... 150 iterations of very different cost) */
+int cvo_batch_last_pair_seconds(cvo_batch b, int n, double* seconds);
 /* The last launch's results as records of CVO_RESULT_FLOATS floats {transform[12], iter, A_nonzero, iterations_run, status}: the
  * payload of the cross-GPU RCCL gather.  The align kernel writes them itself when a pair ends (no pack kernel behind the
  * launch): cvo_batch_result_records hands out the DEVICE address of the record table (valid once the launch's stream has drained; it
