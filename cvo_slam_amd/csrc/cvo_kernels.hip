@@ -146,6 +146,29 @@ typedef CVO_GLOBAL uint32_t gu32;
 typedef CVO_GLOBAL int gint;
 typedef CVO_GLOBAL unsigned long long gu64;
 __device__ __forceinline__ float4 ld4(const gfloat* p) { const v4f t = *reinterpret_cast<const gv4f*>(p); return make_float4(t.x, t.y, t.z, t.w); }
+// Cache policy of the two big per-iteration streams: list entries read in the steady candidate walk, nonzero records written there and read back by
+// the line search.  The entries of a resident-cloud (3 k-point) launch are read non-temporally: a dense pair's list is 2 MB per iteration, it never
+// survives in the XCD's 4 MiB L2 until the next iteration, and marked as a stream it no longer evicts what the XCD's other pairs re-read (+2 %,
+// profiles/r03_cache_policy_ab.txt; the same for the records loses 4 %, and 9 k-point launches gain nothing: kept plain, -DCVO_NT_REC for the record).
+template <bool NT>
+__device__ __forceinline__ v2u ld_ent(const gv2u* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+__device__ __forceinline__ void st_rec(gv2u* p, const v2u v) {
+#ifdef CVO_NT_REC
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ v2u ld_rec(const gv2u* p) {
+#ifdef CVO_NT_REC
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 
 // ---------------------------------------------------------------- reductions
 // butterfly inside the wave (every lane ends with the wave total), one LDS slot
@@ -1066,7 +1089,7 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
     if (a > 0.f) {
         const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         v2u rec; rec.x = __float_as_uint(a); rec.y = tag;             // 8 bytes per nonzero: the line search finds x_i, y_j in LDS
-        sp[(unsigned)wcount + below] = rec;                           // scalar base + 32-bit lane offset
+        st_rec(&sp[(unsigned)wcount + below], rec);                   // scalar base + 32-bit lane offset
     }
     wcount += __popcll(mask);
 }
@@ -1084,7 +1107,7 @@ __device__ __forceinline__ void fold_entry_e(const float* xi, const float4 y4, c
     if (a > 0.f) {
         const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         v2u rec; rec.x = __float_as_uint(a); rec.y = tag;
-        sp[(unsigned)wcount + below] = rec;
+        st_rec(&sp[(unsigned)wcount + below], rec);
     }
     wcount += __popcll(mask);
 }
@@ -1104,7 +1127,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
     if (nb > 0) {
         const gv2u* eb0 = uni_ptr(c.ent + wave_block(0, wave, nwaves) * 64);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) ehead[u] = eb0[(unsigned)lane + (unsigned)u * rp];
+        for (int u = 0; u < PF; ++u) ehead[u] = ld_ent<YM == 1>(&eb0[(unsigned)lane + (unsigned)u * rp]);
     }
     for (int bi = 0; bi < nb; ++bi) {
         const int blk = wave_block(bi, wave, nwaves);
@@ -1122,13 +1145,13 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         if (bi + 1 < nb) {
             const gv2u* eb1 = uni_ptr(c.ent + wave_block(bi + 1, wave, nwaves) * 64);
 #pragma unroll
-            for (int u = 0; u < PF; ++u) ehead[u] = eb1[(unsigned)lane + (unsigned)u * rp];
+            for (int u = 0; u < PF; ++u) ehead[u] = ld_ent<YM == 1>(&eb1[(unsigned)lane + (unsigned)u * rp]);
         }
         for (int n0 = 0; n0 < lw; n0 += PF) {
             if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
             v2u en[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) en[u] = eb[eo + (unsigned)u * rp];
+            for (int u = 0; u < PF; ++u) en[u] = ld_ent<YM == 1>(&eb[eo + (unsigned)u * rp]);
             float av[PF], ckv[PF]; float4 yv4[PF]; bool actv[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -1483,13 +1506,13 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
             if (cnt_w <= 0) return;
             v2u ring[RD];
 #pragma unroll
-            for (int u = 0; u < RD; ++u) ring[u] = sp[min(lane + 64 * u, cnt_w - 1)];
+            for (int u = 0; u < RD; ++u) ring[u] = ld_rec(&sp[min(lane + 64 * u, cnt_w - 1)]);
             for (int q0 = lane; q0 < cnt_w; q0 += 64 * RD) {
 #pragma unroll
                 for (int u = 0; u < RD; ++u) {
                     const int q = q0 + 64 * u;
                     const v2u rec = ring[u];
-                    ring[u] = sp[min(q + 64 * RD, cnt_w - 1)];
+                    ring[u] = ld_rec(&sp[min(q + 64 * RD, cnt_w - 1)]);
                     if (q < cnt_w) {
                         const int slot = (int)(rec.y >> 16), j = (int)(rec.y & 0xFFFFu);
                         float xi[3]; load_x(c, L, x_lds, slot, xi);
