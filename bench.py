@@ -233,11 +233,11 @@ def main():
     ap.add_argument("--total-pairs", type=int, default=0, help="pairs per step over ALL ranks, dealt in contiguous blocks (cvo_shard_range: blocks may differ by one, the gather pads); 0 = --pairs per rank")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
     args = ap.parse_args()
-    if args.shape == "eth3d":      # BASELINE config 5 defaults: 4 workgroups per pair, 6 launches side by side, 40 workgroups (10 pair slots) each
+    if args.shape == "eth3d":      # BASELINE config 5 defaults: 4 workgroups per pair, 4 launches side by side, 64 workgroups (16 pair slots) each
         dflt = ap.parse_args([])
         if args.workgroups == dflt.workgroups: args.workgroups = 4
-        if args.streams == dflt.streams: args.streams = 6
-        if args.max_workgroups == dflt.max_workgroups: args.max_workgroups = 40
+        if args.streams == dflt.streams: args.streams = 4
+        if args.max_workgroups == dflt.max_workgroups: args.max_workgroups = 64
         if args.steps == dflt.steps: args.steps = 24
         if args.warmup == dflt.warmup: args.warmup = 4
 

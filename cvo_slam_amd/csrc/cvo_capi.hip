@@ -138,6 +138,7 @@ DevParams to_dev(const cvo_params& p) {
     d.skin = 0.25f;
     d.resort = 1;
     d.adopt_kmax = 20;
+    d.colocate = 1;
     return d;
 }
 
@@ -260,6 +261,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_WGS_PER_CU")) per_cu = std::max(1, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_SKIN")) P.skin = (float)std::atof(e);
         if (const char* e = std::getenv("CVO_HIP_RESORT")) P.resort = std::max(0, std::min(2, std::atoi(e)));
+        if (const char* e = std::getenv("CVO_HIP_COLOCATE")) P.colocate = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_ADOPT_KMAX")) P.adopt_kmax = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("CVO_HIP_ADOPT")) adopt = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
@@ -1440,7 +1442,7 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
     A.trace = want_trace ? static_cast<AdaptiveRow*>(d_trace.p) : nullptr; A.trace_cap = want_trace ? trace_cap : 0; A.trace_len = static_cast<int*>(d_len.p);
     A.ell_min = ap.ell_min; A.dl_step = ap.dl_step;
     A.P.sigma = ap.sigma; A.P.sp_thres = ap.sp_thres; A.P.c = ap.c; A.P.d = ap.d; A.P.c_ell = ap.c_ell; A.P.c_sigma = ap.c_sigma;
-    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0;
+    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.colocate = 0;
     A.partials = static_cast<double*>(d_part.p);
     // a few iterations are queued at a time (five small kernels each, the rows of the sweeps spread over the device); kernels queued behind a
     // stop return at once, and the host looks at the stop flag between the chunks

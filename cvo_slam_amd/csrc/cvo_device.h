@@ -20,6 +20,8 @@ struct DevParams {           // cvo.cpp:35-51
     int max_iter;
     float skin;              // candidate lists are built with radius (1+skin)*r and reused until the cloud has moved skin*r
     int resort;              // rows re-sorted after a list refinement: 0 never, 1 when the cost model says it pays (default), 2 always (tests)
+    int colocate;            // the workgroups of a pair on ONE XCD (blocks b, b + 8, ... share one): they read the same moving cloud and swap partial sums through
+                             // L2 twice per iteration.  Takes a launch whose pair slots are a multiple of 8; 0 = consecutive blocks (four XCDs for G = 4)
     int adopt_kmax;          // adoption: a finished workgroup only offers its help to pairs with fewer iterations than this behind them (the heavy
                              // early iterations divide well between workgroups; the light late ones are bound by the iteration's fixed latency)
 };

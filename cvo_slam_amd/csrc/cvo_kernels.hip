@@ -1872,7 +1872,12 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                                                                          const float* const* __restrict__ raw_table /* pinned host memory, or null */) {
     Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
     const int tid = threadIdx.x;
-    const int slots = gridDim.x / G, slot = blockIdx.x / G, g = blockIdx.x % G;
+    const int slots = gridDim.x / G;
+    int slot = blockIdx.x / G, g = blockIdx.x % G;
+    if (P.colocate && G > 1 && (slots & 7) == 0) {                  // members of a slot at blocks congruent mod 8: one XCD, one L2 (DevParams::colocate)
+        const int t = blockIdx.x >> 3;
+        g = t % G; slot = (blockIdx.x & 7) + 8 * (t / G);
+    }
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
     if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
     const bool adopting = wgs_started != nullptr;                   // set by the host for launches of one workgroup and one slot per pair

@@ -1,7 +1,8 @@
 """BASELINE config 5 AS BENCHMARKED (`bench.py --shape eth3d`): 64 ETH3D-shape 736x456 pairs (~9.3 k points per cloud), four
-workgroups per pair, launches capped to 40 workgroups (10 pair slots: the pairs are handed out by the in-kernel queue), six
-batch objects in flight side by side -- and EVERY launch's 64 results compared with the oracle (KD-tree search, host threads):
-pose within the north-star tolerance, iteration count and nnz of the last iteration equal."""
+workgroups per pair (on one XCD), launches capped to 64 workgroups (16 pair slots: the pairs are handed out by the in-kernel queue,
+densest clouds first), four batch objects in flight side by side -- and EVERY launch's 64 results compared with the oracle (KD-tree
+search, host threads): pose within the north-star tolerance, iteration count and nnz of the last iteration equal.  A second geometry
+(40 workgroups = 10 slots, not a multiple of 8: members on consecutive blocks; six objects) runs one round."""
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -11,7 +12,8 @@ from helpers import rot_trans_err
 
 pytestmark = pytest.mark.gpu
 
-N_PAIRS, DEPTH, ROUNDS = 64, 6, 2
+N_PAIRS = 64
+GEOMETRIES = ((64, 4, 2), (40, 6, 1))          # (workgroups per launch, objects in flight, rounds): bench.py's defaults first
 
 
 def _oracle_result(args):
@@ -33,24 +35,25 @@ def test_config5_as_benchmarked_every_concurrent_launch_matches_the_oracle(hipli
     workers = max(1, min(16, len(os.sched_getaffinity(0))))
     with ThreadPoolExecutor(workers) as ex:
         want = list(ex.map(_oracle_result, clouds))
-    batches = []
-    for _ in range(DEPTH):
-        b = hiplib.CvoBatch(N_PAIRS)
-        b.set_workgroups(4); b.set_max_workgroups(40)                          # bench.py's config-5 defaults
-        b.set_pairs(clouds)
-        batches.append(b)
-    checked = 0
-    for rnd in range(ROUNDS):
+    for max_wgs, depth, rounds in GEOMETRIES:
+        batches = []
+        for _ in range(depth):
+            b = hiplib.CvoBatch(N_PAIRS)
+            b.set_workgroups(4); b.set_max_workgroups(max_wgs)
+            b.set_pairs(clouds)
+            batches.append(b)
+        checked = 0
+        for rnd in range(rounds):
+            for b in batches:
+                b.reset_states(); b.align_async(N_PAIRS)
+            for bi, b in enumerate(batches):
+                res = b.wait(N_PAIRS)
+                for i, (r, (tf, it, nnz)) in enumerate(zip(res, want)):
+                    assert r["status"] == 0 and r["dense_fallbacks"] == 0, (max_wgs, rnd, bi, i, r["status"])
+                    rot, tr = rot_trans_err(r["transform"], tf)
+                    assert rot <= 1e-4 and tr <= 1e-4, (max_wgs, rnd, bi, i, rot, tr)
+                    assert r["iter"] == it and r["A_nonzero"] == nnz, (max_wgs, rnd, bi, i, r["iter"], it, r["A_nonzero"], nnz)
+                    checked += 1
+        assert checked == rounds * depth * N_PAIRS
         for b in batches:
-            b.reset_states(); b.align_async(N_PAIRS)
-        for bi, b in enumerate(batches):
-            res = b.wait(N_PAIRS)
-            for i, (r, (tf, it, nnz)) in enumerate(zip(res, want)):
-                assert r["status"] == 0 and r["dense_fallbacks"] == 0, (rnd, bi, i, r["status"])
-                rot, tr = rot_trans_err(r["transform"], tf)
-                assert rot <= 1e-4 and tr <= 1e-4, (rnd, bi, i, rot, tr)
-                assert r["iter"] == it and r["A_nonzero"] == nnz, (rnd, bi, i, r["iter"], it, r["A_nonzero"], nnz)
-                checked += 1
-    assert checked == ROUNDS * DEPTH * N_PAIRS
-    for b in batches:
-        b.close()
+            b.close()
