@@ -149,21 +149,22 @@ __device__ __forceinline__ float4 ld4(const gfloat* p) { const v4f t = *reinterp
 // Cache policy of the two big per-iteration streams: list entries read in the steady candidate walk, nonzero records written there and read back by
 // the line search.  The entries of a resident-cloud (3 k-point) launch are read non-temporally: a dense pair's list is 2 MB per iteration, it never
 // survives in the XCD's 4 MiB L2 until the next iteration, and marked as a stream it no longer evicts what the XCD's other pairs re-read (+2 %,
-// profiles/r03_cache_policy_ab.txt; the same for the records loses 4 %, and 9 k-point launches gain nothing: kept plain, -DCVO_NT_REC for the record).
+// profiles/r03_cache_policy_ab.txt; the same for the records loses 4 %, and 9 k-point launches gain nothing: kept plain, -DCVO_NT_REC / _LD / _ST for the record:
+// loads alone lose 1.5-2 %, profiles/r03_masked_entry_loads_ab.txt).
 template <bool NT>
 __device__ __forceinline__ v2u ld_ent(const gv2u* p) {
     if (NT) return __builtin_nontemporal_load(p);
     return *p;
 }
 __device__ __forceinline__ void st_rec(gv2u* p, const v2u v) {
-#ifdef CVO_NT_REC
+#if defined(CVO_NT_REC) || defined(CVO_NT_REC_ST)
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
 #endif
 }
 __device__ __forceinline__ v2u ld_rec(const gv2u* p) {
-#ifdef CVO_NT_REC
+#if defined(CVO_NT_REC) || defined(CVO_NT_REC_LD)
     return __builtin_nontemporal_load(p);
 #else
     return *p;
