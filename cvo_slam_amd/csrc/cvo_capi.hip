@@ -689,14 +689,18 @@ struct Engine {
             const int mode = order_mode == 1 ? (queue_launch ? 2 : 5) : order_mode;      // 2 densest first, 5 eighths of the ranking per XCD class
             if (mode == 3) std::reverse(order.begin(), order.end());                      // lightest first
             if (mode == 4) { std::vector<int> o2; for (int i = 0, j = n - 1; i <= j; ++i, --j) { o2.push_back(order[i]); if (i != j) o2.push_back(order[j]); } order = o2; }   // heavy, light, heavy, ...
-            if (mode == 5) {                                                               // position p <- chunk p % 8 of the ranking, its (p / 8)-th pair
+            if (mode == 5 || mode == 10 || mode == 11) {                                   // position p <- chunk p % 8 of the ranking, its (p / 8)-th pair
                 std::vector<int> first(9, 0), o2(n);
                 for (int c = 0; c < 8; ++c) first[c + 1] = first[c] + n / 8 + (c < n % 8 ? 1 : 0);
-                for (int p = 0; p < n; ++p) o2[p] = order[first[p % 8] + p / 8];
+                for (int p = 0; p < n; ++p) {
+                    const int c = mode == 11 ? 7 - p % 8 : p % 8, len = first[c + 1] - first[c];
+                    const int k = p / 8;                                                  // experiment orders: 10 lightest of the chunk first, 11 chunks in reverse
+                    o2[p] = order[first[c] + (mode == 10 ? len - 1 - k : k)];
+                }
                 order = o2;
             }
             if (mode == 6) { std::vector<int> o2; const int nb8 = (n + 7) / 8; for (int i = 0, j = nb8 - 1; i <= j; ++i, --j) { for (int q = 8 * i; q < std::min(n, 8 * i + 8); ++q) o2.push_back(order[q]); if (i != j) for (int q = 8 * j; q < std::min(n, 8 * j + 8); ++q) o2.push_back(order[q]); } order = o2; }   // eight heavy, eight light, ...
-            if (mode >= 7) { unsigned st = 12345u * (unsigned)mode; for (int i = n - 1; i > 0; --i) { st = st * 1664525u + 1013904223u; std::swap(order[i], order[(st >> 8) % (unsigned)(i + 1)]); } }   // shuffles
+            if (mode >= 7 && mode < 10) { unsigned st = 12345u * (unsigned)mode; for (int i = n - 1; i > 0; --i) { st = st * 1664525u + 1013904223u; std::swap(order[i], order[(st >> 8) % (unsigned)(i + 1)]); } }   // shuffles
         }
         for (int i = 0; i < n; ++i) {
             PairDesc& D = hd[i];
