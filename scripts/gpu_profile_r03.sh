@@ -18,4 +18,12 @@ if [ $WHAT = eth ] || [ $WHAT = all ]; then
   timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/eth_trace -- python3 bench.py --shape eth3d --no-cpu-baseline --no-latency-probe > $O/eth_trace.json 2> $O/eth_trace.err; echo "trace eth rc=$?"
   BENCH_ARGS="--shape eth3d --steps 2 --warmup 1 --streams 1 --max-workgroups 256" bash scripts/pmc_run.sh $O/eth_pmc sq1 sq2 sq4 fetch write
 fi
+if [ $WHAT = ethmask ] || [ $WHAT = all ]; then   # the experiment build that masks the entry loads of rows that have ended (scripts/experiments/r03_masked_entry_loads.patch): its traffic
+  rm -rf $O/eth_pmc_masked
+  if [ -f tmp_libs/libcvo_hip_mdef.so ]; then
+    export CVO_HIP_LIB=$PWD/tmp_libs/libcvo_hip_mdef.so
+    BENCH_ARGS="--shape eth3d --steps 2 --warmup 1 --streams 1 --max-workgroups 256" bash scripts/pmc_run.sh $O/eth_pmc_masked fetch write
+    unset CVO_HIP_LIB
+  fi
+fi
 find $O -name "*kernel_stats.csv" | head; du -sh $O
