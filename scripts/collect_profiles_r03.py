@@ -59,4 +59,9 @@ if os.path.exists(os.path.join(SRC, "eth_trace.json")):
                   "source": f"profiles/r03_eth3d_pmc_summary.json (rocprofv3 --pmc passes of scripts/pmc_run.sh at commit {commit}, lease {lease[0]} {lease[-1]}: 64 pairs, ~9.3 k points, four workgroups per pair, one step in flight)",
                   "commit": commit}
     print("eth3d:", round(eb["value"]), "alignments/s;", json.dumps(t["eth3d"], indent=1))
+if os.path.isdir(os.path.join(SRC, "eth_pmc_masked")) and os.path.exists(os.path.join(DST, "r03_eth3d_bench_under_rocprof.json")):
+    eb = json.loads(open(os.path.join(DST, "r03_eth3d_bench_under_rocprof.json")).read())
+    subprocess.check_call(summ + [os.path.join(SRC, "eth_pmc_masked"), os.path.join(DST, "r03_eth3d_pmc_masked_entry_loads_summary.json"), str(eb["hbm"]["algorithmic_bytes_per_launch"])], stdout=subprocess.DEVNULL)
+    m = json.load(open(os.path.join(DST, "r03_eth3d_pmc_masked_entry_loads_summary.json")))
+    print("eth3d, experiment build with masked entry loads: traffic per launch", m["hbm_bytes_per_launch_corrected"], "uncorrected", m["hbm_bytes_per_launch_uncorrected"])
 json.dump(t, open(tpath, "w"), indent=1)
