@@ -691,7 +691,7 @@ struct Engine {
             if (mode == 4) { std::vector<int> o2; for (int i = 0, j = n - 1; i <= j; ++i, --j) { o2.push_back(order[i]); if (i != j) o2.push_back(order[j]); } order = o2; }   // heavy, light, heavy, ...
             if (mode == 5 || mode == 10 || mode == 11) {                                   // position p <- chunk p % 8 of the ranking, its (p / 8)-th pair
                 std::vector<int> first(9, 0), o2(n);
-                for (int c = 0; c < 8; ++c) first[c + 1] = first[c] + n / 8 + (c < n % 8 ? 1 : 0);
+                for (int c = 0; c < 8; ++c) first[c + 1] = first[c] + n / 8 + ((mode == 11 ? 7 - c : c) < n % 8 ? 1 : 0);   // a chunk has as many pairs as its class has positions
                 for (int p = 0; p < n; ++p) {
                     const int c = mode == 11 ? 7 - p % 8 : p % 8, len = first[c + 1] - first[c];
                     const int k = p / 8;                                                  // experiment orders: 10 lightest of the chunk first, 11 chunks in reverse
