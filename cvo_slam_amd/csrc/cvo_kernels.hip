@@ -151,6 +151,17 @@ __device__ __forceinline__ float4 ld4(const gfloat* p) { const v4f t = *reinterp
 // survives in the XCD's 4 MiB L2 until the next iteration, and marked as a stream it no longer evicts what the XCD's other pairs re-read (+2 %,
 // profiles/r03_cache_policy_ab.txt; the same for the records loses 4 %, and 9 k-point launches gain nothing: kept plain, -DCVO_NT_REC / _LD / _ST for the record:
 // loads alone lose 1.5-2 %, profiles/r03_masked_entry_loads_ab.txt).
+// Entries of a list in slot order: entry n of slot s is ent[2 * ((n >> 1) * rows_pad + s) + (n & 1)] -- two consecutive entries of a row are neighbours, so the
+// steady walk fetches its four entries per step with two 16-byte loads per lane (the vector memory pipe is as busy as the VALU in that walk: four loads and
+// up to four record stores per step; see DESIGN.md, "Measured in round 3").  ent_ix(n, rows_pad) is the offset from the slot's base ent + 2 * s.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef CVO_GLOBAL v4u gv4u;
+__device__ __forceinline__ size_t ent_ix(int n, size_t rows_pad) { return (size_t)(n >> 1) * rows_pad * 2 + (size_t)(n & 1); }
+template <bool NT>
+__device__ __forceinline__ v4u ld_ent2(const gv4u* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
 template <bool NT>
 __device__ __forceinline__ v2u ld_ent(const gv2u* p) {
     if (NT) return __builtin_nontemporal_load(p);
@@ -1121,14 +1132,15 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
     const bool x_lds = sh->x_lds != 0;
     int wcount = 0;
     const int nb = sh->wnb[wave];
-    const unsigned rp = (unsigned)c.rows_pad, estep = PF * rp;
+    const unsigned rp = (unsigned)c.rows_pad, estep = (PF / 2) * rp;      // in 16-byte words
     // the first entries of a block are fetched while the block before it is walked: in the late iterations a row holds only a
     // handful of entries, and a block would otherwise start with an exposed memory round trip
-    v2u ehead[PF];
+    static_assert(PF == 4, "a step is two 16-byte words of two entries");
+    v4u ehead[PF / 2];
     if (nb > 0) {
-        const gv2u* eb0 = uni_ptr(c.ent + wave_block(0, wave, nwaves) * 64);
+        const gv4u* eb0 = uni_ptr((const gv4u*)c.ent + wave_block(0, wave, nwaves) * 64);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) ehead[u] = ld_ent<YM == 1>(&eb0[(unsigned)lane + (unsigned)u * rp]);
+        for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<YM == 1>(&eb0[(unsigned)lane + (unsigned)u * rp]);
     }
     for (int bi = 0; bi < nb; ++bi) {
         const int blk = wave_block(bi, wave, nwaves);
@@ -1137,22 +1149,25 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         const int lw = uni((int)sh->blk_lmax[blk]);                  // longest list of the block (phase_sort / refine_lists)
         float xi[3]; load_x(c, L, x_lds, slot, xi);
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
-        const gv2u* eb = uni_ptr(c.ent + (slot - lane));             // scalar base of the block's entries + 32-bit lane offsets
+        const gv4u* eb = uni_ptr((const gv4u*)c.ent + (slot - lane)); // scalar base of the block's entries + 32-bit lane offsets
         unsigned eo = (unsigned)lane;
         const unsigned stag = (unsigned)slot << 16;
-        v2u eq[PF];
+        v4u eq4[PF / 2];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) eq[u] = ehead[u];
+        for (int u = 0; u < PF / 2; ++u) eq4[u] = ehead[u];
         if (bi + 1 < nb) {
-            const gv2u* eb1 = uni_ptr(c.ent + wave_block(bi + 1, wave, nwaves) * 64);
+            const gv4u* eb1 = uni_ptr((const gv4u*)c.ent + wave_block(bi + 1, wave, nwaves) * 64);
 #pragma unroll
-            for (int u = 0; u < PF; ++u) ehead[u] = ld_ent<YM == 1>(&eb1[(unsigned)lane + (unsigned)u * rp]);
+            for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<YM == 1>(&eb1[(unsigned)lane + (unsigned)u * rp]);
         }
         for (int n0 = 0; n0 < lw; n0 += PF) {
             if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
-            v2u en[PF];
+            v4u en4[PF / 2];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) en[u] = ld_ent<YM == 1>(&eb[eo + (unsigned)u * rp]);
+            for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<YM == 1>(&eb[eo + (unsigned)u * rp]);
+            v2u eq[PF];
+#pragma unroll
+            for (int u = 0; u < PF / 2; ++u) { eq[2 * u].x = eq4[u].x; eq[2 * u].y = eq4[u].y; eq[2 * u + 1].x = eq4[u].z; eq[2 * u + 1].y = eq4[u].w; }
             float av[PF], ckv[PF]; float4 yv4[PF]; bool actv[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -1173,7 +1188,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
                 for (int u = 0; u < PF; ++u) fold_entry(xi, yv4[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, wcount, lane);
             }
 #pragma unroll
-            for (int u = 0; u < PF; ++u) eq[u] = en[u];
+            for (int u = 0; u < PF / 2; ++u) eq4[u] = en4[u];
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * rs.sw[q]); acc8[3 + q] += (double)(inv_d * rs.sv[q]); }   // cvo.cpp:222-223
@@ -1204,7 +1219,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
         const gv2u* jp = c.jT4 + li;                                // entries 4q .. 4q+3 of this row: jp[q * rows_pad]
         static_assert(PF == 4, "the cull packs four columns per word");
-        gv2u* ep = c.ent + slot;
+        gv2u* ep = c.ent + 2 * slot;
         const unsigned stag = (unsigned)slot << 16;
         auto cols = [&](int n0, int (&jo)[PF]) {
 #pragma unroll
@@ -1246,7 +1261,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
             for (int u = 0; u < PF; ++u) {
                 const float ckx = (float)((double)gates.csig2 * __builtin_ldexp(pc[u], (int)kc[u]));
                 ckv[u] = (d2c[u] < gates.d2c_thres) ? ckx : __builtin_nanf("");
-                if (actv[u]) { v2u e; e.x = __float_as_uint(ckv[u]); e.y = (unsigned)j0[u]; ep[(size_t)(n0 + u) * c.rows_pad] = e; }
+                if (actv[u]) { v2u e; e.x = __float_as_uint(ckv[u]); e.y = (unsigned)j0[u]; ep[ent_ix(n0 + u, (size_t)c.rows_pad)] = e; }
             }
             if (FLAT) {
                 float ev[PF][3];
@@ -1280,18 +1295,18 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
         const int len = L.lenS[slot];
         const int lw = uni((int)sh->blk_lmax[blk]);
         float xi[3]; load_x(c, L, sh->x_lds != 0, slot, xi);
-        gv2u* wp = c.ent + slot;                                    // where the next kept entry goes: never ahead of the reads
+        gv2u* wp = c.ent + 2 * slot;                                // the kept entries go to the front of the row: never ahead of the reads
         const gv2u* ep = wp;
-        const size_t estep = (size_t)PF * c.rows_pad;
-        int cnt = 0;
+        const size_t rp = (size_t)c.rows_pad;
+        int cnt = 0, nr = 0;
         v2u eq[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) eq[u] = ep[(size_t)u * c.rows_pad];
+        for (int u = 0; u < PF; ++u) eq[u] = ep[ent_ix(u, rp)];
         for (int n0 = 0; n0 < lw; n0 += PF) {
-            if (n0 + 2 * PF <= c.capn) ep += estep;                 // next step's entries: loaded before this step stores anything
+            if (n0 + 2 * PF <= c.capn) nr += PF;                    // next step's entries: loaded before this step stores anything
             v2u en[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) en[u] = ep[(size_t)u * c.rows_pad];
+            for (int u = 0; u < PF; ++u) en[u] = ep[ent_ix(nr + u, rp)];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const bool act = n0 + u < len;
@@ -1299,7 +1314,7 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
                 const float4 y = load_y<YM>(c, L, j);
                 const float dx = xi[0] - y.x, dy = xi[1] - y.y, dz = xi[2] - y.z;
                 const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nthr)));
-                if (act && t < 0.f) { *wp = eq[u]; wp += c.rows_pad; ++cnt; }
+                if (act && t < 0.f) { wp[ent_ix(cnt, rp)] = eq[u]; ++cnt; }
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) eq[u] = en[u];
@@ -1344,7 +1359,7 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
         const int left = k < 3 ? 3 - k : (k < 10 ? 10 - k : (k < 20 ? 20 - k : 24));
         const float gain_ns = 0.28f * (float)left * ((float)walked - 1.3f * (float)tot), cost_ns = 25000.f + 1.7f * (float)tot;
         const int mode = sh->P.resort;                               // CVO_HIP_RESORT: 0 never, 1 by the cost model, 2 always
-        sh->resort = (mode && lmax_new > 0 && (long long)lmax_new * c.rows_pad <= (long long)c.flat_cap && (mode == 2 || gain_ns > cost_ns)) ? 1 : 0;
+        sh->resort = (mode && lmax_new > 0 && (long long)((lmax_new + 1) & ~1) * c.rows_pad <= (long long)c.flat_cap && (mode == 2 || gain_ns > cost_ns)) ? 1 : 0;
     }
     __syncthreads();
     if (!sh->resort) return;
@@ -1370,15 +1385,15 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) lw = max(lw, __shfl_xor(lw, off, 64));
             const int so = (pass == 0 && len > 0) ? (int)slot_of[L.row_of[sn]] : sn;
-            const gv2u* src = (pass == 0 ? c.ent : stage) + so;
-            gv2u* dst = (pass == 0 ? stage : c.ent) + sn;
+            const gv2u* src = (pass == 0 ? c.ent : stage) + 2 * so;
+            gv2u* dst = (pass == 0 ? stage : c.ent) + 2 * sn;
             constexpr int MV = 8;
             for (int n0 = 0; n0 < lw; n0 += MV) {
                 v2u e[MV];
 #pragma unroll
-                for (int u = 0; u < MV; ++u) if (n0 + u < len) e[u] = src[(size_t)(n0 + u) * rp];
+                for (int u = 0; u < MV; ++u) if (n0 + u < len) e[u] = src[ent_ix(n0 + u, rp)];
 #pragma unroll
-                for (int u = 0; u < MV; ++u) if (n0 + u < len) dst[(size_t)(n0 + u) * rp] = e[u];
+                for (int u = 0; u < MV; ++u) if (n0 + u < len) dst[ent_ix(n0 + u, rp)] = e[u];
             }
         }
         __syncthreads();
@@ -1742,11 +1757,11 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
                 const int gi = global_row(c, (int)L.row_of[slot]);
                 const float4 flo = ld4(c.fixed + lo_off(gi)), fhi = ld4(c.fixed + hi_off(c.nf, gi));
                 const float fb[5] = {flo.w, fhi.x, fhi.y, fhi.z, fhi.w};
-                const gv2u* ep = c.ent + slot;
+                const gv2u* ep = c.ent + 2 * slot;
                 for (int n0 = 0; n0 < lw; n0 += PF) {
                     v2u en[PF];
 #pragma unroll
-                    for (int u = 0; u < PF; ++u) en[u] = ep[(size_t)min(n0 + u, c.capn - 1) * c.rows_pad];   // the step's entries in one round trip (stale beyond the row's end)
+                    for (int u = 0; u < PF; ++u) en[u] = ep[ent_ix(min(n0 + u, c.capn - 1), (size_t)c.rows_pad)];   // the step's entries in one round trip (stale beyond the row's end)
 #pragma unroll
                     for (int u = 0; u < PF; ++u) {
                         const bool act = n0 + u < len;
