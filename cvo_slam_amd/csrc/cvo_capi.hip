@@ -198,6 +198,9 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
+    bool skin_auto = true;           // the list radius margin follows the layout: 0.35 with the cloud resident as 16-byte points (3 k-point shape), 0.30 otherwise -- measured with
+                                     // the device full (profiles/r03_skin_sweep.txt): a cull costs LDS and issue time only, a longer list costs memory traffic, and that is dearer
+                                     // with 256 workgroups streaming than alone (round 2's 0.25 was tuned on one launch); CVO_HIP_SKIN fixes it
     DevBuf d_descs, d_states, d_ybuf, d_jT, d_ent, d_surv, d_xch, d_queue, d_trace, d_tracelen, d_partials;
     // 64-byte result records, one per pair, written by the align kernel (PairDesc::record); the block a rank contributes to the
     // cross-GPU gather may be longer than its pairs (padding records: pad_from .. pad_to carry pad_status, see padded_records)
@@ -259,7 +262,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_FLAT_CAP")) capf_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_BLOCK")) block_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS_PER_CU")) per_cu = std::max(1, std::min(2, std::atoi(e)));
-        if (const char* e = std::getenv("CVO_HIP_SKIN")) P.skin = (float)std::atof(e);
+        if (const char* e = std::getenv("CVO_HIP_SKIN")) { P.skin = (float)std::atof(e); skin_auto = false; }
         if (const char* e = std::getenv("CVO_HIP_RESORT")) P.resort = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_COLOCATE")) P.colocate = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_ADOPT_KMAX")) P.adopt_kmax = std::max(0, std::atoi(e));
@@ -759,14 +762,16 @@ struct Engine {
         for (hipEvent_t ev : run_after) HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         HIP_TRY(hipEventRecord(ev0, s));
         hipError_t e;
+        DevParams Pl = P;
+        if (skin_auto) Pl.skin = y_mode == 1 ? 0.35f : 0.30f;
         if (ac) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
             std::lock_guard<std::mutex> lk(adopt_submit_mutex());
             *ac->submitted_host += (unsigned)grid;
-            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P,
+            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl,
                              ac->submitted_dev, ac->started_dev, rawtab);
             if (e != hipSuccess) *ac->submitted_host -= (unsigned)grid;
         } else {
-            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), P, nullptr, nullptr, rawtab);
+            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl, nullptr, nullptr, rawtab);
         }
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));

@@ -64,6 +64,7 @@ constexpr unsigned ADOPT_FREE = 0u, ADOPT_REQUEST = 1u, ADOPT_ACCEPT = 2u, ADOPT
 #define CVO_ADOPT_GMAX 4
 #endif
 constexpr int ADOPT_GMAX = CVO_ADOPT_GMAX;                                    // workgroups a pair can grow to by adoption (the host sizes the exchange area and the buffers' slack for it)
+constexpr float SKIN_DENSE_SCENE = 0.25f;   // list radius margin a pair falls back to when the lists of the launch's margin overflow (round 2's value)
 constexpr float FAR_ROW = 3.0e18f;    // coordinates of padding rows / columns: d2 overflows, never < threshold
 constexpr float FAR_COL = -3.0e18f;
 
@@ -1515,7 +1516,10 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
         }
         // records stream from L2 / HBM: four steps of them are in flight per lane (under load one step's arithmetic is shorter
         // than a memory round trip)
-        constexpr int RD = 4;
+#ifndef CVO_LS_RD
+#define CVO_LS_RD 4
+#endif
+        constexpr int RD = CVO_LS_RD;
         auto walk = [&](auto ym, auto tb) {
             constexpr int YM = decltype(ym)::value;
             constexpr bool TAB = decltype(tb)::value;
@@ -2039,7 +2043,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
             for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
             sh->cand_total = 0;
-            sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
+            sh->P.skin = P.skin; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
         // a helper has read what the owner published for it: if the pair may grow further, its word takes offers again (not earlier --
@@ -2066,6 +2070,13 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                 phase_cull(Dp, ge, Ge, tgeo, y_lds);
                 const unsigned long long t_b = CVO_NOW();
                 phase_sort(Dp, ge, Ge, tgeo, y_lds);
+                if (sh->dense_mode && sh->P.skin > SKIN_DENSE_SCENE) {   // the lists of this margin do not fit (a surface a few decimetres from the camera): once more with the
+                    __syncthreads();                                     // narrow margin, kept for the rest of the pair, before the rows fall back to dense sweeps
+                    if (tid == 0) { sh->P.skin = SKIN_DENSE_SCENE; sh->dense_fallbacks -= 1; }
+                    __syncthreads();
+                    phase_cull(Dp, ge, Ge, tgeo, y_lds);
+                    phase_sort(Dp, ge, Ge, tgeo, y_lds);
+                }
                 if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], CVO_NOW() - t_b); }
             } else if (sh->rebuild == 2) {
                 phase_refine(Dp, ge, Ge, tgeo, y_lds, k);
