@@ -158,6 +158,36 @@ __device__ __forceinline__ float4 ld4(const gfloat* p) { const v4f t = *reinterp
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef CVO_GLOBAL v4u gv4u;
 __device__ __forceinline__ size_t ent_ix(int n, size_t rows_pad) { return (size_t)(n >> 1) * rows_pad * 2 + (size_t)(n & 1); }
+// the in-place filter of the lists after an ell drop (refine_lists): -DCVO_NT_REFINE streams its reads and writes
+__device__ __forceinline__ v2u ld_rf(const gv2u* p) {
+#ifdef CVO_NT_REFINE
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_rf(gv2u* p, const v2u v) {
+#ifdef CVO_NT_REFINE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+// the cull's raw lists are written once and read once (by the first candidate pass after the cull): -DCVO_NT_JT marks both as streams
+__device__ __forceinline__ void st_jt(gv2u* p, const v2u v) {
+#ifdef CVO_NT_JT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ v2u ld_jt(const gv2u* p) {
+#ifdef CVO_NT_JT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 template <bool NT>
 __device__ __forceinline__ v4u ld_ent2(const gv4u* p) {
     if (NT) return __builtin_nontemporal_load(p);
@@ -943,7 +973,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                                     buf[r] |= four[r] << (16 * fill);
                                     if (fill + n >= 4) {
                                         v2u wv; wv.x = (unsigned)buf[r]; wv.y = (unsigned)(buf[r] >> 32);
-                                        c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]] = wv;
+                                        st_jt(&c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]], wv);
                                         buf[r] = fill ? (four[r] >> (16 * (4 - fill))) : 0ull;
                                     }
                                 }
@@ -957,7 +987,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             for (int r = 0; r < SWEEP_R; ++r) {
                 if ((cnt[r] & 3) && cnt[r] < c.capn) {              // the partial word (capn is a multiple of 4: a full list never leaves one)
                     v2u w; w.x = (unsigned)buf[r]; w.y = (unsigned)(buf[r] >> 32);
-                    c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]] = w;
+                    st_jt(&c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]], w);
                 }
                 rowlen[li[r]] = (uint16_t)cnt[r];                   // rowlen has room for the padding rows of the last block pair
             }
@@ -1226,7 +1256,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
 #pragma unroll
             for (int u = 0; u < PF; ++u) jo[u] = 0;
             if (n0 < len) {
-                const v2u w = jp[(size_t)(n0 >> 2) * c.rows_pad];
+                const v2u w = ld_jt(&jp[(size_t)(n0 >> 2) * c.rows_pad]);
                 const int q[PF] = {(int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16)};
 #pragma unroll
                 for (int u = 0; u < PF; ++u) jo[u] = (n0 + u < len) ? q[u] : 0;
@@ -1262,8 +1292,17 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
             for (int u = 0; u < PF; ++u) {
                 const float ckx = (float)((double)gates.csig2 * __builtin_ldexp(pc[u], (int)kc[u]));
                 ckv[u] = (d2c[u] < gates.d2c_thres) ? ckx : __builtin_nanf("");
-                if (actv[u]) { v2u e; e.x = __float_as_uint(ckv[u]); e.y = (unsigned)j0[u]; ep[ent_ix(n0 + u, (size_t)c.rows_pad)] = e; }
             }
+#pragma unroll
+            for (int u = 0; u < PF; u += 2)                           // two entries per 16-byte store (the second may lie beyond the row's end: stale there anyway)
+                if (actv[u]) {
+                    v4u e; e.x = __float_as_uint(ckv[u]); e.y = (unsigned)j0[u]; e.z = __float_as_uint(ckv[u + 1]); e.w = (unsigned)j0[u + 1];
+#ifndef CVO_PLAIN_ENT_ST
+                    __builtin_nontemporal_store(e, reinterpret_cast<gv4u*>(&ep[ent_ix(n0 + u, (size_t)c.rows_pad)]));
+#else
+                    *reinterpret_cast<gv4u*>(&ep[ent_ix(n0 + u, (size_t)c.rows_pad)]) = e;
+#endif
+                }
             if (FLAT) {
                 float ev[PF][3];
                 se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av, ev);
@@ -1302,12 +1341,12 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
         int cnt = 0, nr = 0;
         v2u eq[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) eq[u] = ep[ent_ix(u, rp)];
+        for (int u = 0; u < PF; ++u) eq[u] = ld_rf(&ep[ent_ix(u, rp)]);
         for (int n0 = 0; n0 < lw; n0 += PF) {
             if (n0 + 2 * PF <= c.capn) nr += PF;                    // next step's entries: loaded before this step stores anything
             v2u en[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) en[u] = ep[ent_ix(nr + u, rp)];
+            for (int u = 0; u < PF; ++u) en[u] = ld_rf(&ep[ent_ix(nr + u, rp)]);
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const bool act = n0 + u < len;
@@ -1315,7 +1354,7 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
                 const float4 y = load_y<YM>(c, L, j);
                 const float dx = xi[0] - y.x, dy = xi[1] - y.y, dz = xi[2] - y.z;
                 const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nthr)));
-                if (act && t < 0.f) { wp[ent_ix(cnt, rp)] = eq[u]; ++cnt; }
+                if (act && t < 0.f) { st_rf(&wp[ent_ix(cnt, rp)], eq[u]); ++cnt; }
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) eq[u] = en[u];
