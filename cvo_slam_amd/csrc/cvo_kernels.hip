@@ -147,11 +147,15 @@ typedef CVO_GLOBAL uint32_t gu32;
 typedef CVO_GLOBAL int gint;
 typedef CVO_GLOBAL unsigned long long gu64;
 __device__ __forceinline__ float4 ld4(const gfloat* p) { const v4f t = *reinterpret_cast<const gv4f*>(p); return make_float4(t.x, t.y, t.z, t.w); }
-// Cache policy of the two big per-iteration streams: list entries read in the steady candidate walk, nonzero records written there and read back by
-// the line search.  The entries of a resident-cloud (3 k-point) launch are read non-temporally: a dense pair's list is 2 MB per iteration, it never
-// survives in the XCD's 4 MiB L2 until the next iteration, and marked as a stream it no longer evicts what the XCD's other pairs re-read (+2 %,
-// profiles/r03_cache_policy_ab.txt; the same for the records loses 4 %, and 9 k-point launches gain nothing: kept plain, -DCVO_NT_REC / _LD / _ST for the record:
-// loads alone lose 1.5-2 %, profiles/r03_masked_entry_loads_ab.txt).
+// Cache policy of the per-iteration streams.  With every CU at work the walks wait for memory a quarter longer than one launch alone does (a bandwidth hog
+// beside one launch slows them by 60-75 %, profiles/r03_contention_probe.txt), so what the L2 keeps matters:
+//  * list entries read by the steady candidate walk: non-temporal loads -- a dense pair's list is 2 MB per iteration, it never survives in the XCD's 4 MiB L2
+//    until the next iteration, and marked as a stream it no longer evicts what the XCD's other workgroups re-read (+2 % at 3 k points, +3.5 % at 9 k);
+//  * list entries written by the first pass after a cull: non-temporal 16-byte stores (+1 % for the width, +1 ... 1.7 % for the policy);
+//  * nonzero records (written by the candidate walk, read by the line search tens of microseconds later), the cull's raw lists (written, then read once by
+//    the first pass) and the in-place refinement: plain -- streaming them loses 2 ... 8 % (they are re-read soon enough to hit).
+// profiles/r03_cache_policy_ab.txt, r03_entry_stores_ab.txt, r03_raw_list_and_refine_policy_ab.txt, r03_eth3d_entries_nt_ab.txt, r03_masked_entry_loads_ab.txt.
+// -DCVO_NT_REC / _LD / _ST, -DCVO_NT_JT, -DCVO_NT_REFINE, -DCVO_PLAIN_ENT_LD, -DCVO_PLAIN_ENT_ST build the alternatives.
 // Entries of a list in slot order: entry n of slot s is ent[2 * ((n >> 1) * rows_pad + s) + (n & 1)] -- two consecutive entries of a row are neighbours, so the
 // steady walk fetches its four entries per step with two 16-byte loads per lane (the vector memory pipe is as busy as the VALU in that walk: four loads and
 // up to four record stores per step; see DESIGN.md, "Measured in round 3").  ent_ix(n, rows_pad) is the offset from the slot's base ent + 2 * s.
@@ -188,6 +192,11 @@ __device__ __forceinline__ v2u ld_jt(const gv2u* p) {
     return *p;
 #endif
 }
+#ifdef CVO_PLAIN_ENT_LD
+#define ENT_NT(YM) false
+#else
+#define ENT_NT(YM) true      // every layout: +2 % at 3 k points, +3.5 % at 9 k (profiles/r03_cache_policy_ab.txt, r03_eth3d_entries_nt_ab.txt)
+#endif
 template <bool NT>
 __device__ __forceinline__ v4u ld_ent2(const gv4u* p) {
     if (NT) return __builtin_nontemporal_load(p);
@@ -1171,7 +1180,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
     if (nb > 0) {
         const gv4u* eb0 = uni_ptr((const gv4u*)c.ent + wave_block(0, wave, nwaves) * 64);
 #pragma unroll
-        for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<YM == 1>(&eb0[(unsigned)lane + (unsigned)u * rp]);
+        for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<ENT_NT(YM)>(&eb0[(unsigned)lane + (unsigned)u * rp]);
     }
     for (int bi = 0; bi < nb; ++bi) {
         const int blk = wave_block(bi, wave, nwaves);
@@ -1189,13 +1198,13 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         if (bi + 1 < nb) {
             const gv4u* eb1 = uni_ptr((const gv4u*)c.ent + wave_block(bi + 1, wave, nwaves) * 64);
 #pragma unroll
-            for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<YM == 1>(&eb1[(unsigned)lane + (unsigned)u * rp]);
+            for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<ENT_NT(YM)>(&eb1[(unsigned)lane + (unsigned)u * rp]);
         }
         for (int n0 = 0; n0 < lw; n0 += PF) {
             if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
             v4u en4[PF / 2];
 #pragma unroll
-            for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<YM == 1>(&eb[eo + (unsigned)u * rp]);
+            for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<ENT_NT(YM)>(&eb[eo + (unsigned)u * rp]);
             v2u eq[PF];
 #pragma unroll
             for (int u = 0; u < PF / 2; ++u) { eq[2 * u].x = eq4[u].x; eq[2 * u].y = eq4[u].y; eq[2 * u + 1].x = eq4[u].z; eq[2 * u + 1].y = eq4[u].w; }
