@@ -1240,7 +1240,9 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
 // (cvo.cpp:169-173) are evaluated once and kept with the column in the slot-ordered entries.  Three stages in flight per
 // lane: columns of step s+2 (gathered from the raw lists), second feature plane of the columns of step s+1, arithmetic
 // of step s.
-template <int YM, bool FLAT>
+// GL: the moving cloud's second feature plane has been staged in LDS (the line-search table's room, dead until the line search of this iteration makes its
+// table): the four 16-byte feature gathers of a step are LDS reads instead of vector-memory gathers from L2
+template <int YM, bool FLAT, bool GL = false>
 __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                            double (&acc8)[8]) {
     gv2u* sp = uni_ptr(c.surv + c.fbase + sh->wbase[wave]);
@@ -1273,7 +1275,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         };
         auto feats = [&](const int (&ji)[PF], float4 (&go)[PF]) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) go[u] = ld4(c.moving + hi_off(c.nm, ji[u]));
+            for (int u = 0; u < PF; ++u) go[u] = GL ? L.tab[ji[u]] : ld4(c.moving + hi_off(c.nm, ji[u]));
         };
         int j0[PF], j1[PF], j2[PF]; float4 g0[PF], g1[PF];
         cols(0, j0); cols(PF, j1);
@@ -1466,6 +1468,14 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 #define CVO_CAND(fn, flat) do { if (y_lds == 1) fn<1, flat>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8); \
                                 else if (y_lds == 2) fn<2, flat>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8); \
                                 else fn<0, flat>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8); } while (0)
+#ifndef CVO_NO_FEATURE_STAGING
+        if (fresh_list && y_lds == 1 && sh->tab_cols >= c.nm) {
+            for (int j = tid; j < c.nm; j += nthreads) L.tab[j] = ld4(c.moving + hi_off(c.nm, j));
+            __syncthreads();
+            if (gates.poly_ok) cand_fresh<1, true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+            else cand_fresh<1, false, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);
+        } else
+#endif
         if (fresh_list) { if (gates.poly_ok) CVO_CAND(cand_fresh, true); else CVO_CAND(cand_fresh, false); }
         else { if (gates.poly_ok) CVO_CAND(cand_steady, true); else CVO_CAND(cand_steady, false); }
 #undef CVO_CAND
