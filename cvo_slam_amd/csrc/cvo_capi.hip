@@ -26,6 +26,16 @@
 #include "cvo_device.h"
 #include "cvo_math.hpp"
 
+// the align kernel's translation unit is in the library twice (cvo_kernels.hip, head comment): cvohip = two waves per SIMD, cvohip_w3 = three
+namespace cvohip_w3 {
+using cvohip::PairDesc; using cvohip::DevParams;
+size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab_cols);
+int align_min_tile(int rows_cap, int y_mode, int y_cap);
+int align_tile_granule();
+int align_block_max();
+hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode, int y_cap, int tab_cols, hipStream_t stream, const PairDesc* descs, int n_pairs, int G,
+                        unsigned launch_tag, unsigned long long* queue, const DevParams& P, const unsigned* wgs_submitted, unsigned* wgs_started, const float* const* raw_table);
+}
 namespace cvohip {
 size_t align_shared_bytes(int tile, int rows_cap, int y_mode, int y_cap, int tab_cols);
 int align_min_tile(int rows_cap, int y_mode, int y_cap);
@@ -198,6 +208,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
+    bool wide_waves = true;          // CVO_HIP_WIDE=0: plane-layout launches run the two-waves-per-SIMD build as well
     bool skin_auto = true;           // the list radius margin follows the layout: 0.35 with the cloud resident as 16-byte points (3 k-point shape), 0.30 otherwise -- measured with
                                      // the device full (profiles/r03_skin_sweep.txt): a cull costs LDS and issue time only, a longer list costs memory traffic, and that is dearer
                                      // with 256 workgroups streaming than alone (round 2's 0.25 was tuned on one launch); CVO_HIP_SKIN fixes it
@@ -265,6 +276,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_SKIN")) { P.skin = (float)std::atof(e); skin_auto = false; }
         if (const char* e = std::getenv("CVO_HIP_RESORT")) P.resort = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_COLOCATE")) P.colocate = std::atoi(e) != 0;
+        if (const char* e = std::getenv("CVO_HIP_WIDE")) wide_waves = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_ADOPT_KMAX")) P.adopt_kmax = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("CVO_HIP_ADOPT")) adopt = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
@@ -575,43 +587,62 @@ struct Engine {
         // room for the nonzero records: nm/6 per row on average (512 at 3 k points; a fronto-parallel wall half a metre from the
         // camera gives ~300 neighbours per row at the first ell), beyond that the dense per-row fallback takes over
         if (capf <= 0) capf = std::max(128, nm_max / 6);
-        const int tgran = align_tile_granule();
+        // Which build of the kernel runs the launch, and its LDS plan.  Clouds that only fit in the plane layout (9 k points) run with three waves per SIMD:
+        // their walks wait for memory more than they issue (+5.8 %; the 3 k-point shape loses 3 % to the waves' uneven shares and stays with two).
+        struct KSet { size_t (*shared_bytes)(int, int, int, int, int); int (*min_tile)(int, int, int); int (*tile_granule)(); int (*block_max)();
+                      hipError_t (*launch)(int, int, int, int, int, int, int, hipStream_t, const PairDesc*, int, int, unsigned, unsigned long long*, const DevParams&, const unsigned*, unsigned*, const float* const*); };
+        static const KSet KS2 = {align_shared_bytes, align_min_tile, align_tile_granule, align_block_max, launch_align};
+        static const KSet KS3 = {cvohip_w3::align_shared_bytes, cvohip_w3::align_min_tile, cvohip_w3::align_tile_granule, cvohip_w3::align_block_max, cvohip_w3::launch_align};
+        struct Plan { int y_mode = 0, tile = 0, tab_cols = 0, block = 0; bool err = false; };
+        const int rows_per_w = ((((std::max(nf_max, 1) + 127) / 128) + G - 1) / G) * 128;   // rows are dealt to the workgroups in blocks of 128 (ROW_DEAL)
+        const int rows_cap = round_up(std::max(rows_per_w, 1), 128) + 64;
+        auto plan = [&](const KSet& K) -> Plan {
+        Plan pl;
+        const int tgran = K.tile_granule();
         // LDS budget of one workgroup.  The transformed moving cloud is kept resident if at all possible: as float4 {y, g0}
         // (mode 1) beside a cull tile that holds the whole cloud; else as three float planes (mode 2, 12 B/point) beside a
         // tile just large enough to keep the fixed points in slot order; else it stays in HBM/L2 (mode 0).
         const size_t lds_cap = (size_t)(160 / per_cu - 4) * 1024;
-        const int rows_per_w = ((((std::max(nf_max, 1) + 127) / 128) + G - 1) / G) * 128;   // rows are dealt to the workgroups in blocks of 128 (ROW_DEAL)
-        const int rows_cap = round_up(std::max(rows_per_w, 1), 128) + 64;
         const int tile_full = std::min(round_up(std::max(nm_max, tgran), tgran), 4096);
         const int tile_rows = round_up(std::max(round_up(std::max(rows_per_w, 1), 64), 512), tgran);   // >= the slots: x_i by slot fits the idle tile
         const bool allow_lds = !std::getenv("CVO_HIP_NO_YLDS");
-        int y_mode = 0, tile = tile_request > 0 ? round_up(tile_request, tgran) : tile_full;
+        int& y_mode = pl.y_mode; int& tile = pl.tile; y_mode = 0; tile = tile_request > 0 ? round_up(tile_request, tgran) : tile_full;
         if (const char* e = std::getenv("CVO_HIP_Y_MODE")) {                                // test knob: force a layout (must fit)
             y_mode = std::max(0, std::min(2, std::atoi(e)));
-            if (tile_request <= 0) { tile = y_mode == 1 ? tile_full : std::min(tile_full, std::max(tile_rows, 512)); while (tile > tgran && align_shared_bytes(tile, rows_cap, y_mode, nm_pad, 0) > lds_cap) tile -= tgran; }
-            tile = std::max(tile, align_min_tile(rows_cap, y_mode, nm_pad));
-            if (align_shared_bytes(tile, rows_cap, y_mode, nm_pad, 0) > lds_cap) return fail(CVO_ERR_INVALID, "CVO_HIP_Y_MODE: the requested LDS layout does not fit");
+            if (tile_request <= 0) { tile = y_mode == 1 ? tile_full : std::min(tile_full, std::max(tile_rows, 512)); while (tile > tgran && K.shared_bytes(tile, rows_cap, y_mode, nm_pad, 0) > lds_cap) tile -= tgran; }
+            tile = std::max(tile, K.min_tile(rows_cap, y_mode, nm_pad));
+            if (K.shared_bytes(tile, rows_cap, y_mode, nm_pad, 0) > lds_cap) { pl.err = true; return pl; }
         } else if (tile_request > 0) {
-            if (allow_lds && align_shared_bytes(tile, rows_cap, 1, nm_pad, 0) <= lds_cap) y_mode = 1;
-            else if (allow_lds && align_shared_bytes(std::max(tile, align_min_tile(rows_cap, 2, nm_pad)), rows_cap, 2, nm_pad, 0) <= lds_cap) { y_mode = 2; tile = std::max(tile, align_min_tile(rows_cap, 2, nm_pad)); }
-            else while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0, 0) > lds_cap) tile -= tgran;
+            if (allow_lds && K.shared_bytes(tile, rows_cap, 1, nm_pad, 0) <= lds_cap) y_mode = 1;
+            else if (allow_lds && K.shared_bytes(std::max(tile, K.min_tile(rows_cap, 2, nm_pad)), rows_cap, 2, nm_pad, 0) <= lds_cap) { y_mode = 2; tile = std::max(tile, K.min_tile(rows_cap, 2, nm_pad)); }
+            else while (tile > tgran && K.shared_bytes(tile, rows_cap, 0, 0, 0) > lds_cap) tile -= tgran;
         } else {
-            int t1 = tile_full; while (t1 > 512 && align_shared_bytes(t1, rows_cap, 1, nm_pad, 0) > lds_cap) t1 -= tgran;
+            int t1 = tile_full; while (t1 > 512 && K.shared_bytes(t1, rows_cap, 1, nm_pad, 0) > lds_cap) t1 -= tgran;
             // plane layout: the tile only holds the fixed points by slot (and the rebuild scratch during a rebuild); it is not used for columns
-            const int t2min = align_min_tile(rows_cap, 2, nm_pad);
-            int t2 = std::max(std::min(tile_full, tile_rows), t2min); while (t2 > t2min && align_shared_bytes(t2, rows_cap, 2, nm_pad, 0) > lds_cap) t2 -= tgran;
-            if (allow_lds && align_shared_bytes(t1, rows_cap, 1, nm_pad, 0) <= lds_cap) { y_mode = 1; tile = t1; }
-            else if (allow_lds && align_shared_bytes(t2, rows_cap, 2, nm_pad, 0) <= lds_cap) { y_mode = 2; tile = t2; }
-            else { tile = std::min(tile_full, 2048); while (tile > tgran && align_shared_bytes(tile, rows_cap, 0, 0, 0) > lds_cap) tile -= tgran; }
+            const int t2min = K.min_tile(rows_cap, 2, nm_pad);
+            int t2 = std::max(std::min(tile_full, tile_rows), t2min); while (t2 > t2min && K.shared_bytes(t2, rows_cap, 2, nm_pad, 0) > lds_cap) t2 -= tgran;
+            if (allow_lds && K.shared_bytes(t1, rows_cap, 1, nm_pad, 0) <= lds_cap) { y_mode = 1; tile = t1; }
+            else if (allow_lds && K.shared_bytes(t2, rows_cap, 2, nm_pad, 0) <= lds_cap) { y_mode = 2; tile = t2; }
+            else { tile = std::min(tile_full, 2048); while (tile > tgran && K.shared_bytes(tile, rows_cap, 0, 0, 0) > lds_cap) tile -= tgran; }
         }
         // line-search table (cvo_kernels.hip, phase L): 16 bytes per moving point behind the resident cloud, when that fits
-        int tab_cols = 0;
-        if (!std::getenv("CVO_HIP_NO_TABLE") && y_mode != 0 && align_shared_bytes(tile, rows_cap, y_mode, nm_pad, nm_pad) <= (size_t)(160 / per_cu) * 1024 - 512) tab_cols = nm_pad;
-        const int rows_per = rows_per_w;
-        const int bmax = align_block_max();
-        int block = rows_per > bmax / 2 ? bmax : std::max(64, round_up(rows_per, 64));
+        int& tab_cols = pl.tab_cols; tab_cols = 0;
+        if (!std::getenv("CVO_HIP_NO_TABLE") && y_mode != 0 && K.shared_bytes(tile, rows_cap, y_mode, nm_pad, nm_pad) <= (size_t)(160 / per_cu) * 1024 - 512) tab_cols = nm_pad;
+        const int bmax = K.block_max();
+        int& block = pl.block; block = rows_per_w > bmax / 2 ? bmax : std::max(64, round_up(rows_per_w, 64));
         if (per_cu > 1) block = std::min(block, 256);
         if (block_request > 0) block = std::max(64, std::min(bmax, round_up(block_request, 64)));
+
+        return pl;
+        };
+        const KSet* K = &KS2;
+        Plan pl = plan(KS2);
+        if (pl.err) return fail(CVO_ERR_INVALID, "CVO_HIP_Y_MODE: the requested LDS layout does not fit");
+        if (pl.y_mode == 2 && wide_waves && per_cu == 1) {
+            const Plan p3 = plan(KS3);
+            if (!p3.err && p3.y_mode == 2) { pl = p3; K = &KS3; }
+        }
+        const int y_mode = pl.y_mode, tile = pl.tile, tab_cols = pl.tab_cols, block = pl.block, rows_per = rows_per_w;
 
         int rc;
         if ((rc = d_descs.ensure(sizeof(PairDesc) * n))) return rc;
@@ -767,11 +798,11 @@ struct Engine {
         if (ac) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
             std::lock_guard<std::mutex> lk(adopt_submit_mutex());
             *ac->submitted_host += (unsigned)grid;
-            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl,
+            e = K->launch(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl,
                              ac->submitted_dev, ac->started_dev, rawtab);
             if (e != hipSuccess) *ac->submitted_host -= (unsigned)grid;
         } else {
-            e = launch_align(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl, nullptr, nullptr, rawtab);
+            e = K->launch(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl, nullptr, nullptr, rawtab);
         }
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("align kernel launch: ") + hipGetErrorString(e));
         HIP_TRY(hipEventRecord(ev1, s));

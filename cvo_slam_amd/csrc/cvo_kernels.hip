@@ -42,7 +42,15 @@
 #include <algorithm>
 #include <type_traits>
 
-namespace cvohip {
+// The file is compiled twice into the library: as namespace cvohip with workgroups of up to 512 threads (two waves per SIMD, 256 VGPRs: the 3 k-point
+// shape, bound by issue) and, with -DCVO_KNS=cvohip_w3 -DCVO_BLOCK_MAX=768, as namespace cvohip_w3 with up to 768 threads (three waves per SIMD, 168
+// VGPRs: clouds in the plane layout, whose walks wait for memory more than they issue -- +5.8 % at 9 k points, -3 % at 3 k; profiles/r03_block_size_ab.txt).
+#ifndef CVO_KNS
+#define CVO_KNS cvohip
+#else
+namespace CVO_KNS { using namespace cvohip; }
+#endif
+namespace CVO_KNS {
 
 // phase timers (PairState::phase_ticks): a read of the 100 MHz clock is a scalar memory instruction every wave waits for
 #ifdef CVO_NO_TIMERS
@@ -2520,4 +2528,4 @@ hipError_t launch_align(int grid, int block, int tile, int rows_cap, int y_mode,
     return hipGetLastError();
 }
 
-}  // namespace cvohip
+}  // namespace CVO_KNS
