@@ -92,3 +92,15 @@ def test_queue_launch_densest_first_and_members_on_one_xcd(hiplib, G, max_wgs, c
     for w, g in zip(want, got): _same(w, g)
     got0 = _run(hiplib, pairs, G, max_wgs=max_wgs, CVO_HIP_COLOCATE=colocate, CVO_HIP_ORDER_PAIRS="0")
     _same(want[0], got0[0])
+
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+def test_both_builds_of_the_kernel_agree_on_plane_layout_launches(hiplib, G):
+    """Launches in the plane layout (CVO_HIP_Y_MODE=2 forces it for small clouds; 9 k-point clouds get it by themselves) run the build with three
+    waves per SIMD (768-thread workgroups); CVO_HIP_WIDE=0 keeps them on the two-wave build.  Same results, and those of the resident layout."""
+    pairs = _pairs(9, 4400, lo=900, step=97)                          # 900 ... 1482 points: more rows than 768 threads, several blocks per wave
+    want = _run(hiplib, pairs, 1, CVO_HIP_ORDER_PAIRS="0")            # default layout (16-byte points resident), two waves per SIMD
+    wide = _run(hiplib, pairs, G, CVO_HIP_Y_MODE="2", CVO_HIP_WIDE="1")
+    narrow = _run(hiplib, pairs, G, CVO_HIP_Y_MODE="2", CVO_HIP_WIDE="0")
+    for w, a, b in zip(want, wide, narrow):
+        _same(w, a); _same(w, b)
