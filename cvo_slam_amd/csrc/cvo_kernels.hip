@@ -210,6 +210,17 @@ __device__ __forceinline__ v4u ld_ent2(const gv4u* p) {
     if (NT) return __builtin_nontemporal_load(p);
     return *p;
 }
+// element i of a wave-uniform array, addressed as uniform base + 32-bit BYTE offset: the form the hardware takes as SGPR base + VGPR offset -- no 64-bit address
+// arithmetic per lane (the arrays indexed this way are far below 4 GB)
+typedef CVO_GLOBAL char gchar;
+template <typename T>
+__device__ __forceinline__ T* at_off(T* base, unsigned index) {
+#ifdef CVO_ADDR64
+    return base + index;
+#else
+    return reinterpret_cast<T*>(reinterpret_cast<gchar*>(const_cast<typename std::remove_const<T>::type*>(base)) + index * (unsigned)sizeof(T));
+#endif
+}
 template <bool NT>
 __device__ __forceinline__ v2u ld_ent(const gv2u* p) {
     if (NT) return __builtin_nontemporal_load(p);
@@ -1149,7 +1160,7 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
     if (a > 0.f) {
         const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         v2u rec; rec.x = __float_as_uint(a); rec.y = tag;             // 8 bytes per nonzero: the line search finds x_i, y_j in LDS
-        st_rec(&sp[(unsigned)wcount + below], rec);                   // scalar base + 32-bit lane offset
+        st_rec(at_off(sp, (unsigned)wcount + below), rec);            // scalar base + 32-bit lane offset
     }
     wcount += __popcll(mask);
 }
@@ -1167,7 +1178,7 @@ __device__ __forceinline__ void fold_entry_e(const float* xi, const float4 y4, c
     if (a > 0.f) {
         const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         v2u rec; rec.x = __float_as_uint(a); rec.y = tag;
-        st_rec(&sp[(unsigned)wcount + below], rec);
+        st_rec(at_off(sp, (unsigned)wcount + below), rec);
     }
     wcount += __popcll(mask);
 }
@@ -1188,7 +1199,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
     if (nb > 0) {
         const gv4u* eb0 = uni_ptr((const gv4u*)c.ent + wave_block(0, wave, nwaves) * 64);
 #pragma unroll
-        for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<ENT_NT(YM)>(&eb0[(unsigned)lane + (unsigned)u * rp]);
+        for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<ENT_NT(YM)>(at_off(eb0, (unsigned)lane + (unsigned)u * rp));
     }
     for (int bi = 0; bi < nb; ++bi) {
         const int blk = wave_block(bi, wave, nwaves);
@@ -1206,13 +1217,13 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         if (bi + 1 < nb) {
             const gv4u* eb1 = uni_ptr((const gv4u*)c.ent + wave_block(bi + 1, wave, nwaves) * 64);
 #pragma unroll
-            for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<ENT_NT(YM)>(&eb1[(unsigned)lane + (unsigned)u * rp]);
+            for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<ENT_NT(YM)>(at_off(eb1, (unsigned)lane + (unsigned)u * rp));
         }
         for (int n0 = 0; n0 < lw; n0 += PF) {
             if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
             v4u en4[PF / 2];
 #pragma unroll
-            for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<ENT_NT(YM)>(&eb[eo + (unsigned)u * rp]);
+            for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<ENT_NT(YM)>(at_off(eb, eo + (unsigned)u * rp));
             v2u eq[PF];
 #pragma unroll
             for (int u = 0; u < PF / 2; ++u) { eq[2 * u].x = eq4[u].x; eq[2 * u].y = eq4[u].y; eq[2 * u + 1].x = eq4[u].z; eq[2 * u + 1].y = eq4[u].w; }
