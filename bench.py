@@ -292,8 +292,12 @@ def main():
             b.set_max_workgroups(args.max_workgroups)
         batches.append(b)
     prepared = ca.CvoBatch.prepare_pairs([(fx, ff, mx, mf) for (_, fx, ff, mx, mf) in pairs]) if pairs else None
-    for b in batches:
-        if prepared:
+    distinct = bool(os.environ.get("CVO_BENCH_DISTINCT"))      # experiment: every batch object its own set of pairs (object i: the set that starts at pair first_pair + i * n)
+    for bi, b in enumerate(batches):
+        if prepared and distinct and bi > 0:
+            other = generate_pairs(first_pair + bi * n_mine, n_mine, 1)   # in this process: the GPU is initialised, no fork
+            b.set_pairs(ca.CvoBatch.prepare_pairs([(fx, ff, mx, mf) for (_, fx, ff, mx, mf) in other]))
+        elif prepared:
             b.set_pairs(prepared)                               # cvo_batch_set_pairs: one hand-over for the whole batch
     batch = batches[0]
 
