@@ -733,6 +733,13 @@ struct Engine {
                 }
                 order = o2;
             }
+            if (mode >= 20 && mode < 100) {                                                // experiment: K = mode - 20 classes instead of 8 (position p <- chunk p % K, its (p / K)-th pair)
+                const int Kc = std::max(1, std::min(n, mode - 20));
+                std::vector<int> first(Kc + 1, 0), o2(n);
+                for (int c = 0; c < Kc; ++c) first[c + 1] = first[c] + n / Kc + (c < n % Kc ? 1 : 0);
+                for (int p = 0; p < n; ++p) o2[p] = order[first[p % Kc] + p / Kc];
+                order = o2;
+            }
             if (mode == 6) { std::vector<int> o2; const int nb8 = (n + 7) / 8; for (int i = 0, j = nb8 - 1; i <= j; ++i, --j) { for (int q = 8 * i; q < std::min(n, 8 * i + 8); ++q) o2.push_back(order[q]); if (i != j) for (int q = 8 * j; q < std::min(n, 8 * j + 8); ++q) o2.push_back(order[q]); } order = o2; }   // eight heavy, eight light, ...
             if (mode >= 7 && mode < 10) { unsigned st = 12345u * (unsigned)mode; for (int i = n - 1; i > 0; --i) { st = st * 1664525u + 1013904223u; std::swap(order[i], order[(st >> 8) % (unsigned)(i + 1)]); } }   // shuffles
         }

@@ -56,7 +56,7 @@ def _pairs(n, seed0, lo=260, step=41):
     return out
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "4", "5", "8", "10", "11"])
+@pytest.mark.parametrize("mode", ["1", "2", "4", "5", "8", "10", "11", "23", "36"])
 def test_slot_per_pair_launch_is_indifferent_to_the_order(hiplib, mode):
     pairs = _pairs(19, 4100)                                         # 19: the eighths of the ranking have 3,3,3,2,2,2,2,2 pairs
     want = _run(hiplib, pairs, 1, CVO_HIP_ORDER_PAIRS="0")
