@@ -703,12 +703,14 @@ struct Engine {
         // Which pair a position of the launch (a slot; a pull from the pair queue) works on.  A pair's time is its cost per iteration -- which
         // follows the number of neighbours, i.e. the density of its clouds: mean 1/z^2 explains 0.9 of it on the bench's pairs, the iteration
         // count next to nothing -- so the pairs are ranked by that (Cloud::cost_hint, a sample of the points taken at the hand-over), and
-        //  * a launch with a slot per pair gives the positions b, b + 8, b + 16, ... -- workgroups that share an XCD and its 4 MiB L2 (blocks are
-        //    dealt round-robin over the 8 XCDs; which XCD block 0 gets changes from launch to launch) -- pairs of SIMILAR density: the c-th
-        //    eighth of the ranking goes to the positions = c (mod 8).  The lists and nonzero records of a dense pair stream through L2 every
-        //    iteration (2-3 MB), those of a sparse pair or of a late iteration fit into a CU's share of it (100-200 KB): mixed evenly, the
-        //    streams evict everybody's lists in every XCD.  Measured on four sets of 64 pairs, default run: +5.3 ... +6.4 % over index order,
-        //    while the evenly mixed orders (densest first, eight heavy / eight light) lose 2 ... 13 % (profiles/r03_pair_order_*.txt);
+        //  * a launch with a slot per pair gives the positions b, b + 8, b + 16, ... -- workgroups that share an XCD: block p of a launch runs on XCD
+        //    (h + p) mod 8, h fixed per stream and different from stream to stream (scripts/micro/xcc_map.hip) -- pairs of SIMILAR density: the c-th
+        //    eighth of the ranking goes to the positions = c (mod 8).  With eight streams the launches then form a Latin square over the XCDs: every
+        //    XCD hosts every density class, each from another stream, eight pairs of one class at a time -- equal work per XCD, and the eight CUs a
+        //    class leaves come free together for the next launch's eight blocks on that XCD.  Measured: +5.3 ... +6.4 % over index order on four sets
+        //    of 64 pairs, +11 % with 512 different pairs in flight; evenly mixed orders (densest first, eight heavy / eight light) lose 2 ... 13 %,
+        //    2 / 4 / 16 / 32 classes instead of 8 lose 4 / 2 / 13 / 22 %, and launches that disagree on the classes' positions lose 35 %
+        //    (profiles/r03_pair_order_*.txt, r03_distinct_sets_ab.txt, r03_class_count_sweep.txt, r03_class_shift_across_handles.txt);
         //  * a launch with fewer slots than pairs hands them out densest first: the long pairs start first and the launch's last ones are
         //    short (+5 ... 13 % on the config-5 shape, 64 pairs on 10 slots).
         // Results stay indexed by pair.  CVO_HIP_ORDER_PAIRS: 0 index order, 1 this rule (default); 2 ... experiment orders (below).
