@@ -186,7 +186,8 @@ SlotBook& slot_book() { static SlotBook b; return b; }
 // Adoption (cvo_kernels.hip: finished workgroups help with pairs that still run): a workgroup only offers its help when nothing is
 // queued on the device, i.e. when every workgroup the library has submitted there has started.  Two counters per device: submitted
 // (host-written before each launch, pinned host memory the kernels read) and started (device memory, bumped by every workgroup).
-struct AdoptCounters { int device = -1; unsigned* submitted_host = nullptr; unsigned* submitted_dev = nullptr; unsigned* started_dev = nullptr; };
+struct AdoptCounters { int device = -1; unsigned* submitted_host = nullptr; unsigned* submitted_dev = nullptr; unsigned* started_dev = nullptr;
+                       int in_flight = 0; };                         // adoption launches submitted and not yet waited for (under adopt_submit_mutex)
 AdoptCounters* adopt_counters(int device) {                          // null when they cannot be made: launches then run without adoption
     static std::mutex mu; static std::vector<AdoptCounters*> all;
     std::lock_guard<std::mutex> lk(mu);
@@ -208,6 +209,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
+    AdoptCounters* adopt_counted = nullptr;   // this handle's last launch is counted in AdoptCounters::in_flight until it has been waited for
     bool wide_waves = true;          // CVO_HIP_WIDE=0: plane-layout launches run the two-waves-per-SIMD build as well
     bool skin_auto = true;           // the list radius margin follows the layout: 0.35 with the cloud resident as 16-byte points (3 k-point shape), 0.30 otherwise -- measured with
                                      // the device full (profiles/r03_skin_sweep.txt): a cull costs LDS and issue time only, a longer list costs memory traffic, and that is dearer
@@ -806,10 +808,10 @@ struct Engine {
         if (skin_auto) Pl.skin = y_mode == 1 ? 0.35f : 0.30f;
         if (ac) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
             std::lock_guard<std::mutex> lk(adopt_submit_mutex());
-            *ac->submitted_host += (unsigned)grid;
+            *ac->submitted_host += (unsigned)grid; ac->in_flight += 1; adopt_counted = ac;
             e = K->launch(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl,
                              ac->submitted_dev, ac->started_dev, rawtab);
-            if (e != hipSuccess) *ac->submitted_host -= (unsigned)grid;
+            if (e != hipSuccess) { *ac->submitted_host -= (unsigned)grid; ac->in_flight -= 1; adopt_counted = nullptr; }
         } else {
             e = K->launch(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl, nullptr, nullptr, rawtab);
         }
@@ -854,6 +856,17 @@ struct Engine {
         if (!launched) return fail(CVO_ERR_INVALID, "no launch to wait for");
         const hipError_t es = hipStreamSynchronize(last_stream);
         release_slots();                                             // the launch has left the device, whatever it returned
+        if (adopt_counted) {
+            // "Nothing queued on the device" compares two counters that only adoption launches feed.  Should they ever disagree with nothing in flight
+            // (a launch that did not start all its workgroups), helpers would never offer themselves again in this process: with the last adoption launch
+            // waited for, the submitted count is set to what has started.
+            std::lock_guard<std::mutex> lk(adopt_submit_mutex());
+            AdoptCounters* ac = adopt_counted; adopt_counted = nullptr;
+            if (--ac->in_flight == 0 && es == hipSuccess) {
+                unsigned started = 0;
+                if (hipMemcpy(&started, ac->started_dev, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && started != *ac->submitted_host) *ac->submitted_host = started;
+            }
+        }
         if (es != hipSuccess) return fail(CVO_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(es));
         HIP_TRY(hipEventElapsedTime(&last_ms, ev0, ev1));
         return CVO_OK;
