@@ -446,10 +446,23 @@ def main():
         for b in batches:
             b.set_tail_scores(tail)
 
+        def pick_of(busy_list):
+            """the main loop's policy (pick): a free object, else whichever launch in flight has completed, else the oldest"""
+            for k in range(depth):
+                if k not in busy_list:
+                    return k
+            if args.reuse == "any":
+                t_poll = time.perf_counter()
+                while time.perf_counter() - t_poll < 0.05:
+                    for k in busy_list:
+                        if batches[k].done():
+                            return k
+            return busy_list[0]
+
         def step_scored(i):
-            bi = i % depth
+            bi = pick_of(scored)
             if bi in scored:
-                scored.remove(bi); batches[bi].wait(); batches[bi].innerproduct_results(n)
+                scored.remove(bi); batches[bi].wait(); batches[bi].innerproduct_results_raw(n)   # the C call: the scores are in the caller's array (no per-pair Python objects in the loop)
             b = batches[bi]
             b.reset_states(); b.align_async(n)
             if not tail:
@@ -459,7 +472,7 @@ def main():
         def drain_scored():
             last = None
             while scored:
-                bi = scored.pop(0); batches[bi].wait(); last = batches[bi].innerproduct_results(n)
+                bi = scored.pop(0); batches[bi].wait(); last = batches[bi].innerproduct_results_raw(n)
             return last
 
         for i in range(depth):
@@ -479,7 +492,7 @@ def main():
                                        "cull, the self products from the clouds' tables); the score kernel only for what a workgroup could not answer" if tail else
                                        "one score launch per step queued behind the align launch"),
                        "pairs_fully_answered_in_the_tail": int(sum(1 for m in answered if m == 31)),
-                       "mean_cos_angle": float(np.mean([r["cos_angle"] for r in last_scores]))}
+                       "mean_cos_angle": float(np.mean([o.cos_angle for o in last_scores]))}
         batch.reset_states(); batch.align_async(n); batch.wait()       # leave batch 0 as the timed region left it
 
     # PCIe-inclusive rate, for the record (never `value`): every step first hands its 64 pairs over as host buffers in the
@@ -490,7 +503,7 @@ def main():
         busy = []
 
         def step_upload(i):
-            bi = i % depth
+            bi = pick_of(busy) if with_scores is not None else i % depth
             if bi in busy:
                 busy.remove(bi); batches[bi].wait()
             b = batches[bi]

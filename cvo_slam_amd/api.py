@@ -723,10 +723,15 @@ class CvoBatch:
     def enqueue_innerproduct(self, n: int):
         _check(self.L.cvo_batch_enqueue_innerproduct(self.h, n))
 
-    def innerproduct_results(self, n: int):
-        """One dict per pair with the fields of `compute_innerproduct` (cvo.cpp:475-503), tran = the pair's own align() result."""
+    def innerproduct_results_raw(self, n: int):
+        """cvo_batch_innerproduct_results into a ctypes array of TrackScores: the C call alone, without the per-pair Python objects below."""
         out = (TrackScores * n)()
         _check(self.L.cvo_batch_innerproduct_results(self.h, n, out))
+        return out
+
+    def innerproduct_results(self, n: int):
+        """One dict per pair with the fields of `compute_innerproduct` (cvo.cpp:475-503), tran = the pair's own align() result."""
+        out = self.innerproduct_results_raw(n)
         tup = lambda r: (r.value, r.num, r.num_e)
         return [dict(inn_pre=tup(o.inn_pre), inn_post=tup(o.inn_post), inn_fixed_pcd=tup(o.inn_fixed_pcd), inn_moving_pcd=tup(o.inn_moving_pcd),
                      post_hessian=np.array(o.post_hessian[:]).reshape(6, 6), inliers=o.inliers, cos_angle=o.cos_angle) for o in out]
