@@ -12,7 +12,9 @@ every rank owns its own 64 pairs (weak scaling: BASELINE config 3 at N=1, config
 = 512 pairs at N=8); the only collective is an RCCL all-gather of the 64-byte
 result records.  Rank 0 prints one JSON line.
 
-Launch: python bench.py --gpus 1            (driver: torch.distributed.run for N>1)
+Launch: python bench.py --gpus N            N > 1 without RANK in the environment: this process starts the N ranks itself (child
+                                            processes, one per GPU, rendezvous on 127.0.0.1) and passes rank 0's line through;
+                                            under torch.distributed.run (RANK set) it is one of the ranks.
 """
 from __future__ import annotations
 
@@ -215,6 +217,46 @@ def latency_probe(ca, pairs, device):
             "lc_batch_align_ms": med(la), "lc_batch_score_block_ms": med(ls), "note": "host wall time per call, median of 5, automatic workgroup count"}
 
 
+def launch_ranks(n: int, argv, collect_stdout: bool = False) -> int:
+    """`bench.py --gpus N` invoked bare (no RANK in the environment): start the N ranks as CHILD processes of this one -- which has not
+    touched the GPU and never will --, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
+    torch.distributed.run sets them.  Rank 0 writes the JSON line to this process's stdout; the other ranks' stdout goes to stderr.
+    Returns the largest exit status; when a rank fails the others get ten seconds, then they are ended (by PID)."""
+    import socket
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "GROUP_RANK": "0", "NNODES": "1",
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "CVO_BENCH_LAUNCHED_BY": "bench.py"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if collect_stdout else (None if r == 0 else sys.stderr)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out, text=collect_stdout or None))
+    print(f"[bench] started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    rcs = [None] * n
+    t_fail = None
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rc = pr.poll()
+                if rc is not None:
+                    rcs[i] = rc
+                    if rc != 0 and t_fail is None:
+                        t_fail = time.time()
+                        print(f"[bench] rank {i} exited with status {rc}", file=sys.stderr, flush=True)
+        if t_fail is not None and time.time() - t_fail > 10.0:
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    pr.kill(); rcs[i] = pr.wait() or 1
+        time.sleep(0.05)
+    if collect_stdout:
+        for pr in procs:
+            sys.stdout.write(pr.stdout.read())
+        sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,7 +274,10 @@ def main():
     ap.add_argument("--reuse", choices=("any", "oldest"), default="any", help="which batch object in flight the next step reuses: whichever has completed first (cvo_batch_done), or strictly the oldest")
     ap.add_argument("--total-pairs", type=int, default=0, help="pairs per step over ALL ranks, dealt in contiguous blocks (cvo_shard_range: blocks may differ by one, the gather pads); 0 = --pairs per rank")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
+    ap.add_argument("--dry-launch", action="store_true", help="every rank prints its block of the step's pairs (cvo_shard_range) as one JSON line and exits: no GPU needed")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:      # the bare invocation: this process becomes the launcher of the N ranks (before anything imports torch or touches the GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], collect_stdout=args.dry_launch))
     if args.shape == "eth3d":      # BASELINE config 5 defaults: 4 workgroups per pair, 4 launches side by side, 64 workgroups (16 pair slots) each
         dflt = ap.parse_args([])
         if args.workgroups == dflt.workgroups: args.workgroups = 4
@@ -244,7 +289,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     global _SHAPE
@@ -256,9 +301,19 @@ def main():
     first_pair, n_mine = rank * base + min(rank, rem), base + (1 if rank < rem else 0)
     n_block = (total_pairs + world - 1) // world
     first_shard = first_pair
+    if args.dry_launch:
+        from cvo_slam_amd import api
+        blk = list(api.shard_range(total_pairs, rank, world))            # cvo_shard_range / cvo_shard_block: arithmetic of the C ABI, no device needed
+        assert blk == list(range(first_pair, first_pair + n_mine)) and api.shard_block(total_pairs, world) == n_block
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world, "first_pair": first_pair, "pairs": n_mine,
+                          "block_records": n_block, "total_pairs": total_pairs, "launched_by": os.environ.get("CVO_BENCH_LAUNCHED_BY", "external launcher")}), flush=True)
+        return
     first_pair += int(os.environ.get("CVO_BENCH_PAIR_OFFSET", "0"))      # experiments: another set of synthetic pairs (the metric's set starts at 0)
     # host-side input generation first (forks; no GPU state yet)
     pairs = generate_pairs(first_pair, n_mine, args.gen_workers) if n_mine else []
+    # the other sets of the `distinct_pairs` secondary loop (every batch object in flight its own pairs: streams x pairs different pairs), rendered here too
+    want_distinct = world == 1 and not args.no_latency_probe and n_mine > 0 and not os.environ.get("CVO_BENCH_NO_DISTINCT_LOOP")
+    other_sets = generate_pairs(first_pair + n_mine, (max(1, args.streams) - 1) * n_mine, args.gen_workers) if want_distinct and args.streams > 1 else []
     if rank == 0:
         print(f"[bench] generated {len(pairs)} pairs per rank; starting GPU work", file=sys.stderr, flush=True)
 
@@ -312,6 +367,7 @@ def main():
     # travels through torch.distributed once.  CVO_BENCH_GATHER=torch (or a non-RCCL backend) gathers with torch.distributed
     # after the wait instead.
     comm = None
+    comm_ranks = None                              # ranks in the C ABI's RCCL communicator (None: no communicator was made)
     gather_mode = "none"
     if world > 1:
         gather_mode = "torch"
@@ -335,6 +391,8 @@ def main():
                 dist.all_reduce(ok2, op=dist.ReduceOp.MIN)             # every rank has its communicator, or nobody uses one
                 if int(ok2.item()) == 1:
                     gather_mode = "abi"
+                    comm_ranks, comm_rank = comm.info()                # ncclCommCount / ncclCommUserRank: what the RCCL communicator itself reports
+                    assert (comm_ranks, comm_rank) == (world, rank), (comm_ranks, comm_rank, world, rank)
                 else:
                     if comm is not None:
                         comm.close()
@@ -362,7 +420,11 @@ def main():
                 gathered = recvs[bi]                                           # already there: the all-gather ran behind the kernel
             else:                                                              # rehearsal backends: the rank's padded block through torch.distributed
                 torch.cuda.synchronize()
-                gathered = shard.gather_blocks(shard.device_view(send_ptr[bi], n_block), world)
+                if send_ptr[bi]:
+                    mine_blk = shard.device_view(send_ptr[bi], n_block)
+                else:
+                    mine_blk = torch.zeros((n_block, shard.RESULT_FLOATS), dtype=torch.float32, device="cuda"); mine_blk[:, 15] = float(api.CVO_ERR_RANK_FAILED)
+                gathered = shard.gather_blocks(mine_blk, world)
 
     def pick():
         """The batch object the next step goes to: a free one, else whichever launch in flight has completed (cvo_batch_done, oldest first:
@@ -394,7 +456,10 @@ def main():
         if comm is not None:
             b.gather_results_padded(comm, n, n_block, recvs[bi].data_ptr(), launch_status[bi])   # ONE ncclAllGather on the launch's stream
         elif world > 1:
-            send_ptr[bi] = b.padded_records(n, n_block, launch_status[bi])
+            try:
+                send_ptr[bi] = b.padded_records(n, n_block, launch_status[bi])
+            except ca.CvoError as e:               # this rank cannot make its block: it still enters the collective, with failure records
+                send_ptr[bi] = 0; launch_status[bi] = launch_status[bi] or e.code
         inflight.append(bi)
 
     def drain():
@@ -424,6 +489,7 @@ def main():
     drain()
     sync_all()
     elapsed = time.perf_counter() - t0
+    elapsed_rank = elapsed
     assert len(kernel_ms) == args.steps
     if n == 0:                                     # a rank without pairs (fewer pairs than ranks): it only takes part in the gathers
         kernel_ms[:] = [0.0]
@@ -528,6 +594,41 @@ def main():
                        "note": "clouds cross the boundary as host buffers every step (cvo_batch_set_pairs: the arrays are copied as they are into a pinned block, "
                                "the align launch that follows builds the device layout itself, reading the block over PCIe)"}
         batch.reset_states(); batch.align_async(n); batch.wait()
+    # The timed region's eight batch objects hold the SAME 64 pairs (every step aligns the batch BASELINE config 3 names).  For the record: the same loop with
+    # every object in flight on its own set -- streams x pairs different pairs on the device at once (the launches then do not fall into step with each other).
+    with_distinct = None
+    if want_distinct and other_sets and with_scores is not None:
+        for bi in range(1, depth):
+            sl = other_sets[(bi - 1) * n:(bi) * n]
+            batches[bi].set_pairs(ca.CvoBatch.prepare_pairs([(fx, ff, mx, mf) for (_, fx, ff, mx, mf) in sl]))
+        k4 = max(depth, args.steps)
+        busy4 = []
+
+        def step_distinct(i):
+            bi = pick_of(busy4)
+            if bi in busy4:
+                busy4.remove(bi); batches[bi].wait()
+            batches[bi].reset_states(); batches[bi].align_async(n)
+            busy4.append(bi)
+
+        def drain_distinct():
+            while busy4:
+                batches[busy4.pop(0)].wait()
+            torch.cuda.synchronize()
+
+        for i in range(depth):
+            step_distinct(i)
+        drain_distinct()
+        t4 = time.perf_counter()
+        for i in range(k4):
+            step_distinct(i)
+        drain_distinct()
+        el4 = time.perf_counter() - t4
+        bad4 = [r["status"] for b in batches for r in b.wait(n) if r["status"] != 0]
+        with_distinct = {"value": n * k4 / el4, "unit": "alignments/s", "steps": k4, "ms_per_step": 1e3 * el4 / k4, "distinct_pairs_in_flight": depth * n, "errors": len(bad4),
+                         "note": "every batch object in flight aligns its own set of pairs (object i: pairs i*n .. i*n+n-1 of the seeded generator); the timed region's objects all hold set 0"}
+        for bi in range(1, depth):
+            batches[bi].set_pairs(prepared)
     if rank == 0 and os.environ.get("CVO_BENCH_PHASES"):
         ph = batch.last_phase_seconds(); its_all = sum(r["iterations_run"] for r in results)
         print("[bench] phase us/iteration under load (workgroup 0 of every pair of the last launch): " +
@@ -590,7 +691,9 @@ def main():
             "metric": "CVO frame-pair alignments/sec (640x480, ~3k pts/cloud)",
             "value": value, "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "timed_region_s": elapsed,
+            "ranks_in_communicator": comm_ranks if world > 1 else 1,
+            "gather": ("rccl" if gather_mode == "abi" else ("torch" if backend == "nccl" else backend)) if world > 1 else "none",
             "config": {"workload": f"{n} independent synthetic {'640x480 TUM' if args.shape == 'tum' else '736x456 ETH3D'}-shape RGB-D pairs per GPU per step "
                                    f"(BASELINE config {'3' if args.shape == 'tum' else '5'}; {total_pairs} pairs per step at {world} GPU(s); config 4 = 512 pairs at 8 GPUs), "
                                    f"full align() from R=I,T=0,ell=0.15 to convergence",
@@ -622,9 +725,15 @@ def main():
                             "per_launch_achieved_GBs divides by one launch's own duration instead"},
             "with_score_block": with_scores,
             "with_host_upload": with_upload,
-            "work": {"executed_pair_tests_per_s": pair_tests / step_s if pair_tests else None,
+            "distinct_pairs": with_distinct,
+            "work": {"nonzeros_per_launch": float(info.get("nonzeros_total", 0)) or None,
+                     "valu_lane_instructions_per_nonzero": (64.0 * valu_instr / float(info["nonzeros_total"])) if (valu_instr and info.get("nonzeros_total")) else None,
+                     "executed_pair_tests_per_s": pair_tests / step_s if pair_tests else None,
                      "dense_pair_tests_per_s_equivalent": flops_launch / 8.0 / step_s,
-                     "note": "executed_pair_tests = list candidates the kernel evaluated with the reference's exact expression (all iterations of one step); the "
+                     "note": "nonzeros = members of the sparse kernel matrix A summed over all iterations of one step (what the reference's arithmetic is defined on: cvo.cpp:166-175, "
+                             "213-223, 282-306); valu_lane_instructions_per_nonzero = 64 x VALU wave-instructions of a launch (PMC) / those nonzeros -- the reference's float "
+                             "sequence needs about 190-220 of them for a member (DESIGN.md 4.1), the rest is candidates that are listed but no members, list upkeep, reductions; "
+                             "executed_pair_tests = list candidates the kernel evaluated with the reference's exact expression (all iterations of one step); the "
                              "dense equivalent counts the N*M tests per iteration the reference's radius search stands for (most are skipped by lists + box cull)"},
         }
         if world == 1 and not args.no_latency_probe:

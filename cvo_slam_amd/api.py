@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-CVO_OK, CVO_ERR_NOT_INITIALIZED, CVO_ERR_EMPTY_CLOUD, CVO_ERR_HIP, CVO_ERR_INVALID, CVO_ERR_NO_DEVICE, CVO_ERR_TIMEOUT, CVO_ERR_PADDING = range(8)
+CVO_OK, CVO_ERR_NOT_INITIALIZED, CVO_ERR_EMPTY_CLOUD, CVO_ERR_HIP, CVO_ERR_INVALID, CVO_ERR_NO_DEVICE, CVO_ERR_TIMEOUT, CVO_ERR_PADDING, CVO_ERR_RANK_FAILED = range(9)
 SLOT_FIXED, SLOT_MOVING, SLOT_PREVIOUS = 0, 1, 2
 RESULT_FLOATS = 16
 
@@ -91,10 +91,10 @@ ABI_SYMBOLS = [
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
     "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups", "cvo_batch_set_adoption", "cvo_batch_last_adoptions",
     "cvo_adaptive_default_params", "cvo_adaptive_align",
-    "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_batch_gather_results",
+    "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_comm_info", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
     "cvo_batch_set_pairs", "cvo_batch_result_records", "cvo_shard_block", "cvo_batch_gather_results_padded", "cvo_batch_padded_records",
-    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds",
+    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds", "cvo_batch_last_nonzeros",
 ]
 
 _lib = None
@@ -180,6 +180,7 @@ def load_library():
     L.cvo_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.cvo_comm_create_all.argtypes = [ip, C.c_int, C.POINTER(vp)]
     L.cvo_comm_destroy.argtypes = [vp]
+    L.cvo_comm_info.argtypes = [vp, ip, ip]
     L.cvo_batch_gather_results.argtypes = [vp, vp, C.c_int, vp]
     L.cvo_gather_results.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]
     L.cvo_multi_create.argtypes = [C.POINTER(Params), ip, C.c_int, C.c_int, C.POINTER(vp)]
@@ -200,6 +201,7 @@ def load_library():
     L.cvo_batch_set_tail_scores.argtypes = [vp, C.c_int]
     L.cvo_batch_last_tail_answers.argtypes = [vp, C.c_int, ip]
     L.cvo_batch_last_pair_seconds.argtypes = [vp, C.c_int, dp]
+    L.cvo_batch_last_nonzeros.argtypes = [vp, C.POINTER(C.c_longlong)]
     _lib = L
     return L
 
@@ -515,6 +517,12 @@ class CvoComm:
         assert len(unique_id) == COMM_ID_BYTES
         _check(self.L.cvo_comm_create(unique_id, n_ranks, rank, device, C.byref(self.h)))
 
+    def info(self):
+        """(ranks, rank) as the RCCL communicator reports them (ncclCommCount / ncclCommUserRank)."""
+        n = C.c_int(0); r = C.c_int(0)
+        _check(self.L.cvo_comm_info(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
     def close(self):
         if getattr(self, "h", None) and self.h.value:
             self.L.cvo_comm_destroy(self.h); self.h = C.c_void_p()
@@ -698,7 +706,9 @@ class CvoBatch:
     def last_launch(self):
         ms = C.c_float(0); it = C.c_longlong(0); ca = C.c_longlong(0)
         _check(self.L.cvo_batch_last_launch(self.h, C.byref(ms), C.byref(it), C.byref(ca)))
-        return dict(kernel_ms=ms.value, iterations_total=it.value, candidates_total=ca.value)
+        nz = C.c_longlong(0)
+        _check(self.L.cvo_batch_last_nonzeros(self.h, C.byref(nz)))
+        return dict(kernel_ms=ms.value, iterations_total=it.value, candidates_total=ca.value, nonzeros_total=nz.value)
 
     def last_phase_seconds(self):
         out = np.zeros(10); _check(self.L.cvo_batch_last_phase_seconds(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))

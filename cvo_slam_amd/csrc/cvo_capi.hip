@@ -1661,6 +1661,14 @@ int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_t
     if (candidates_total) *candidates_total = ca;
     return CVO_OK;
 }
+int cvo_batch_last_nonzeros(cvo_batch b, long long* nonzeros_total) {
+    if (!b || !nonzeros_total) return fail(CVO_ERR_INVALID, "null argument");
+    long long nz = 0;
+    const PairState* r = b->eng.results();
+    for (int i = 0; i < b->last_n; ++i) nz += r[i].nonzeros_total;
+    *nonzeros_total = nz;
+    return CVO_OK;
+}
 int cvo_batch_last_pair_seconds(cvo_batch b, int n, double* seconds) {
     if (!b || !seconds || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad argument");
     const PairState* r = b->eng.results();
@@ -1819,6 +1827,8 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
 };
 struct Id128 { char b[CVO_COMM_ID_BYTES]; };
 Rccl g_rccl;
@@ -1831,6 +1841,7 @@ int rccl_load() {
     CVO_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); CVO_RCCL_SYM(CommInitRank, "ncclCommInitRank"); CVO_RCCL_SYM(CommInitAll, "ncclCommInitAll");
     CVO_RCCL_SYM(CommDestroy, "ncclCommDestroy"); CVO_RCCL_SYM(AllGather, "ncclAllGather"); CVO_RCCL_SYM(GroupStart, "ncclGroupStart");
     CVO_RCCL_SYM(GroupEnd, "ncclGroupEnd"); CVO_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    CVO_RCCL_SYM(CommCount, "ncclCommCount"); CVO_RCCL_SYM(CommUserRank, "ncclCommUserRank");
 #undef CVO_RCCL_SYM
     g_rccl.lib = h;
     return CVO_OK;
@@ -1839,7 +1850,9 @@ int rccl_load() {
 constexpr int RCCL_FLOAT = 7;     // ncclFloat32 (rccl.h)
 }  // namespace
 
-struct cvo_comm_s { void* comm = nullptr; int n_ranks = 1, rank = 0, device = 0; DevBuf send; };
+// `send`: a block of records that all carry CVO_ERR_RANK_FAILED, made when the communicator is: what this rank contributes to a gather whose own block
+// could not be prepared (bad arguments, a buffer that would not grow, a fill kernel that would not launch) -- so that the rank still enters the collective.
+struct cvo_comm_s { void* comm = nullptr; int n_ranks = 1, rank = 0, device = 0; DevBuf send; int fallback_records = 0; };
 
 struct cvo_multi_s {
     int n_devices = 0, max_pairs = 0, last_n = 0;
@@ -1848,6 +1861,22 @@ struct cvo_multi_s {
     std::vector<cvo_comm> comms;
     std::vector<DevBuf> recv;
 };
+
+namespace {
+constexpr int COMM_FALLBACK_RECORDS = 1024;        // 64 KB; a gather of larger blocks grows it when it is first needed
+// (re)make the communicator's block of failure records; the device is current.  Not fatal when it cannot be made: the communicator works without it,
+// a failed prepare then returns without entering the collective (and says so).
+int comm_fallback_block(cvo_comm_s* c, int records) {
+    if (records <= c->fallback_records) return CVO_OK;
+    c->fallback_records = 0;
+    int rc = c->send.ensure(sizeof(float) * CVO_RESULT_FLOATS * (size_t)records); if (rc) return rc;
+    hipError_t e = cvohip::launch_fill_records(static_cast<float*>(c->send.p), 0, records, CVO_ERR_RANK_FAILED, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("failure-record block: ") + hipGetErrorString(e));
+    c->fallback_records = records;
+    return CVO_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -1872,6 +1901,7 @@ int cvo_comm_create(const char id[CVO_COMM_ID_BYTES], int n_ranks, int rank, int
     void* comm = nullptr;
     RCCL_TRY(g_rccl.CommInitRank(&comm, n_ranks, uid, rank));
     cvo_comm_s* c = new cvo_comm_s(); c->comm = comm; c->n_ranks = n_ranks; c->rank = rank; c->device = device;
+    (void)comm_fallback_block(c, COMM_FALLBACK_RECORDS);
     *out = c;
     return CVO_OK;
 }
@@ -1883,8 +1913,18 @@ int cvo_comm_create_all(const int* devices, int n_devices, cvo_comm* out) {
     RCCL_TRY(g_rccl.CommInitAll(comms.data(), n_devices, devices));
     for (int i = 0; i < n_devices; ++i) {
         cvo_comm_s* c = new cvo_comm_s(); c->comm = comms[i]; c->n_ranks = n_devices; c->rank = i; c->device = devices[i];
+        if (hipSetDevice(devices[i]) == hipSuccess) (void)comm_fallback_block(c, COMM_FALLBACK_RECORDS);
         out[i] = c;
     }
+    return CVO_OK;
+}
+// what the communicator itself says (ncclCommCount / ncclCommUserRank), not what it was asked for
+int cvo_comm_info(cvo_comm c, int* n_ranks, int* rank) {
+    if (!c || !c->comm) return fail(CVO_ERR_INVALID, "null communicator");
+    int n = 0, r = 0;
+    RCCL_TRY(g_rccl.CommCount(c->comm, &n)); RCCL_TRY(g_rccl.CommUserRank(c->comm, &r));
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
     return CVO_OK;
 }
 int cvo_comm_destroy(cvo_comm c) {
@@ -1897,12 +1937,23 @@ int cvo_comm_destroy(cvo_comm c) {
 }
 namespace {
 // Everything of a gather that can fail happens here, BEFORE the collective is entered: argument checks, the record block (growth,
-// padding / status records).  The all-gather itself is posted by gather_post and reads the block in stream order.
+// padding / status records).  The all-gather itself is posted by gather_post and reads the block in stream order.  When the preparation
+// fails, gather_fallback_plan points the plan at the communicator's block of CVO_ERR_RANK_FAILED records instead: the rank still enters the
+// collective (its peers read the failure in the gathered table instead of waiting for the rank forever) and the call returns the error.
 struct GatherPlan { hipStream_t s = nullptr; float* send = nullptr; };
 int gather_prepare(cvo_batch b, cvo_comm c, int n_valid, int n_block, int launch_status, void* recv_device, GatherPlan& plan) {
     if (!b || !c || !recv_device) return fail(CVO_ERR_INVALID, "bad gather arguments");
     if (c->device != b->eng.device) return fail(CVO_ERR_INVALID, "communicator and batch live on different devices");
     return b->eng.padded_records(n_valid, n_block, launch_status, b->last_n, &plan.s, &plan.send);
+}
+bool gather_fallback_plan(cvo_batch b, cvo_comm c, int n_block, void* recv_device, GatherPlan& plan) {
+    if (!c || !c->comm || !recv_device || n_block <= 0) return false;                 // nothing to enter the collective with
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    if (n_block > c->fallback_records && comm_fallback_block(c, n_block) != CVO_OK) return false;
+    // behind the rank's launch when there is one on this device (the peers' gathers of this step are ordered behind theirs), else the null stream
+    plan.s = (b && b->eng.device == c->device) ? (b->eng.launched ? b->eng.last_stream : b->eng.stream) : nullptr;
+    plan.send = static_cast<float*>(c->send.p);
+    return true;
 }
 int gather_post(cvo_comm c, int n_block, void* recv_device, const GatherPlan& plan) {
     RCCL_TRY(g_rccl.AllGather(plan.send, recv_device, (size_t)n_block * CVO_RESULT_FLOATS, RCCL_FLOAT, c->comm, plan.s));
@@ -1920,7 +1971,13 @@ int cvo_batch_padded_records(cvo_batch b, int n_valid, int n_block, int launch_s
 int cvo_batch_gather_results_padded(cvo_batch b, cvo_comm c, int n_valid, int n_block, int launch_status, void* recv_device) {
     int rc = rccl_load(); if (rc) return rc;
     GatherPlan plan;
-    rc = gather_prepare(b, c, n_valid, n_block, launch_status, recv_device, plan); if (rc) return rc;
+    rc = gather_prepare(b, c, n_valid, n_block, launch_status, recv_device, plan);
+    if (rc) {                                                       // the rank enters the collective all the same, with failure records
+        const std::string msg = g_err;
+        if (gather_fallback_plan(b, c, n_block, recv_device, plan) && gather_post(c, n_block, recv_device, plan) == CVO_OK)
+            return fail(rc, msg + " (collective entered with CVO_ERR_RANK_FAILED records)");
+        return fail(rc, msg + " (collective NOT entered)");
+    }
     return gather_post(c, n_block, recv_device, plan);
 }
 int cvo_batch_gather_results(cvo_batch b, cvo_comm c, int n, void* recv_device) {
@@ -1930,12 +1987,15 @@ int cvo_gather_results_padded(cvo_batch* batches, cvo_comm* comms, int n_devices
     if (!batches || !comms || !recv_device || !n_valid || n_devices <= 0) return fail(CVO_ERR_INVALID, "bad gather arguments");
     int rc = rccl_load(); if (rc) return rc;
     std::vector<GatherPlan> plans(n_devices);
+    int first_err = CVO_OK; std::string first_msg;
     for (int i = 0; i < n_devices; ++i) {                            // nothing can fail inside the RCCL group: a rank enqueued without its peers would wait for ever
         rc = gather_prepare(batches[i], comms[i], n_valid[i], n_block, launch_status ? launch_status[i] : CVO_OK, recv_device[i], plans[i]);
-        if (rc) return rc;
+        if (rc) {                                                   // this device sends failure records; the error is reported after the collective is posted
+            if (!first_err) { first_err = rc; first_msg = g_err + " (collective entered with CVO_ERR_RANK_FAILED records)"; }
+            if (!gather_fallback_plan(batches[i], comms[i], n_block, recv_device[i], plans[i])) return fail(rc, first_msg = g_err + " (collective NOT entered)");
+        }
     }
     RCCL_TRY(g_rccl.GroupStart());                                  // one process drives several ranks: their calls must be grouped
-    int first_err = CVO_OK; std::string first_msg;
     for (int i = 0; i < n_devices; ++i) {
         const int r = gather_post(comms[i], n_block, recv_device[i], plans[i]);
         if (r && !first_err) { first_err = r; first_msg = g_err; }

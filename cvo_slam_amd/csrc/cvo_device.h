@@ -41,6 +41,7 @@ struct PairState {
     int rebuilds;             // dense culls executed
     int dense_fallbacks;      // rebuilds whose candidates did not fit the lists (dense per-row path taken)
     long long candidates_total;
+    long long nonzeros_total; // nonzeros of A summed over the executed iterations (the reference's work: cvo.cpp:166-175 members, :282-306 terms)
     // wall time (100 MHz ticks) workgroup 0 of the pair spent per phase (slots as cvo_batch_last_phase_seconds documents them)
     unsigned long long clk_cycles, clk_ticks;   // shader-clock cycles and 100 MHz ticks workgroup 0 spent on the pair: cycles/ticks*100 MHz = clock
     unsigned long long phase_ticks[10];

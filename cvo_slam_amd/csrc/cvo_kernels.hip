@@ -123,6 +123,7 @@ struct __attribute__((aligned(16))) Shared {
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
     unsigned long long ticks[10];   // thread 0's time per phase (PairState::phase_ticks), summed over the pair's iterations
     unsigned long long cand_total;  // list candidates evaluated so far (PairState::candidates_total)
+    unsigned long long nnz_total;   // nonzeros of A so far (PairState::nonzeros_total)
 #ifdef CVO_KTRACE
     unsigned long long ksub[4];  // experiment builds: line-search walk, line-search reduction, epilogue scalar part, epilogue transform (ticks, this iteration)
 #endif
@@ -2119,7 +2120,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             sh->iter_at_break = k_join ? (int)__hip_atomic_load((const CVO_GLOBAL unsigned*)&st->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->iter;
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
             for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
-            sh->cand_total = 0;
+            sh->cand_total = 0; sh->nnz_total = 0;
             sh->P.skin = P.skin; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
@@ -2160,7 +2161,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             }
             CVO_PHASE(0);
             phase_candidates(Dp, ge, Ge, tgeo, y_lds, k);
-            if (tid == 0) atomicAdd(&sh->cand_total, (unsigned long long)sh->cand);
+            if (tid == 0) { atomicAdd(&sh->cand_total, (unsigned long long)sh->cand); atomicAdd(&sh->nnz_total, (unsigned long long)sh->nnz); }
             CVO_PHASE(1);
             if (sh->status != 0) break;
             phase_linesearch(Dp, ge, Ge, tgeo, y_lds, k);
@@ -2252,7 +2253,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             fin.rebuilds = sh->rebuilds;
             fin.joined_at = sh->joined_at;
             fin.dense_fallbacks = sh->dense_fallbacks;
-            fin.candidates_total = (long long)sh->cand_total;
+            fin.candidates_total = (long long)sh->cand_total; fin.nonzeros_total = (long long)sh->nnz_total;
             for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
             fin.phase_ticks[7] = sh->sub[0]; fin.phase_ticks[9] = sh->sub[1]; fin.phase_ticks[2] = sh->sub[2]; fin.phase_ticks[4] = sh->sub[3];
             fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0;

@@ -42,7 +42,9 @@ enum {
     CVO_ERR_INVALID = 4,          /* bad argument */
     CVO_ERR_NO_DEVICE = 5,        /* no gfx950 device: the library never falls back to the CPU */
     CVO_ERR_TIMEOUT = 6,          /* in-kernel inter-workgroup wait gave up */
-    CVO_ERR_PADDING = 7           /* status field of a gathered result record that stands for no pair (shard padding); never returned by a call */
+    CVO_ERR_PADDING = 7,          /* status field of a gathered result record that stands for no pair (shard padding); never returned by a call */
+    CVO_ERR_RANK_FAILED = 8       /* status field of the records a rank contributes to a gather when it could not prepare its own block (the rank's
+                                     call returned the cause); never returned by a call */
 };
 
 enum { CVO_SLOT_FIXED = 0, CVO_SLOT_MOVING = 1, CVO_SLOT_PREVIOUS = 2 };   /* cvo.hpp:91-94 */
@@ -263,6 +265,9 @@ int cvo_batch_wait(cvo_batch b, cvo_pair_result* results, int n);
 int cvo_batch_done(cvo_batch b, int* done);
 /* device time of the last launch in ms (HIP events on the launch stream), total loop trips it executed */
 int cvo_batch_last_launch(cvo_batch b, float* kernel_ms, long long* iterations_total, long long* candidates_total);
+/* nonzeros of the kernel matrix A (cvo.cpp:166-175) summed over every executed iteration of every pair of the last launch: the work the
+ * reference's arithmetic is defined on (bench.py prices the kernel's instructions per nonzero with it) */
+int cvo_batch_last_nonzeros(cvo_batch b, long long* nonzeros_total);
 /* where the last launch spent its time: seconds summed over pairs, as seen by workgroup 0 of each pair:
  * [0] transform + list upkeep (cull, sort, refine)   [1] candidate phase   [2] candidates: workgroup reduction (incl. waiting
  * for the slowest wave)   [3] line-search phase   [4] candidates: exchange between the pair's workgroups   [5] scalar epilogue
@@ -299,7 +304,11 @@ int cvo_batch_result_records(cvo_batch b, const void** records_device);
  * RULE: every rank enters the collective exactly once per step, whatever happened before.  A rank whose cvo_batch_align_async
  * failed passes that code as launch_status (n_valid is then ignored): all its records carry the status, its peers see it in the
  * gathered table instead of waiting for the rank forever.  A rank with no pairs (n_valid = 0) just sends padding.  Everything
- * that can fail inside the call (argument checks, buffer growth) happens before the collective is posted.
+ * that can fail inside the call (argument checks, buffer growth, the padding kernel) happens before the collective is posted, and a
+ * rank on which it does fail STILL posts the all-gather -- from a block of CVO_ERR_RANK_FAILED records the communicator has held since
+ * cvo_comm_create (1024 records; grown on demand) -- and then returns the error: its peers find status 8 in the gathered table
+ * (cvo_compact_records' first_error).  Only when even that block is unavailable does the call return without entering the collective;
+ * cvo_last_error() then ends in "(collective NOT entered)" and the peers have to be told out of band.
  * cvo_batch_gather_results(b, c, n, recv) is the n_valid = n_block = n form: n MUST be the same on every rank. */
 #define CVO_COMM_ID_BYTES 128
 typedef struct cvo_comm_s* cvo_comm;
@@ -308,6 +317,7 @@ int cvo_shard_block(int n_pairs_total, int n_ranks);                            
 int cvo_comm_unique_id(char id[CVO_COMM_ID_BYTES]);
 int cvo_comm_create(const char id[CVO_COMM_ID_BYTES], int n_ranks, int rank, int device, cvo_comm* out);
 int cvo_comm_create_all(const int* devices, int n_devices, cvo_comm* out /* n_devices handles */);
+int cvo_comm_info(cvo_comm c, int* n_ranks, int* rank);                                    /* ncclCommCount / ncclCommUserRank of the communicator */
 int cvo_comm_destroy(cvo_comm c);
 int cvo_batch_gather_results(cvo_batch b, cvo_comm c, int n, void* recv_device);
 int cvo_batch_gather_results_padded(cvo_batch b, cvo_comm c, int n_valid, int n_block, int launch_status, void* recv_device);

@@ -139,8 +139,27 @@ def test_padded_block_of_a_short_rank_and_status_records(hiplib):
     b2.gather_results_padded(comm, 0, 2, recv.data_ptr())
     torch.cuda.synchronize()
     assert np.all(recv.cpu().numpy()[:2, 15] == api.CVO_ERR_PADDING)
+    # a rank whose block cannot be prepared (it asks for a record no launch has written) returns the error AND has entered the collective:
+    # its peers find CVO_ERR_RANK_FAILED records in the gathered table instead of waiting for the rank forever
+    recv.fill_(-1.0)
+    with pytest.raises(ca.CvoError) as e2:
+        b2.gather_results_padded(comm, 1, 2, recv.data_ptr())
+    assert "collective entered" in str(e2.value)
+    torch.cuda.synchronize()
+    got = recv.cpu().numpy()
+    assert np.all(got[:2, 15] == api.CVO_ERR_RANK_FAILED) and np.all(got[:2, :15] == 0) and np.all(got[2:] == -1.0)
+    _, first_err = api.compact_records(got[:2], 2, 1)
+    assert first_err == api.CVO_ERR_RANK_FAILED
+    # the same for a block larger than the communicator's standing failure block (1024 records): it grows
+    big = torch.full((1500, api.RESULT_FLOATS), -1.0, dtype=torch.float32, device="cuda")
     with pytest.raises(ca.CvoError):
-        b2.gather_results_padded(comm, 1, 2, recv.data_ptr())         # asks for a record no launch has written
+        b.gather_results_padded(comm, len(pairs) + 1, 1500, big.data_ptr())   # more records than the last launch aligned
+    torch.cuda.synchronize()
+    assert np.all(big.cpu().numpy()[:, 15] == api.CVO_ERR_RANK_FAILED)
+    # and the rank is fine afterwards
+    b.reset_states(); b.align_async(len(pairs)); b.gather_results_padded(comm, len(pairs), len(pairs) + 1, recv.data_ptr())
+    res = b.wait(len(pairs)); got = recv.cpu().numpy()
+    np.testing.assert_array_equal(got[: len(pairs)], _records(res)); assert got[len(pairs), 15] == api.CVO_ERR_PADDING
     b.close(); b2.close(); comm.close()
 
 
