@@ -68,7 +68,7 @@ hipError_t launch_adaptive(const AdaptiveArgs& A, int iterations, hipStream_t st
 int adaptive_partial_records(int nf, int nm);
 hipError_t launch_selftest(int kind, const float* in, float* out, int n, hipStream_t s);
 hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
-                        double* out_pinned, hipStream_t stream);
+                        double* out_pinned, hipStream_t stream, unsigned* wgs_started, bool* sweep_submitted);
 }  // namespace cvohip
 
 using namespace cvohip;
@@ -147,7 +147,7 @@ DevParams to_dev(const cvo_params& p) {
     d.min_step = p.min_step; d.eps = p.eps; d.eps_2 = p.eps_2; d.max_iter = p.max_iter;
     d.skin = 0.25f;
     d.resort = 1;
-    d.adopt_kmax = 20;
+    d.adopt_kmax = 20; d.adopt_on = 0; d.adopt_inject = 0;
     d.colocate = 1;
     return d;
 }
@@ -186,8 +186,11 @@ SlotBook& slot_book() { static SlotBook b; return b; }
 // Adoption (cvo_kernels.hip: finished workgroups help with pairs that still run): a workgroup only offers its help when nothing is
 // queued on the device, i.e. when every workgroup the library has submitted there has started.  Two counters per device: submitted
 // (host-written before each launch, pinned host memory the kernels read) and started (device memory, bumped by every workgroup).
-struct AdoptCounters { int device = -1; unsigned* submitted_host = nullptr; unsigned* submitted_dev = nullptr; unsigned* started_dev = nullptr;
-                       int in_flight = 0; };                         // adoption launches submitted and not yet waited for (under adopt_submit_mutex)
+// EVERY align launch of the process counts (with or without adoption, cooperative, queue mode), and so does every score launch: those are
+// the kernels whose workgroups wait for a compute unit while persistent align workgroups hold them.  The two counters only ever move
+// together: a launch adds its grid to `submitted` before it is submitted (and takes it back when the submission fails), and every one of
+// its workgroups adds itself to `started` first thing -- there is nothing to re-synchronise and no host read of the device counter.
+struct AdoptCounters { int device = -1; unsigned* submitted_host = nullptr; unsigned* submitted_dev = nullptr; unsigned* started_dev = nullptr; };
 AdoptCounters* adopt_counters(int device) {                          // null when they cannot be made: launches then run without adoption
     static std::mutex mu; static std::vector<AdoptCounters*> all;
     std::lock_guard<std::mutex> lk(mu);
@@ -209,7 +212,6 @@ struct Engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
-    AdoptCounters* adopt_counted = nullptr;   // this handle's last launch is counted in AdoptCounters::in_flight until it has been waited for
     bool wide_waves = true;          // CVO_HIP_WIDE=0: plane-layout launches run the two-waves-per-SIMD build as well
     bool skin_auto = true;           // the list radius margin follows the layout: 0.35 with the cloud resident as 16-byte points (3 k-point shape), 0.30 otherwise -- measured with
                                      // the device full (profiles/r03_skin_sweep.txt): a cull costs LDS and issue time only, a longer list costs memory traffic, and that is dearer
@@ -280,6 +282,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_COLOCATE")) P.colocate = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_WIDE")) wide_waves = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_ADOPT_KMAX")) P.adopt_kmax = std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("CVO_HIP_ADOPT_INJECT")) P.adopt_inject = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_ADOPT")) adopt = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
@@ -660,7 +663,8 @@ struct Engine {
         // in LDS.  Every member keeps its lists and records in a region of its own, sized for the rows it owns when it joins (make_ctx:
         // 1 + 1/2 + 1/3 + 1/4 of the rows, each rounded up to blocks of 128), and the exchange area has room for four members
         // (cvo_kernels.hip: ADOPT_GMAX).
-        AdoptCounters* const ac = (adopt && G == 1 && slots == n && y_mode != 0) ? adopt_counters(device) : nullptr;
+        AdoptCounters* const qc = adopt_counters(device);                   // what is queued on the device: every launch counts (null: the counters could not be made)
+        AdoptCounters* const ac = (adopt && G == 1 && slots == n && y_mode != 0) ? qc : nullptr;
         const int gmax = align_adopt_gmax();                                 // the kernel's limit (ADOPT_GMAX)
         const int Gx = ac ? gmax : G;                                        // members a pair's exchange area has room for
         size_t member_rows = 0;                                              // rows of all member regions of a slot under adoption
@@ -806,12 +810,13 @@ struct Engine {
         hipError_t e;
         DevParams Pl = P;
         if (skin_auto) Pl.skin = y_mode == 1 ? 0.35f : 0.30f;
-        if (ac) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
+        Pl.adopt_on = ac ? 1 : 0;
+        if (qc) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
             std::lock_guard<std::mutex> lk(adopt_submit_mutex());
-            *ac->submitted_host += (unsigned)grid; ac->in_flight += 1; adopt_counted = ac;
+            *qc->submitted_host += (unsigned)grid;
             e = K->launch(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl,
-                             ac->submitted_dev, ac->started_dev, rawtab);
-            if (e != hipSuccess) { *ac->submitted_host -= (unsigned)grid; ac->in_flight -= 1; adopt_counted = nullptr; }
+                             qc->submitted_dev, qc->started_dev, rawtab);
+            if (e != hipSuccess) *qc->submitted_host -= (unsigned)grid;
         } else {
             e = K->launch(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl, nullptr, nullptr, rawtab);
         }
@@ -856,17 +861,6 @@ struct Engine {
         if (!launched) return fail(CVO_ERR_INVALID, "no launch to wait for");
         const hipError_t es = hipStreamSynchronize(last_stream);
         release_slots();                                             // the launch has left the device, whatever it returned
-        if (adopt_counted) {
-            // "Nothing queued on the device" compares two counters that only adoption launches feed.  Should they ever disagree with nothing in flight
-            // (a launch that did not start all its workgroups), helpers would never offer themselves again in this process: with the last adoption launch
-            // waited for, the submitted count is set to what has started.
-            std::lock_guard<std::mutex> lk(adopt_submit_mutex());
-            AdoptCounters* ac = adopt_counted; adopt_counted = nullptr;
-            if (--ac->in_flight == 0 && es == hipSuccess) {
-                unsigned started = 0;
-                if (hipMemcpy(&started, ac->started_dev, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && started != *ac->submitted_host) *ac->submitted_host = started;
-            }
-        }
         if (es != hipSuccess) return fail(CVO_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(es));
         HIP_TRY(hipEventElapsedTime(&last_ms, ev0, ev1));
         return CVO_OK;
@@ -951,7 +945,15 @@ struct Engine {
             }
             more = static_cast<const ScoreDesc*>(d_scoredescs.p);
         }
-        hipError_t e = launch_score(B, more, n, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), s);
+        hipError_t e;
+        if (AdoptCounters* const qc = adopt_counters(device)) {      // the score workgroups are queued work too: helpers of align launches in flight hold back for them
+            std::lock_guard<std::mutex> lk(adopt_submit_mutex());
+            const unsigned wgs = (unsigned)row_blocks * (unsigned)chunks * (unsigned)n;
+            *qc->submitted_host += wgs;
+            bool sweep_submitted = false;
+            e = launch_score(B, more, n, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), s, qc->started_dev, &sweep_submitted);
+            if (!sweep_submitted) *qc->submitted_host -= wgs;       // nothing of it will start
+        } else e = launch_score(B, more, n, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), s, nullptr, nullptr);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("score kernel launch: ") + hipGetErrorString(e));
         score_stream = s; score_pending = n;
         return CVO_OK;
@@ -1504,7 +1506,7 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
     A.trace = want_trace ? static_cast<AdaptiveRow*>(d_trace.p) : nullptr; A.trace_cap = want_trace ? trace_cap : 0; A.trace_len = static_cast<int*>(d_len.p);
     A.ell_min = ap.ell_min; A.dl_step = ap.dl_step;
     A.P.sigma = ap.sigma; A.P.sp_thres = ap.sp_thres; A.P.c = ap.c; A.P.d = ap.d; A.P.c_ell = ap.c_ell; A.P.c_sigma = ap.c_sigma;
-    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.colocate = 0;
+    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.colocate = 0;
     A.partials = static_cast<double*>(d_part.p);
     // a few iterations are queued at a time (five small kernels each, the rows of the sweeps spread over the device); kernels queued behind a
     // stop return at once, and the host looks at the stop flag between the chunks
@@ -1612,6 +1614,13 @@ int cvo_batch_last_adoptions(cvo_batch b, int* pairs_helped) {
     const PairState* r = b->eng.results(); int n = 0;
     for (int i = 0; i < b->last_n; ++i) n += r[i].joined_at > 0 ? 1 : 0;
     *pairs_helped = n; return CVO_OK;
+}
+int cvo_batch_last_adoption_retractions(cvo_batch b, int* retractions) {
+    if (!b || !retractions) return fail(CVO_ERR_INVALID, "null argument");
+    int rc = b->eng.wait(); if (rc) return rc;
+    const PairState* r = b->eng.results(); int n = 0;
+    for (int i = 0; i < b->last_n; ++i) n += r[i].adopt_retracted;
+    *retractions = n; return CVO_OK;
 }
 int cvo_batch_reset_states(cvo_batch b) { if (!b) return fail(CVO_ERR_INVALID, "null batch"); b->states_dirty = true; return CVO_OK; }
 

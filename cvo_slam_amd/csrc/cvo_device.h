@@ -24,6 +24,9 @@ struct DevParams {           // cvo.cpp:35-51
                              // L2 twice per iteration.  Takes a launch whose pair slots are a multiple of 8; 0 = consecutive blocks (four XCDs for G = 4)
     int adopt_kmax;          // adoption: a finished workgroup only offers its help to pairs with fewer iterations than this behind them (the heavy
                              // early iterations divide well between workgroups; the light late ones are bound by the iteration's fixed latency)
+    int adopt_on;            // set per launch by the host: finished workgroups of this launch may help with its pairs that still run (one workgroup and one slot per pair)
+    int adopt_inject;        // test knob (CVO_HIP_ADOPT_INJECT): 1 = a helper whose offer has been accepted leaves instead of confirming -- the owner must take the
+                             // acceptance back and carry on with the members it has
 };
 
 // per-pair state, read at kernel start and written back at the end (Q1, Q2)
@@ -38,6 +41,7 @@ struct PairState {
     int iterations_run;
     int status;
     int joined_at;            // iteration at which a finished workgroup of the launch joined this pair (adoption), 0 = none
+    int adopt_retracted;      // acceptances the owner took back because the helper did not confirm in time (adoption)
     int rebuilds;             // dense culls executed
     int dense_fallbacks;      // rebuilds whose candidates did not fit the lists (dense per-row path taken)
     long long candidates_total;

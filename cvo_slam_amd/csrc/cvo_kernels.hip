@@ -67,7 +67,8 @@ namespace CVO_KNS {
 #endif                            //  is an experiment knob: measured, no phase gets faster -- DESIGN.md "Measured in round 2")
 constexpr int BLOCK_MAX = CVO_BLOCK_MAX;
 constexpr int MAX_WAVES = BLOCK_MAX / 64;
-constexpr unsigned ADOPT_FREE = 0u, ADOPT_REQUEST = 1u, ADOPT_ACCEPT = 2u, ADOPT_CLOSED = 3u;   // states of a pair's adoption word (cvo_align_kernel)
+constexpr unsigned ADOPT_FREE = 0u, ADOPT_REQUEST = 1u, ADOPT_ACCEPT = 2u, ADOPT_CLOSED = 3u, ADOPT_CONFIRMED = 4u;   // states of a pair's adoption word (cvo_align_kernel)
+constexpr unsigned long long ADOPT_CONFIRM_TICKS = 5000ull;   // 50 us at 100 MHz: how long an owner waits for an accepted helper to confirm before it takes the acceptance back
 #ifndef CVO_ADOPT_GMAX
 #define CVO_ADOPT_GMAX 4
 #endif
@@ -111,6 +112,7 @@ struct __attribute__((aligned(16))) Shared {
     int adopt_req;         // a finished workgroup of the launch has asked to help with this pair (1 + its block index), seen by the epilogue
     unsigned adopt_k;      // iteration at which a helper joins the pair it adopted
     int joined_at;         // owner: iteration at which a helper joined this pair (0 = none)
+    int retracted;         // owner: acceptances taken back (the helper did not confirm in time)
     unsigned long long* adopt_word;   // this pair's adoption word in the launch's queue area, or null (no adoption for this pair / any more)
     int dense_fallbacks;
     int rebuild;           // this iteration rebuilds the candidate lists
@@ -867,7 +869,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh; uint16_t* rowlen = L.rowlen;
     const Ctx c = make_ctx(Dp, g, G);
-    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int nrows = c.nrows;
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
     const float Rb = r_c * (1.0f + sh->P.skin);
@@ -1822,9 +1824,24 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
     const bool dense = sh->dense_mode != 0;
     const bool own = g == 0;                                                            // the pair's first workgroup writes the answers
     // ---- fip(T moving, fixed) and the Hessian terms from the candidate lists
+    unsigned ep_pre = ep0 + 1u;                                                         // epoch of the last exchange below: consecutive exchanges alternate between the two buffers
     if (can) {
         transform_body_t<1>(c, L, sh, none, false);                                     // y = FINAL transform * p (cvo.cpp:485-487 with cvo.cpp:817); are the lists still valid for it?
-        if (sh->rebuild == 0) {
+        // The members of a pair do NOT all see the same answer: their lists may have been built under different margins (a member whose rows overflowed
+        // the launch's margin rebuilt them with SKIN_DENSE_SCENE, the others did not) and at different iterations, so one member's lists can be stale for
+        // the final transform while another's are not.  They exchange partial sums below, so they have to take the same branch: one more exchange, of the
+        // "my lists are stale" flags, and everybody walks only when nobody's are.  (One workgroup per pair: its own flag.)
+        bool lists_ok = sh->rebuild == 0;
+        if (G > 1) {
+            double fl[8] = {(tid == 0 && sh->rebuild != 0) ? 1.0 : 0.0, 0, 0, 0, 0, 0, 0, 0};
+            const double stale = tail_reduce8(fl, sh, c, G, g, ep0, tid, nwaves);
+            if (tid == 0) sh->cull_next = stale == 0.0 ? 1 : 0;                         // (a scratch word: idle outside a cull)
+            __syncthreads();
+            lists_ok = sh->cull_next != 0;
+            __syncthreads();
+        }
+        if (lists_ok) {
+            ep_pre = ep0 + 4u;
             double sumA = 0; int count = 0, hcount = 0; float H[21];
 #pragma unroll
             for (int q = 0; q < 21; ++q) H[q] = 0.f;
@@ -1864,16 +1881,16 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
             v[0] = sumA; v[1] = (double)count;
 #pragma unroll
             for (int q = 0; q < 6; ++q) v[2 + q] = (double)H[q];
-            double r0 = tail_reduce8(v, sh, c, G, g, ep0, tid, nwaves);
+            double r0 = tail_reduce8(v, sh, c, G, g, ep0 + 1u, tid, nwaves);
             if (own && tid < 2) { out[24 + tid] = r0; out[4 * 24 + tid] = (tid == 1) ? r0 : 0.0; }
             if (own && tid >= 2 && tid < 8) out[4 * 24 + tid] = r0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (double)H[6 + q];
-            r0 = tail_reduce8(v, sh, c, G, g, ep0 + 1u, tid, nwaves);
+            r0 = tail_reduce8(v, sh, c, G, g, ep0 + 2u, tid, nwaves);
             if (own && tid < 8) out[4 * 24 + 8 + tid] = r0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = q < 7 ? (double)H[14 + q] : ((dense && tid == 0) ? 1.0 : 0.0);
-            r0 = tail_reduce8(v, sh, c, G, g, ep0 + 2u, tid, nwaves);
+            r0 = tail_reduce8(v, sh, c, G, g, ep0 + 3u, tid, nwaves);
             if (own && tid < 7) out[4 * 24 + 16 + tid] = r0;
             const double no_lists = __shfl(r0, 7, 64);                                  // (wave 0 holds the totals; thread 0 decides)
             if (tid == 0 && no_lists == 0.0) answered |= TAIL_POST | TAIL_HESSIAN;
@@ -1921,7 +1938,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
                 }
             }
             double v[8] = {sumA, (double)count, (double)overflow, 0, 0, 0, 0, 0};
-            const double r0 = tail_reduce8(v, sh, c, G, g, ep0 + 3u, tid, nwaves);     // (with or without the lists of the first part: the members all take the same branches)
+            const double r0 = tail_reduce8(v, sh, c, G, g, ep_pre, tid, nwaves);       // (with or without the lists of the first part: the members all took the same branch)
             if (own && tid < 2) out[tid] = r0;
             const double ovf = __shfl(r0, 2, 64);                                       // lanes 0..7 of wave 0 hold the totals; thread 0 decides
             if (tid == 0 && ovf == 0.0) answered |= TAIL_PRE;
@@ -1976,10 +1993,11 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
         const int t = blockIdx.x >> 3;
         g = t % G; slot = (blockIdx.x & 7) + 8 * (t / G);
     }
+    // "is anything queued on the device?" (adoption): every workgroup the library submits counts itself as started, whatever kind of launch it belongs to
+    if (wgs_started != nullptr && tid == 0) atomicAdd(wgs_started, 1u);
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
     if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
-    const bool adopting = wgs_started != nullptr;                   // set by the host for launches of one workgroup and one slot per pair
-    if (adopting && tid == 0) atomicAdd(wgs_started, 1u);
+    const bool adopting = wgs_started != nullptr && P.adopt_on != 0;   // set by the host for launches of one workgroup and one slot per pair
     const int tgeo = pack_geometry(tile, rows_cap, y_cap);
     gu64* queue = (gu64*)queue_in;
 
@@ -2026,7 +2044,14 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                             for (;;) {                              // the owner answers in its next epilogue
                                 const unsigned long long x = __hip_atomic_load(&queue[1 + s2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                                 const unsigned st = (unsigned)(x >> 32) - launch_tag;
-                                if (st == ADOPT_ACCEPT) { got = 1; kj = (unsigned)x; break; }   // members after the join << 24 | this helper's index << 16 | iteration of the join
+                                if (st == ADOPT_ACCEPT) {              // payload: members after the join << 24 | this helper's index << 16 | iteration of the join
+                                    // confirm at once (a CAS: the owner takes the acceptance back when no confirmation comes, and only one of the two can win)
+                                    unsigned long long e = x;
+                                    if (P.adopt_inject != 1 &&
+                                        __hip_atomic_compare_exchange_strong(&queue[1 + s2], &e, ((unsigned long long)(launch_tag | ADOPT_CONFIRMED) << 32) | (unsigned)x,
+                                                                             __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = 1; kj = (unsigned)x; }
+                                    break;
+                                }
                                 if (st != ADOPT_REQUEST) break;     // the pair ended meanwhile
                                 if (__builtin_amdgcn_s_memrealtime() - t_start > 200000ull) {   // 2 ms: take the offer back -- unless it has just been accepted
                                     unsigned long long e = want;
@@ -2111,7 +2136,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             int rp, nr; pair_rows(nf, ge, Ge, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
             sh->ws_slot = k_join ? ps : slot;                         // (one slot per pair when workgroups help each other)
             store_ctx(Dp, ge, Ge);
-            sh->adopt_req = 0; sh->adopt_word = nullptr; sh->joined_at = 0;
+            sh->adopt_req = 0; sh->adopt_word = nullptr; sh->joined_at = 0; sh->retracted = 0;
             if (adopt_launch && !k_join) {                            // this pair may be helped: its word says so from now on
                 __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_FREE) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sh->adopt_word = (unsigned long long*)&queue[1 + slot];
@@ -2203,9 +2228,27 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                             unsigned long long e = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)(sh->adopt_req - 1);
                             const unsigned long long acc = ((unsigned long long)(launch_tag | ADOPT_ACCEPT) << 32) | ((unsigned)(Ge + 1) << 24) | ((unsigned)Ge << 16) | (unsigned)((k + 1) & 0xFFFF);
                             if (__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e, acc, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                g_next = Ge + 1;
-                                if (!sh->joined_at) sh->joined_at = k + 1;
-                                if (g_next >= ADOPT_GMAX) sh->adopt_word = nullptr;     // full: no more offers are looked at (the newcomer leaves the word as it is)
+                                // The helper polls this word and confirms within a microsecond or two (ACCEPT -> CONFIRMED, its CAS).  Only then does the pair count on
+                                // it: should no confirmation come (the helper is gone), the owner takes the acceptance back (ACCEPT -> FREE, its CAS -- one of the two
+                                // wins) and the pair carries on with the members it has, instead of waiting for a member that never sends its partial sums.
+                                bool joined = false;
+                                const unsigned long long t_acc = __builtin_amdgcn_s_memrealtime();
+                                for (;;) {
+                                    const unsigned long long x = __hip_atomic_load((gu64*)sh->adopt_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if ((unsigned)(x >> 32) != (launch_tag | ADOPT_ACCEPT)) { joined = true; break; }
+                                    if (__builtin_amdgcn_s_memrealtime() - t_acc > ADOPT_CONFIRM_TICKS) {
+                                        unsigned long long e2 = acc;
+                                        joined = !__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e2, ((unsigned long long)(launch_tag | ADOPT_FREE) << 32) | (unsigned)(k + 1),
+                                                                                        __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        break;
+                                    }
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
+                                if (joined) {
+                                    g_next = Ge + 1;
+                                    if (!sh->joined_at) sh->joined_at = k + 1;
+                                    if (g_next >= ADOPT_GMAX) sh->adopt_word = nullptr;     // full: no more offers are looked at (the newcomer leaves the word as it is)
+                                } else sh->retracted += 1;
                             }
                         }
                         if (g_next > 1) __hip_atomic_store(ctrl, ((unsigned long long)(launch_tag | (unsigned)((k + 1) & 0xFFFF)) << 32) | (unsigned)g_next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -2251,7 +2294,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             fin.iterations_run = k;
             fin.status = sh->status;
             fin.rebuilds = sh->rebuilds;
-            fin.joined_at = sh->joined_at;
+            fin.joined_at = sh->joined_at; fin.adopt_retracted = sh->retracted;
             fin.dense_fallbacks = sh->dense_fallbacks;
             fin.candidates_total = (long long)sh->cand_total; fin.nonzeros_total = (long long)sh->nnz_total;
             for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(64) void cvo_cloud_boxes_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, const ScoreDesc* __restrict__ more, DevParams P, double* __restrict__ partials) {
+__global__ __launch_bounds__(SCORE_BLOCK) void cvo_score_kernel(ScoreBatch B, const ScoreDesc* __restrict__ more, DevParams P, double* __restrict__ partials,
+                                                                unsigned* __restrict__ wgs_started) {
+    // adoption's "is anything queued on the device?" (cvo_capi.hip, AdoptCounters): this workgroup has started
+    if (wgs_started && threadIdx.x == 0) atomicAdd(wgs_started, 1u);
     const ScoreDesc& D = more ? more[blockIdx.z] : B.d[blockIdx.z];     // a tracker's score block travels in the kernel arguments, a batch's in HBM
     __shared__ __attribute__((aligned(16))) float lx[32 * SCORE_STAGE];
     __shared__ __attribute__((aligned(16))) float ly[32 * SCORE_STAGE];
@@ -305,10 +308,12 @@ int score_row_blocks(int na) { return (na + SCORE_BLOCK - 1) / SCORE_BLOCK; }
 
 // one launch for the whole batch of requests; out_pinned[request][24] is complete when the stream has drained
 hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
-                        double* out_pinned, hipStream_t stream) {
-    hipLaunchKernelGGL(cvo_score_kernel, dim3(row_blocks, chunks, nreq), dim3(SCORE_BLOCK), 0, stream, B, more, P, partials);
+                        double* out_pinned, hipStream_t stream, unsigned* wgs_started, bool* sweep_submitted) {
+    if (sweep_submitted) *sweep_submitted = false;
+    hipLaunchKernelGGL(cvo_score_kernel, dim3(row_blocks, chunks, nreq), dim3(SCORE_BLOCK), 0, stream, B, more, P, partials, wgs_started);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (sweep_submitted) *sweep_submitted = true;                   // its workgroups will count themselves as started
     hipLaunchKernelGGL(cvo_score_reduce_kernel, dim3(nreq), dim3(256), 0, stream, B, more, partials, row_blocks * chunks, out_pinned);
     return hipGetLastError();
 }

@@ -249,11 +249,15 @@ int cvo_batch_set_workgroups(cvo_batch b, int workgroups_per_pair /* 0 = auto: f
 int cvo_batch_set_max_workgroups(cvo_batch b, int max_workgroups);
 /* Adoption (off by default): in launches with one workgroup and one slot per pair, a workgroup that has finished its pair and finds
  * nothing queued on the device offers its help to a pair of the launch that still runs; from the next iteration on that pair runs on one
- * more workgroup (a pair can grow to four).  "Nothing queued" only counts launches of this library in this process that take part in
- * adoption.  Shortens the tail of a job whose alignments take different numbers of iterations (33 ... 150); the results are those of
- * any other workgroup count.  cvo_batch_last_adoptions: pairs of the last launch that were helped. */
+ * more workgroup (a pair can grow to four).  "Nothing queued" counts every align and score launch this library has submitted on the
+ * device in this process, whatever its kind (not other processes, not other libraries' kernels).  Shortens the tail of a job whose
+ * alignments take different numbers of iterations (33 ... 150); the results are those of any other workgroup count.
+ * A pair only counts on a helper that has CONFIRMED the acceptance of its offer; when no confirmation comes within 50 us the owner takes the
+ * acceptance back and carries on with the workgroups it has -- a helper that disappears cannot turn a healthy pair into CVO_ERR_TIMEOUT.
+ * cvo_batch_last_adoptions: pairs of the last launch that were helped; cvo_batch_last_adoption_retractions: acceptances taken back. */
 int cvo_batch_set_adoption(cvo_batch b, int on);
 int cvo_batch_last_adoptions(cvo_batch b, int* pairs_helped);
+int cvo_batch_last_adoption_retractions(cvo_batch b, int* retractions);
 /* restore every pair's (R,T,ell) to what set_pair/set_state last gave it (bench loops re-run the same inputs) */
 int cvo_batch_reset_states(cvo_batch b);
 /* enqueue one persistent launch aligning pairs [0, n_pairs) on `stream` (a hipStream_t, NULL = the batch's own); asynchronous */

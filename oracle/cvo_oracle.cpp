@@ -225,17 +225,29 @@ inline void radius_matches(const float* cloud, int n, const KdTree* tree, const 
     else std::stable_sort(out.begin(), out.end(), [](const Match& a, const Match& b) { return a.d2 < b.d2; });
 }
 
-// (f_a - f_b).squaredNorm() on fixed Matrix<float,5,1>: Eigen unrolled reduction of
-// length 5 = (t0+t1) + (t2 + (t3+t4)).
-inline float feat_d2(const float* fa, int na, int i, const float* fb, int nb, int j) {
-    float t[5];
-    for (int c = 0; c < 5; ++c) { float e = fa[c * na + i] - fb[c * nb + j]; t[c] = e * e; }
+// (f_a - f_b).squaredNorm() and f_a.dot(f_b) on fixed Matrix<float,5,1> (cvo.cpp:169, :662): an Eigen redux of length 5.
+// Eigen 3.3.7, Core/Redux.h: the packet type of a fixed size 5 is Packet4f (find_best_packet halves Packet8f until the size divides or
+// the half is itself), the traversal LinearVectorized with complete unrolling: predux(packet of t0..t3) + t4.  predux<Packet4f> is two
+// _mm_hadd_ps with SSE3 on, (t0+t1)+(t2+t3), and _mm_movehl_ps + _mm_add_ss without, (t0+t2)+(t1+t3) (arch/SSE/PacketMath.h).  A build
+// without vectorisation (EIGEN_DONT_VECTORIZE, or a target without SSE) takes redux_novec_unroller's binary split, (t0+t1)+(t2+(t3+t4)):
+// the BASE order here and in the HIP kernels.  order: 0 base, 1 hadd (ORC_VAR_FEAT_HADD), 2 movehl (ORC_VAR_FEAT_MOVEHL).
+// With features as the reference's generator makes them (8-bit B, G, R and half-integer gradients, pcd_generator.cpp:601-609) every term
+// is a multiple of 1/4 below 2^18 and every partial sum is exact in f32: all three orders give the same bits.  The bench's synthetic
+// pairs carry gradients of a float gray image, and there the order shows (tests/test_oracle_noise.py, tests/golden/noise_envelope.json).
+inline float redux5(const float (&t)[5], int order) {
+    if (order == 1) return ((t[0] + t[1]) + (t[2] + t[3])) + t[4];
+    if (order == 2) return ((t[0] + t[2]) + (t[1] + t[3])) + t[4];
     return (t[0] + t[1]) + (t[2] + (t[3] + t[4]));
 }
-inline float feat_dot(const float* fa, int na, int i, const float* fb, int nb, int j) {
+inline float feat_d2(const float* fa, int na, int i, const float* fb, int nb, int j, int order = 0) {
+    float t[5];
+    for (int c = 0; c < 5; ++c) { float e = fa[c * na + i] - fb[c * nb + j]; t[c] = e * e; }
+    return redux5(t, order);
+}
+inline float feat_dot(const float* fa, int na, int i, const float* fb, int nb, int j, int order = 0) {
     float t[5];
     for (int c = 0; c < 5; ++c) t[c] = fa[c * na + i] * fb[c * nb + j];
-    return (t[0] + t[1]) + (t[2] + (t[3] + t[4]));
+    return redux5(t, order);
 }
 
 }  // namespace
@@ -285,6 +297,7 @@ void se_kernel_clouds(orc_cvo* o, const float* a_xyz, const Cloud& A, const floa
                       std::vector<int>& rowptr, std::vector<int>& colv, std::vector<float>& valv) {
     const orc_params& P = o->p;
     const int N = A.n, M = B.n;
+    const int feat_order = (o->variant & ORC_VAR_FEAT_HADD) ? 1 : ((o->variant & ORC_VAR_FEAT_MOVEHL) ? 2 : 0);
     // float d2_thres = -2.0*l*l*log(sp_thres/s2);            cvo.cpp:125
     const float d2_thres = (float)(-2.0 * l * l * (double)std::log(P.sp_thres / s2));
     // float d2_c_thres = -2.0*c_ell*c_ell*log(sp_thres/c_sigma/c_sigma);   cvo.cpp:126
@@ -305,7 +318,7 @@ void se_kernel_clouds(orc_cvo* o, const float* a_xyz, const Cloud& A, const floa
             for (const Match& mt : ms) {
                 const float d2 = mt.d2;
                 if (d2 < d2_thres) {                                              // cvo.cpp:166
-                    const float d2_color = feat_d2(A.feat.data(), N, i, B.feat.data(), M, mt.j);   // cvo.cpp:169
+                    const float d2_color = feat_d2(A.feat.data(), N, i, B.feat.data(), M, mt.j, feat_order);   // cvo.cpp:169
                     if (d2_color < d2_c_thres) {                                  // cvo.cpp:171
                         const float k = (float)(s2 * std::exp(-d2 / (2.0 * l * l)));                         // cvo.cpp:172
                         const float ck = (float)(P.c_sigma * P.c_sigma * std::exp(-d2_color / (2.0 * P.c_ell * P.c_ell)));   // cvo.cpp:173
@@ -338,6 +351,45 @@ struct SweepTimer {   // the two sparse sweeps (compute_flow after se_kernel, co
     explicit SweepTimer(orc_cvo* p) : o(p) {}
     ~SweepTimer() { o->t_sec[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
+// One row of compute_flow: the f32 values of (1/c*Ai*cross_xy) and (1/d*Ai*diff_yx) (cvo.cpp:213-223), Ai = the row's nonzeros in column
+// order.  What Eigen 3.3.7 does with `scalar * MatrixXf(1,n) * MatrixXf(n,3)` (GeneralMatrixMatrix.h, generic_product_impl<..., GemmProduct>::evalTo):
+//   * n + 1 + 3 < 20 (EIGEN_GEMM_TO_COEFFBASED_THRESHOLD), i.e. rows of fewer than 16 nonzeros: the coefficient-based lazy product.  Its
+//     evaluator nests the left factor through nested_eval<Lhs, Dynamic>, which EVALUATES `1/c*Ai` into a temporary (the scalar is folded into
+//     every a_j first), and each of the three coefficients is (lhs.row(0).transpose().cwiseProduct(rhs.col(k))).sum(): a row block of a
+//     column-major matrix has no packet access, so the redux is DefaultTraversal -- sequential in j;
+//   * 16 nonzeros and more: general_matrix_matrix_product with actualAlpha = 1/c taken out of the expression by blas_traits.  The result
+//     has 3 columns, fewer than the kernel's nr = 4, and one row: gebp's "remaining columns, remaining rows" loop, C0 = sum_k A0*B_0 + C0
+//     sequential in k, then res += alpha*C0 -- alpha AFTER the sum.  (The compiler may contract the multiply-add: the FMA build.)
+// The base oracle and the HIP kernels: sequential, alpha after the sum, for every row.  Variants (ORC_VAR_ROW_*): LAZY16 = the rule above;
+// ALPHA_FIRST = alpha folded into a_j in every row; STRIDE4 / STRIDE8 = the sum as 4 / 8 strided partial sums and a horizontal add
+// ((p0+p1)+(p2+p3); 8: halves added first, like predux<Packet8f>) -- what a vectorising compiler allowed to re-associate (icpc's default
+// fp-model) or an Eigen with a packet redux on this path would produce.
+static void row_flow(const orc_cvo* o, int i, float inv_c, float inv_d, float (&rw)[3], float (&rv)[3]) {
+    const Cloud& X = *o->fixed;
+    const float* xi = &X.xyz[(size_t)i * 3];
+    const int e0 = o->A_rowptr[i], e1 = o->A_rowptr[i + 1], n = e1 - e0;
+    const bool alpha_first = (o->variant & ORC_VAR_ROW_ALPHA_FIRST) || ((o->variant & ORC_VAR_ROW_LAZY16) && n < 16);
+    const int stride = (o->variant & ORC_VAR_ROW_STRIDE8) ? 8 : ((o->variant & ORC_VAR_ROW_STRIDE4) ? 4 : 1);
+    float pw[8][3], pv[8][3];
+    for (int q = 0; q < 8; ++q) for (int k = 0; k < 3; ++k) { pw[q][k] = 0.f; pv[q][k] = 0.f; }
+    for (int e = e0; e < e1; ++e) {
+        const float* yj = &o->cloud_y[(size_t)o->A_col[e] * 3];
+        const float a = o->A_val[e];
+        const float aw = alpha_first ? inv_c * a : a, av = alpha_first ? inv_d * a : a;
+        float cr[3]; cross3(xi, yj, cr);                                          // cvo.cpp:216
+        const int q = (e - e0) % stride;
+        for (int k = 0; k < 3; ++k) { pw[q][k] += aw * cr[k]; pv[q][k] += av * (yj[k] - xi[k]); }   // cvo.cpp:217, 222-223
+    }
+    for (int k = 0; k < 3; ++k) {
+        float sw = pw[0][k], sv = pv[0][k];
+        if (stride == 4) { sw = (pw[0][k] + pw[1][k]) + (pw[2][k] + pw[3][k]); sv = (pv[0][k] + pv[1][k]) + (pv[2][k] + pv[3][k]); }
+        if (stride == 8) {
+            sw = ((pw[0][k] + pw[4][k]) + (pw[1][k] + pw[5][k])) + ((pw[2][k] + pw[6][k]) + (pw[3][k] + pw[7][k]));
+            sv = ((pv[0][k] + pv[4][k]) + (pv[1][k] + pv[5][k])) + ((pv[2][k] + pv[6][k]) + (pv[3][k] + pv[7][k]));
+        }
+        rw[k] = alpha_first ? sw : inv_c * sw; rv[k] = alpha_first ? sv : inv_d * sv;
+    }
+}
 void compute_flow(orc_cvo* o) {
     se_kernel(o, o->ell, o->p.sigma * o->p.sigma);                                // cvo.cpp:189
     SweepTimer sweep_timer(o);
@@ -351,15 +403,8 @@ void compute_flow(orc_cvo* o) {
         // mutex in whatever order the TBB workers arrive)
         std::vector<float> rw((size_t)N * 3), rv((size_t)N * 3);
         for (int i = 0; i < N; ++i) {
-            const float* xi = &X.xyz[(size_t)i * 3];
-            float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
-            for (int e = o->A_rowptr[i]; e < o->A_rowptr[i + 1]; ++e) {
-                const float* yj = &o->cloud_y[(size_t)o->A_col[e] * 3];
-                const float a = o->A_val[e];
-                float cr[3]; cross3(xi, yj, cr);
-                for (int k = 0; k < 3; ++k) { sw[k] += a * cr[k]; sv[k] += a * (yj[k] - xi[k]); }
-            }
-            for (int k = 0; k < 3; ++k) { rw[(size_t)i * 3 + k] = inv_c * sw[k]; rv[(size_t)i * 3 + k] = inv_d * sv[k]; }
+            float a3[3], b3[3]; row_flow(o, i, inv_c, inv_d, a3, b3);
+            for (int k = 0; k < 3; ++k) { rw[(size_t)i * 3 + k] = a3[k]; rv[(size_t)i * 3 + k] = b3[k]; }
         }
         std::vector<int> perm(N); std::iota(perm.begin(), perm.end(), 0);
         std::mt19937_64 rng(o->shuffle_seed + 0x9E3779B97F4A7C15ull * (++o->shuffle_calls));
@@ -374,15 +419,8 @@ void compute_flow(orc_cvo* o) {
         double lw[3] = {0, 0, 0}, lv[3] = {0, 0, 0}; long ln = 0;
 #pragma omp for schedule(static)
         for (int i = 0; i < N; ++i) {
-            const float* xi = &X.xyz[(size_t)i * 3];
-            float sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
-            for (int e = o->A_rowptr[i]; e < o->A_rowptr[i + 1]; ++e) {
-                const float* yj = &o->cloud_y[(size_t)o->A_col[e] * 3];
-                const float a = o->A_val[e];
-                float cr[3]; cross3(xi, yj, cr);                                  // cvo.cpp:216
-                for (int k = 0; k < 3; ++k) { sw[k] += a * cr[k]; sv[k] += a * (yj[k] - xi[k]); }   // cvo.cpp:217,222-223 (GEMV: alpha * sum_j a_j*col_j)
-            }
-            for (int k = 0; k < 3; ++k) { lw[k] += (double)(inv_c * sw[k]); lv[k] += (double)(inv_d * sv[k]); }
+            float rw[3], rv[3]; row_flow(o, i, inv_c, inv_d, rw, rv);             // cvo.cpp:213-223
+            for (int k = 0; k < 3; ++k) { lw[k] += (double)rw[k]; lv[k] += (double)rv[k]; }
             ln += o->A_rowptr[i + 1] - o->A_rowptr[i];
         }
 #pragma omp critical
@@ -793,6 +831,7 @@ static orc_inn_p fip_impl(orc_cvo* o, const std::vector<float>& a_xyz, const Clo
     const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)std::log(P.sp_thres / P.c_sigma / P.c_sigma));   // cvo.cpp:396
     KdTree tree; const KdTree* tp = nullptr;
     if (o->search_mode == ORC_SEARCH_KDTREE) { tree.build(b.xyz.data(), b.n); tp = &tree; }
+    const int feat_order = (o->variant & ORC_VAR_FEAT_HADD) ? 1 : ((o->variant & ORC_VAR_FEAT_MOVEHL) ? 2 : 0);
     double sum_A = 0, sum = 0, sum_e = 0;
 #pragma omp parallel num_threads(o->threads)
     {
@@ -803,7 +842,7 @@ static orc_inn_p fip_impl(orc_cvo* o, const std::vector<float>& a_xyz, const Clo
             for (const Match& mt : ms) {
                 const float d2 = mt.d2;
                 if (d2 < d2_thres) {
-                    const float d2_color = feat_d2(a.feat.data(), a.n, i, b.feat.data(), b.n, mt.j);
+                    const float d2_color = feat_d2(a.feat.data(), a.n, i, b.feat.data(), b.n, mt.j, feat_order);
                     if (d2_color < d2_c_thres) {
                         const float k = (float)(sigma * sigma * std::exp(-d2 / (2.0 * ell * ell)));              // cvo.cpp:429
                         const float ck = (float)(P.c_sigma * P.c_sigma * std::exp(-d2_color / (2.0 * P.c_ell * P.c_ell)));
@@ -875,6 +914,7 @@ static void hessian_impl(orc_cvo* o, const std::vector<float>& a_xyz, const Clou
     const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)std::log(P.sp_thres / P.c_sigma / P.c_sigma));
     KdTree tree; const KdTree* tp = nullptr;
     if (o->search_mode == ORC_SEARCH_KDTREE) { tree.build(b.xyz.data(), b.n); tp = &tree; }
+    const int feat_order = (o->variant & ORC_VAR_FEAT_HADD) ? 1 : ((o->variant & ORC_VAR_FEAT_MOVEHL) ? 2 : 0);
     float H[36]; std::memset(H, 0, sizeof(H));
     double Hd[36]; std::memset(Hd, 0, sizeof(Hd));
     int inliers = *inliers_out;                       // the reference accumulates into the caller's variable
@@ -886,11 +926,11 @@ static void hessian_impl(orc_cvo* o, const std::vector<float>& a_xyz, const Clou
         for (const Match& mt : ms) {
             const float d2 = mt.d2;
             if (!(d2 < d2_thres)) continue;
-            const float d2_color = feat_d2(a.feat.data(), a.n, i, b.feat.data(), b.n, mt.j);
+            const float d2_color = feat_d2(a.feat.data(), a.n, i, b.feat.data(), b.n, mt.j, feat_order);
             if (!(d2_color < d2_c_thres)) continue;
             const float* pb = &b.xyz[(size_t)mt.j * 3];
             const float k = (float)(sigma * sigma * std::exp(-d2 / (2.0 * ell * ell)));                          // cvo.cpp:661
-            const float cdot = feat_dot(a.feat.data(), a.n, i, b.feat.data(), b.n, mt.j);                       // cvo.cpp:662
+            const float cdot = feat_dot(a.feat.data(), a.n, i, b.feat.data(), b.n, mt.j, feat_order);                      // cvo.cpp:662
             float cr[3]; cross3(pa, pb, cr);
             float Bk[36];
             const float dot1 = pa[1] * pb[1] + pa[2] * pb[2], dot2 = pa[0] * pb[0] + pa[2] * pb[2], dot3 = pa[0] * pb[0] + pa[1] * pb[1];

@@ -118,7 +118,18 @@ void orc_get_timing(const orc_cvo* o, double seconds[4]);
  * A fourth source, FMA contraction / re-association by an optimising compiler (the reference is built
  * -O3 -march=native with icpc, CMakeLists.txt:13), is a second BUILD of this same source
  * (oracle/Makefile: libcvo_oracle_fast.so, -O3 -march=native -ffp-contract=fast). */
-enum { ORC_VAR_SHUFFLE = 1, ORC_VAR_F32_ROOTS = 2, ORC_VAR_F32_LOGM = 4 };
+/* Two more, inside a row / a feature vector (Eigen 3.3.7 read from its sources' structure; DESIGN.md section 2 has the derivation):
+ *   ORC_VAR_ROW_LAZY16      compute_flow's `1/c*Ai*cross_xy` (cvo.cpp:222-223) as Eigen 3.3.7 evaluates it: rows with fewer than 16
+ *                           nonzeros go through the coefficient-based lazy product, whose left factor `1/c*Ai` is evaluated first (alpha
+ *                           folded into every a_j, then a sequential sum); longer rows through gebp's scalar tail (sequential sum, alpha after)
+ *   ORC_VAR_ROW_ALPHA_FIRST alpha folded into a_j in every row
+ *   ORC_VAR_ROW_STRIDE4/8   the row sum as 4 / 8 strided partial sums + horizontal add (re-associating vectoriser, packet redux)
+ *   ORC_VAR_FEAT_HADD       (f_a-f_b).squaredNorm(), f_a.dot(f_b) (cvo.cpp:169, :662) as predux(Packet4f) + tail with SSE3's hadd:
+ *                           ((t0+t1)+(t2+t3))+t4 -- the vectorised redux of a fixed size 5; the base order is the un-vectorised one
+ *   ORC_VAR_FEAT_MOVEHL     the same with the movehl/add_ss predux: ((t0+t2)+(t1+t3))+t4 */
+enum { ORC_VAR_SHUFFLE = 1, ORC_VAR_F32_ROOTS = 2, ORC_VAR_F32_LOGM = 4,
+       ORC_VAR_ROW_LAZY16 = 8, ORC_VAR_ROW_STRIDE4 = 16, ORC_VAR_ROW_STRIDE8 = 32, ORC_VAR_ROW_ALPHA_FIRST = 64,
+       ORC_VAR_FEAT_HADD = 128, ORC_VAR_FEAT_MOVEHL = 256 };
 void  orc_set_variant(orc_cvo* o, int flags, unsigned long long shuffle_seed);
 float orc_cubic_step_f32eig(float c3, float c2, float c1, float c0, float min_step);
 float orc_dist_se3_f32logm(const float dR[9], const float dT[3]);

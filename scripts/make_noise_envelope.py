@@ -33,6 +33,14 @@ VARIANTS = [   # name, library flavour, ORC_VAR_* flags, shuffle seed
     ("f32_companion_roots", "parity", 2, 0),
     ("f32_logm", "parity", 4, 0),
     ("all_sources", "fast", 7, 404),
+    # inside a row / a feature vector (ORC_VAR_ROW_*, ORC_VAR_FEAT_*): cvo.cpp:222-223 and :169 / :662 are Eigen reductions whose order Eigen picks
+    ("row_eigen337_lazy16", "parity", 8, 0),        # Eigen 3.3.7 as written: rows of < 16 nonzeros fold alpha into a_j first
+    ("row_alpha_first", "parity", 64, 0),
+    ("row_stride4", "parity", 16, 0),
+    ("row_stride8", "parity", 32, 0),
+    ("feat_hadd", "parity", 128, 0),
+    ("feat_movehl", "parity", 256, 0),
+    ("all_sources_eigen337", "fast", 7 | 8 | 128, 505),
 ]
 
 

@@ -81,3 +81,34 @@ def test_adoption_under_other_layouts_and_cutoffs(hiplib, knobs):
         for k, v in old.items():
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
+
+
+def test_a_helper_that_leaves_after_the_acceptance_cannot_fail_the_pair(hiplib):
+    """Injection (CVO_HIP_ADOPT_INJECT=1, read when the handle is made): every helper whose offer an owner has accepted walks away instead of
+    confirming.  The owner must take the acceptance back (cvo_batch_last_adoption_retractions counts them) and carry on with the workgroups it
+    has: status 0 and the bits of the batch without adoption on 24 full-size pairs -- not CVO_ERR_TIMEOUT after three seconds."""
+    import os
+    import time
+    from cvo_slam_amd import synth
+    pairs = [synth.make_pair(i) for i in range(24)]
+    ref = _batch(hiplib, pairs, False)
+    ref.align_async(len(pairs)); want = ref.wait(len(pairs)); ref.close()
+    old = os.environ.get("CVO_HIP_ADOPT_INJECT")
+    os.environ["CVO_HIP_ADOPT_INJECT"] = "1"
+    try:
+        b = _batch(hiplib, pairs, True)
+    finally:
+        if old is None: os.environ.pop("CVO_HIP_ADOPT_INJECT", None)
+        else: os.environ["CVO_HIP_ADOPT_INJECT"] = old
+    retracted = 0
+    t0 = time.perf_counter()
+    for rep in range(4):
+        b.reset_states(); b.align_async(len(pairs)); got = b.wait(len(pairs))
+        assert b.last_adoptions() == 0                               # nobody ever joined ...
+        retracted += b.last_adoption_retractions()                   # ... although offers were accepted
+        for w, g in zip(want, got):
+            assert g["status"] == 0 and g["iter"] == w["iter"] and g["iterations_run"] == w["iterations_run"] and g["A_nonzero"] == w["A_nonzero"]
+            assert np.array_equal(g["transform"], w["transform"])
+    assert retracted >= 4, retracted
+    assert time.perf_counter() - t0 < 2.0                            # no wait ran into a timeout
+    b.close()

@@ -52,7 +52,10 @@ def _bench_adoption_default() -> bool:
     return m.group(1) == "True"
 
 
-@pytest.mark.parametrize("adoption", [False, True])
+ADOPTION_MODES = [False, True]
+
+
+@pytest.mark.parametrize("adoption", ADOPTION_MODES)
 def test_config3_as_benchmarked_every_concurrent_launch_matches_the_oracle(hiplib, oracle, adoption):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # read when the runtime initialises; harmless later
     clouds, want = _inputs_and_oracle()
@@ -86,4 +89,10 @@ def test_config3_as_benchmarked_every_concurrent_launch_matches_the_oracle(hipli
 
 
 def test_the_mode_the_bench_times_is_one_of_the_tested_modes():
-    assert _bench_adoption_default() in (False, True)
+    """bench.py's ADOPTION_DEFAULT (what the driver's command runs with) must be a member of the parametrisation above, and the
+    parametrised test must really carry that list (a renamed or narrowed parametrisation would leave the timed mode untested)."""
+    marks = [m for m in test_config3_as_benchmarked_every_concurrent_launch_matches_the_oracle.pytestmark if m.name == "parametrize"]
+    assert marks and marks[0].args[0] == "adoption" and list(marks[0].args[1]) == ADOPTION_MODES
+    assert _bench_adoption_default() in list(marks[0].args[1])
+    import bench                                             # and the constant the regex reads is the one the module uses
+    assert bench.ADOPTION_DEFAULT is _bench_adoption_default()

@@ -80,3 +80,62 @@ def test_tail_scores_under_adoption(hiplib):
             _check(g, w, 1e-6)
     assert helped > 0
     B.close()
+
+
+def test_members_with_different_list_margins_agree_in_the_tail(hiplib, oracle):
+    """Two workgroups per pair; the fixed cloud alternates, in blocks of 128 rows (the unit rows are dealt in), between a dense patch a few
+    decimetres from the camera and a sparse far wall: member 0 owns the dense blocks, its lists overflow the launch's margin and it rebuilds
+    them with the narrow one, member 1 never does.  Their lists go stale at different iterations, so after the final transform one member's
+    may be valid and the other's not -- and the tail exchanges partial sums: both must take the same branch (round 3: mismatched exchanges,
+    status 6 after three seconds).  Scores against the oracle, poses against the oracle, with and without the tail."""
+    rng = np.random.default_rng(11)
+    nblk, per = 24, 128
+    xyz = np.zeros((nblk * per, 3), np.float32); feat = np.zeros((5, nblk * per), np.float32)
+    for b in range(nblk):
+        sl = slice(b * per, (b + 1) * per)
+        if b % 2 == 0:                                               # dense patch: 1536 points on 0.38 x 0.285 m at 0.6 m: ~545 list candidates per row at the launch margin of 0.35 (the records hold 512 per row), ~483 at the narrow 0.25
+            uv = rng.uniform(-1, 1, size=(per, 2)) * np.array([0.19, 0.1425])
+            z = 0.6 + 0.02 * np.sin(9 * uv[:, 0]) * np.cos(7 * uv[:, 1])
+        else:                                                        # far wall: 1536 points on 3 x 2.2 m at 3 m
+            uv = rng.uniform(-1, 1, size=(per, 2)) * np.array([1.5, 1.1])
+            z = 3.0 + 0.05 * np.sin(3 * uv[:, 0])
+        xyz[sl] = np.stack([uv[:, 0], uv[:, 1], z], axis=1)
+        feat[:, sl] = np.stack([128 + 80 * np.sin(11 * uv[:, 0]), 128 + 70 * np.cos(13 * uv[:, 1]), 128 + 60 * np.sin(9 * (uv[:, 0] + uv[:, 1])),
+                                15 * np.cos(17 * uv[:, 0]), 15 * np.sin(19 * uv[:, 1])], axis=0)
+    from helpers import make_tf, rot_trans_err
+    tf = make_tf([0.2, 1.0, 0.1], 0.012, [0.006, -0.004, 0.003])
+    mov = ((xyz - tf[:, 3]) @ tf[:, :3] + rng.normal(0, 5e-4, size=xyz.shape)).astype(np.float32)
+    mfeat = (feat + rng.normal(0, 1.0, size=feat.shape)).astype(np.float32)
+    cloud = (xyz, feat, mov, mfeat)
+    o = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8)
+    o.set_pcd(xyz, feat); o.set_pcd(mov, mfeat); rc, _ = o.align(); assert rc == 0
+    ost = o.get_state()
+    rc, want = o.compute_innerproduct(ost["transform"]); assert rc == 0
+    for wgs in (2, 4, 1):
+        B = hiplib.CvoBatch(1); B.set_workgroups(wgs); B.set_pairs([cloud]); B.set_tail_scores(True)
+        B.align_async(1); res = B.wait(1)
+        assert res[0]["status"] == 0, (wgs, res[0])
+        re, te = rot_trans_err(res[0]["transform"], ost["transform"])
+        assert re <= 1e-6 and te <= 1e-6 and res[0]["iter"] == ost["iter"] and res[0]["A_nonzero"] == ost["A_nonzero"], (wgs, re, te)
+        got = B.innerproduct_results(1)[0]
+        _check(got, want, 1e-5)
+        B.close()
+    # The alignment cut short at every iteration of its first phases: the clouds have moved 25 ... 40 mm by then, more than the narrow margin
+    # allows (0.25 r_c = 25 mm at ell = 0.15) and less than the launch's (35 mm) -- at some of these cuts member 0's lists are stale for the
+    # final transform and member 1's are not.  Against the score-kernel path of the same launch without the tail.
+    import time
+    t0 = time.perf_counter()
+    partly = 0
+    for max_iter in range(2, 16):
+        prm = hiplib.default_params(); prm.max_iter = max_iter
+        ref = hiplib.CvoBatch(1, prm); ref.set_workgroups(2); ref.set_pairs([cloud])
+        B = hiplib.CvoBatch(1, prm); B.set_workgroups(2); B.set_pairs([cloud]); B.set_tail_scores(True)
+        ref.align_async(1); ref.enqueue_innerproduct(1); rres = ref.wait(1); wantg = ref.innerproduct_results(1)[0]
+        B.align_async(1); res = B.wait(1); mask = B.last_tail_answers(1)[0]; got = B.innerproduct_results(1)[0]
+        assert res[0]["status"] == 0 and rres[0]["status"] == 0, (max_iter, res[0]["status"])
+        assert np.array_equal(res[0]["transform"], rres[0]["transform"]), max_iter
+        _check(got, wantg, 1e-6)
+        partly += int(mask & 0b10010 != 0b10010)                      # inn_post / Hessian left to the host: somebody's lists were stale
+        ref.close(); B.close()
+    assert time.perf_counter() - t0 < 3.0                              # nobody waited for an exchange that never came (3 s each)
+    assert partly >= 1, partly

@@ -87,7 +87,10 @@ def test_variants_reproduce_the_committed_envelope(oracle, envelope):
     """The parity-build variants are deterministic: re-running them on the fixture's first small pair gives the recorded
     distances; the envelope file is what the script writes (64 bench pairs, every variant)."""
     from cvo_slam_amd import synth
-    assert len(envelope["tum64"]["per_pair"]) == 64 and len(envelope["variants"]) == 7
+    assert len(envelope["tum64"]["per_pair"]) == 64 and len(envelope["variants"]) == 14
+    names = {v["name"]: v for v in envelope["variants"]}
+    assert names["row_eigen337_lazy16"]["flags"] == 8 and names["row_stride4"]["flags"] == 16 and names["row_stride8"]["flags"] == 32     # ORC_VAR_ROW_*
+    assert names["row_alpha_first"]["flags"] == 64 and names["feat_hadd"]["flags"] == 128 and names["feat_movehl"]["flags"] == 256
     row = envelope["small"]["per_pair"][0]
     pair = synth.make_small_pair(row["pair"], n=600)
     base, it0 = _align(oracle, pair)
@@ -113,9 +116,40 @@ def test_fast_build_agrees_within_the_reference_noise(oracle):
     assert r < 1e-3 and t < 1e-3
 
 
+def test_row_and_feature_order_variants(oracle):
+    """ORC_VAR_ROW_* / ORC_VAR_FEAT_* (cvo.cpp:222-223, :169, :662 are Eigen reductions whose order Eigen picks).  On features as the
+    reference's generator makes them -- 8-bit B, G, R and half-integer gradients (pcd_generator.cpp:601-609) -- every term of the colour
+    reductions is a multiple of 1/4 below 2^18 and every partial sum is exact: the feature orders give the base oracle's bits.  On
+    arbitrary float features (the bench's synthetic gradients come from a float gray image) they do not; the row orders never do."""
+    from cvo_slam_amd import synth
+    import copy
+    pair = synth.make_small_pair(13, n=600)
+    base, it0 = _align(oracle, pair)
+    q = copy.deepcopy(pair)
+    for cl in (q.fixed, q.moving):
+        cl.feat[:3] = np.round(cl.feat[:3]); cl.feat[3:] = np.round(2 * cl.feat[3:]) / 2
+    qbase, qit = _align(oracle, q)
+    for flags in (128, 256):
+        tf, it = _align(oracle, q, variant=flags)
+        assert it == qit and np.array_equal(tf, qbase), flags                                   # exact arithmetic: same bits
+    moved = 0
+    for flags in (8, 16, 32, 64, 128, 256):
+        tf, it = _align(oracle, pair, variant=flags)
+        r, t = rot_trans_err(tf, base)
+        assert r < 1e-3 and t < 1e-3, (flags, r, t)                                             # noise, not another answer
+        tf2, it2 = _align(oracle, pair, variant=flags)
+        assert np.array_equal(tf, tf2) and it == it2                                            # deterministic
+        moved += int(not np.array_equal(tf, base))
+    assert moved >= 4                                                                           # they really are other float sequences
+
+
 def test_envelope_statement(envelope):
     """What DESIGN.md section 2 says about the envelope is what the file holds."""
     e = envelope["tum64"]
     assert e["per_variant"]["shuffled_reduction_1"]["max_rot_rad"] < 1e-6          # f64 cross-row sums: order does not reach the pose
     assert e["max_rot_rad"] < 1e-3 and e["max_trans_m"] < 1e-3
+    # the within-row / within-feature orders are as loud as FMA contraction and the f32 roots: the same 1e-4 scale, never 1e-3
+    for name in ("row_eigen337_lazy16", "row_alpha_first", "row_stride4", "row_stride8", "feat_hadd", "feat_movehl"):
+        assert 1e-6 < e["per_variant"][name]["max_trans_m"] < 1e-3, name
+    assert e["pairs_beyond_1e-4"] >= 5                                              # the north-star tolerance is tighter than the reference's own freedom on some pairs
     assert e["max_trans_m"] > 1e-4                                                 # the reference's own noise exceeds the north-star tolerance
