@@ -44,7 +44,10 @@ _SHAPE = "tum"
 
 def _gen_pair(idx):
     from cvo_slam_amd import synth
-    p = synth.make_pair(idx, cam=synth.ETH3D if _SHAPE == "eth3d" else synth.TUM1)
+    kw = {}
+    if os.environ.get("CVO_BENCH_MOTION"):          # experiments: another inter-frame motion "max_deg,max_trans_m" (the metric's set: 2 degrees, 3 cm -- SURVEY 8d)
+        deg, tr = os.environ["CVO_BENCH_MOTION"].split(","); kw = dict(max_deg=float(deg), max_trans=float(tr))
+    p = synth.make_pair(idx, cam=synth.ETH3D if _SHAPE == "eth3d" else synth.TUM1, **kw)
     return idx, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat
 
 

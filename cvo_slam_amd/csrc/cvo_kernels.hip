@@ -86,7 +86,11 @@ struct __attribute__((aligned(16))) Shared {
     float step;
     float M[12];
     float Mb[12];          // the transform the candidate lists were built (or last filtered) under
-    float Rb;              // radius they were built with
+    float Rb;              // radius they were built with: its part that is the same for every row, r (1 + skin)
+    float alpha_build;     // ... and the depth-proportional part of the margin they were built (or last filtered) with: row i holds every column within
+                           // (Rb + alpha_build |x_i|) / (1 - alpha_build) of it (DevParams::skin_alpha)
+    float alpha_next;      // phase_transform -> phase_refine: the alpha the filtered lists can have
+    float xmax;            // largest |x_i| of this workgroup's rows (phase_cull)
     float ell_build;
     float fred[MAX_WAVES];
     int wsum[MAX_WAVES];
@@ -615,7 +619,7 @@ __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float
 constexpr int SWEEP_R = 2;
 
 __device__ __forceinline__ void sweep_group(const float* lx, const float* ly, const float* lz, int c0 /* wave-uniform */,
-                                            const float (&x)[SWEEP_R][3], float nthr, uint32_t (&w)[SWEEP_R]) {
+                                            const float (&x)[SWEEP_R][3], const float (&nthr)[SWEEP_R], uint32_t (&w)[SWEEP_R]) {
     const float4* qx = reinterpret_cast<const float4*>(lx + c0);
     const float4* qy = reinterpret_cast<const float4*>(ly + c0);
     const float4* qz = reinterpret_cast<const float4*>(lz + c0);
@@ -630,7 +634,7 @@ __device__ __forceinline__ void sweep_group(const float* lx, const float* ly, co
 #pragma unroll
             for (int r = 0; r < SWEEP_R; ++r) {
                 const float dx = x[r][0] - cx[u], dy = x[r][1] - cy[u], dz = x[r][2] - cz[u];
-                const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nthr)));
+                const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nthr[r])));
                 w[r] = __builtin_amdgcn_alignbit(w[r], __float_as_uint(t), 31);
             }
         }
@@ -802,7 +806,10 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
     float Mb[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Mb[i] = sh->Mb[i];
-    float dmax2 = 0.f;
+    // how much closer a pair can be now than when the lists were built: the largest displacement of a point since then, less the part of it the lists of
+    // its neighbourhood allow for by themselves (alpha_build x its distance from the camera at build time; 0 with one margin for all rows)
+    float dmax = 0.f;
+    const float alpha_b = sh->alpha_build;
     auto one = [&](int j, const float4 lo) {
         float y0, y1, y2;
         apply_transform(M, lo.x, lo.y, lo.z, y0, y1, y2);
@@ -813,7 +820,9 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
             float b0, b1, b2;
             apply_transform(Mb, lo.x, lo.y, lo.z, b0, b1, b2);
             const float e0 = y0 - b0, e1 = y1 - b1, e2 = y2 - b2;
-            dmax2 = fmaxf(dmax2, __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)));
+            const float disp = sqrtf(__builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0))) * 1.0001f + 1.0e-5f;
+            const float far = sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f;
+            dmax = fmaxf(dmax, disp - alpha_b * far);
         }
     };
     int j = tid;
@@ -822,17 +831,25 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
         for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u]); j += nthreads; }
     }
     for (; j < c.nm; j += nthreads) one(j, ld4(c.moving + lo_off(j)));
-    dmax2 = block_max(dmax2, sh, tid, nwaves);                      // also makes ybuf / ylds visible to the workgroup
+    dmax = block_max(dmax, sh, tid, nwaves);                        // also makes ybuf / ylds visible to the workgroup
     if (tid == 0) {
         const float ell = sh->ell;
         const float r_c = sqrtf(gate_d2_align(ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
-        // the lists hold every pair within Rb of the build positions; a pair within r_c now was within
-        // r_c + (its point's displacement) then.  Every workgroup of the pair computes the same bits here.
-        const float reach = (sqrtf(dmax2) * 1.0001f + 1.0e-5f);      // how much closer a pair can be now than when the lists were built
+        // Row i's list holds every column within (Rb + a |x_i|) / (1 - a) of it at the build positions (a = alpha_build).  A pair within r_c now was
+        // within D < r_c + (its point's displacement) <= r_c + reach + a |y_j| <= r_c + reach + a (|x_i| + D) then: inside the list while
+        // r_c + reach <= Rb.  (a = 0: the lists hold every pair within Rb, reach = the largest displacement.)
+        const float reach = have_list ? dmax : 1.0e-5f;
         int rb = (!have_list || (sh->ell_build != ell) || (r_c + reach) * 1.00001f > sh->Rb) ? 1 : 0;
         // ell has dropped (cvo.cpp:810-812) and the old, wider lists still hold every pair within the NEW list radius of the
         // current positions: filter them in place instead of a dense cull (2 = refine).  Not in dense mode (no lists to filter).
-        if (rb && have_list && !sh->dense_mode && sh->ell_build != ell && (r_c * (1.0f + sh->P.skin) + reach) * 1.00001f <= sh->Rb) rb = 2;
+        // With new radii (Rn + a' |x_i|) / (1 - a') =: Rn_i the old lists must hold D < Rn_i + reach + a (|x_i| + D), i.e. Rn_i + reach <= Rb for the
+        // farthest row: that bounds the depth-proportional margin a' the filtered lists can have.
+        const float Rn = r_c * (1.0f + sh->P.skin);
+        if (rb && have_list && !sh->dense_mode && sh->ell_build != ell && (Rn + reach) * 1.00001f <= sh->Rb) {
+            rb = 2;
+            const float room = sh->Rb - (Rn + reach) * 1.00001f;
+            sh->alpha_next = fminf(sh->P.skin_alpha, 0.999f * room / (sh->xmax * 1.0001f + sh->Rb));
+        }
         sh->rebuild = rb;
         for (int i = 0; i < 12; ++i) sh->M[i] = M[i];
     }
@@ -873,9 +890,9 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     const int nrows = c.nrows;
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
     const float Rb = r_c * (1.0f + sh->P.skin);
-    const float thr_cull = Rb * Rb * 1.00001f;
-    const float thr_box = thr_cull * 1.001f;                        // box gaps are compared with a margin: a skipped group holds no hit
-    const float nthr = -thr_cull;
+    // row i is listed with radius (Rb + alpha |x_i|) / (1 - alpha) (DevParams::skin_alpha; phase_transform's staleness test is its counterpart)
+    const float alpha = sh->P.skin_alpha, inv_1ma = 1.0f / (1.0f - alpha);
+    float xmax_l = 0.f;
     const bool planes = y_lds == 2;                                 // columns come straight from the resident y planes: one pass over the whole cloud
     const int span = planes ? max(c.nm, 1) : tile;
     const float* colx = planes ? L.ysx : L.lx; const float* coly = planes ? L.ysy : L.ly; const float* colz = planes ? L.ysz : L.lz;
@@ -924,14 +941,23 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             b2 = uni(b2);
             if (b2 >= nblk2) break;
             float x[SWEEP_R][3]; int li[SWEEP_R]; int cnt[SWEEP_R];
+            float nthr[SWEEP_R];                                    // - (the row's list radius)^2
+            float Rrow = Rb * inv_1ma;                              // the widest radius of the wave's rows
             unsigned long long buf[SWEEP_R];                        // the row's last, not yet full word of four columns
             float blo[4] = {INF, INF, INF, INF}, bhi[4] = {-INF, -INF, -INF, -INF};
 #pragma unroll
             for (int r = 0; r < SWEEP_R; ++r) {
                 li[r] = (b2 * SWEEP_R + r) * 64 + lane;
+                nthr[r] = -(Rrow * Rrow * 1.00001f);
                 if (li[r] < nrows) {
                     const float4 lo4 = ld4(c.fixed + lo_off(global_row(c, li[r])));
                     x[r][0] = lo4.x; x[r][1] = lo4.y; x[r][2] = lo4.z;
+                    if (alpha > 0.f) {
+                        const float xn = sqrtf(__builtin_fmaf(lo4.z, lo4.z, __builtin_fmaf(lo4.y, lo4.y, lo4.x * lo4.x)));
+                        const float Ri = (Rb + alpha * xn * 1.0001f) * inv_1ma;
+                        nthr[r] = -(Ri * Ri * 1.00001f);
+                        xmax_l = fmaxf(xmax_l, xn);
+                    }
 #pragma unroll
                     for (int q = 0; q < 3; ++q) { blo[q] = fminf(blo[q], x[r][q]); bhi[q] = fmaxf(bhi[q], x[r][q]); }
                     if (lo4.z > 1.0e-3f) { const float t = lo4.y / lo4.z; blo[3] = fminf(blo[3], t); bhi[3] = fmaxf(bhi[3], t); }
@@ -948,8 +974,10 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) { blo[q] = wave_min(blo[q]); bhi[q] = wave_max(bhi[q]); }
-            // points p (a row), q (a column) within Rb of each other: |y_p/z_p - y_q/z_q| <= Rb (1 + |y_q/z_q|) / z_p
-            const float slope_reach = (blo[2] > 1.0e-3f) ? Rb * 1.01f / blo[2] : INF;
+            if (alpha > 0.f) Rrow = sqrtf(wave_max(-fminf(nthr[0], nthr[1])));
+            const float thr_box = Rrow * Rrow * 1.00001f * 1.001f;  // box gaps are compared with a margin: a skipped group holds no hit
+            // points p (a row), q (a column) within R of each other: |y_p/z_p - y_q/z_q| <= R (1 + |y_q/z_q|) / z_p
+            const float slope_reach = (blo[2] > 1.0e-3f) ? Rrow * 1.01f / blo[2] : INF;
             for (int gb = 0; gb < ngr; gb += 64) {
                 bool near = false;
                 if (gb + lane < ngr) {
@@ -1024,7 +1052,8 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             }
         }
     }
-    if (tid == 0) { sh->Rb = Rb; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1; for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i]; }
+    if (alpha > 0.f) xmax_l = block_max(xmax_l, sh, tid, nthreads >> 6);
+    if (tid == 0) { sh->Rb = Rb; sh->alpha_build = alpha; sh->xmax = xmax_l; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1; for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i]; }
     __syncthreads();
 }
 
@@ -1359,7 +1388,8 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
 // ---- R: ell has dropped: the lists shrink to the new radius in place.  The test is the cull's (same fused arithmetic on the
 // current positions), so the result is the list a dense cull would build now, with the colour factors it already carries.
 template <int YM>
-__device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* sh, float nthr, int lane, int wave, int nwaves) {
+__device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* sh, float Rb, float alpha, int lane, int wave, int nwaves) {
+    const float inv_1ma = 1.0f / (1.0f - alpha);
     int kept = 0, nb_left = 0;
     const int nb = sh->wnb[wave];
     for (int bi = 0; bi < nb; ++bi) {
@@ -1368,6 +1398,9 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
         const int len = L.lenS[slot];
         const int lw = uni((int)sh->blk_lmax[blk]);
         float xi[3]; load_x(c, L, sh->x_lds != 0, slot, xi);
+        // the row's new list radius (Rb + alpha |x_i|) / (1 - alpha): the cull's for this ell
+        const float Ri = (Rb + alpha * sqrtf(__builtin_fmaf(xi[2], xi[2], __builtin_fmaf(xi[1], xi[1], xi[0] * xi[0]))) * 1.0001f) * inv_1ma;
+        const float nthr = -(Ri * Ri * 1.00001f);
         gv2u* wp = c.ent + 2 * slot;                                // the kept entries go to the front of the row: never ahead of the reads
         const gv2u* ep = wp;
         const size_t rp = (size_t)c.rows_pad;
@@ -1414,8 +1447,8 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
     const int nblk = (c.nrows + 63) >> 6;
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
     const float Rb = r_c * (1.0f + sh->P.skin);
-    const float nthr = -(Rb * Rb * 1.00001f);                       // = the cull's threshold for this ell
-    const int kept = y_lds == 1 ? refine_lists<1>(c, L, sh, nthr, lane, wave, nwaves) : (y_lds == 2 ? refine_lists<2>(c, L, sh, nthr, lane, wave, nwaves) : refine_lists<0>(c, L, sh, nthr, lane, wave, nwaves));
+    const float alpha = sh->alpha_next;                             // what the old lists leave room for (phase_transform)
+    const int kept = y_lds == 1 ? refine_lists<1>(c, L, sh, Rb, alpha, lane, wave, nwaves) : (y_lds == 2 ? refine_lists<2>(c, L, sh, Rb, alpha, lane, wave, nwaves) : refine_lists<0>(c, L, sh, Rb, alpha, lane, wave, nwaves));
     if (lane == 0) sh->wsum[wave] = kept;
     __syncthreads();
     if (tid == 0) {
@@ -1423,7 +1456,7 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
         long long walked = 0;                                        // list slots a walk evaluates in the present order: 64 rows x the longest list of each block, in steps of PF
         for (int w = 0; w < nwaves; ++w) tot += sh->wsum[w];
         for (int bq = 0; bq < nblk; ++bq) { const int lm = (int)sh->blk_lmax[bq]; lmax_new = max(lmax_new, lm); walked += 64 * PF * ((lm + PF - 1) / PF); }
-        sh->total = tot; sh->lmax = lmax_new; sh->Rb = Rb; sh->ell_build = sh->ell; sh->refines += 1;
+        sh->total = tot; sh->lmax = lmax_new; sh->Rb = Rb; sh->alpha_build = alpha; sh->ell_build = sh->ell; sh->refines += 1;
         for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i];          // displacements count from here again
         // Re-sort (below) when it pays: it costs about 25 us + 1.7 ns per list entry (measured: 31 us at 13 k entries, 68 at 48 k, 240 at
         // 126 k -- the lists change columns, 64 cache lines per wave load) and saves 0.28 ns per list slot no longer walked, in every
@@ -1903,7 +1936,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 #pragma unroll
             for (int i = 0; i < 3; ++i) { Ts[i] = sh->T[i]; sh->T[i] = 0.f; }
             sh->list_valid = 0;
-            sh->P.skin = 0.f;                                                           // nothing moves any more: the cull's radius is r_c itself (restored below)
+            sh->P.skin = 0.f; sh->P.skin_alpha = 0.f;                                   // nothing moves any more: the cull's radius is r_c itself (restored below)
         }
         __syncthreads();
         transform_body_t<1>(c, L, sh, none, false);                                     // y = p
@@ -1950,7 +1983,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 #pragma unroll
             for (int i = 0; i < 3; ++i) sh->T[i] = Ts[i];
             sh->rebuilds = rebuilds_before;
-            sh->P.skin = P.skin;
+            sh->P.skin = P.skin; sh->P.skin_alpha = P.skin_alpha;
         }
         __syncthreads();
     }
@@ -2146,7 +2179,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
             for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
             sh->cand_total = 0; sh->nnz_total = 0;
-            sh->P.skin = P.skin; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
+            sh->P.skin = P.skin; sh->P.skin_alpha = P.skin_alpha; sh->alpha_build = 0.f; sh->alpha_next = 0.f; sh->xmax = 0.f; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
         // a helper has read what the owner published for it: if the pair may grow further, its word takes offers again (not earlier --
@@ -2175,7 +2208,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                 phase_sort(Dp, ge, Ge, tgeo, y_lds);
                 if (sh->dense_mode && sh->P.skin > SKIN_DENSE_SCENE) {   // the lists of this margin do not fit (a surface a few decimetres from the camera): once more with the
                     __syncthreads();                                     // narrow margin, kept for the rest of the pair, before the rows fall back to dense sweeps
-                    if (tid == 0) { sh->P.skin = SKIN_DENSE_SCENE; sh->dense_fallbacks -= 1; }
+                    if (tid == 0) { sh->P.skin = SKIN_DENSE_SCENE; sh->P.skin_alpha = 0.f; sh->dense_fallbacks -= 1; }
                     __syncthreads();
                     phase_cull(Dp, ge, Ge, tgeo, y_lds);
                     phase_sort(Dp, ge, Ge, tgeo, y_lds);
@@ -2299,7 +2332,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             fin.candidates_total = (long long)sh->cand_total; fin.nonzeros_total = (long long)sh->nnz_total;
             for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
             fin.phase_ticks[7] = sh->sub[0]; fin.phase_ticks[9] = sh->sub[1]; fin.phase_ticks[2] = sh->sub[2]; fin.phase_ticks[4] = sh->sub[3];
-            fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0;
+            fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0; fin.clk_t0 = clk_t0;
             *Dp->state = fin;                                          // device copy: the next launch may start from it
             *Dp->state_host = fin;                                     // pinned host mirror: visible to the host when the kernel has completed
             if (Dp->record) {                                          // the pair's 64-byte record of the cross-GPU gather (ints as floats: exact below 2^24)

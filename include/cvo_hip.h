@@ -279,6 +279,9 @@ int cvo_batch_last_nonzeros(cvo_batch b, long long* nonzeros_total);
 int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]);
 /* seconds the first workgroup of each pair of the last launch spent on it (diagnostics: alignments take 33 ... 150 iterations of very different cost) */
 int cvo_batch_last_pair_seconds(cvo_batch b, int n, double* seconds);
+/* the same as spans on the device's own 100 MHz clock (one counter per device: the pairs of launches that ran side by side lie on one time axis), and the iteration
+ * at which a finished workgroup joined the pair (0 = none; joined_at may be NULL): the drain of a job, pair by pair (scripts/gpu_timeline.py) */
+int cvo_batch_last_pair_spans(cvo_batch b, int n, double* start_s, double* end_s, int* joined_at);
 /* The last launch's results as records of CVO_RESULT_FLOATS floats {transform[12], iter, A_nonzero, iterations_run, status}: the
  * payload of the cross-GPU RCCL gather.  The align kernel writes them itself when a pair ends (no pack kernel behind the
  * launch): cvo_batch_result_records hands out the DEVICE address of the record table (valid once the launch's stream has drained; it
