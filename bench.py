@@ -636,6 +636,10 @@ def main():
         ph = batch.last_phase_seconds(); its_all = sum(r["iterations_run"] for r in results)
         print("[bench] phase us/iteration under load (workgroup 0 of every pair of the last launch): " +
               str({k: round(1e6 * v / its_all, 1) for k, v in ph.items()}) + f"; culls per pair {np.mean([r['rebuilds'] for r in results]):.2f}, iterations {its_all / len(results):.1f}", file=sys.stderr, flush=True)
+        masks, pmasks = batch.last_cull_masks(len(results))
+        hist = [sum((m >> k) & 1 for m in masks) for k in range(64)]
+        print("[bench] culls by iteration (pairs of the last launch that culled at k = 0, 1, ...; 63 = later): " + " ".join(str(h) for h in hist) +
+              f"; around extrapolated positions: {sum(bin(m).count('1') for m in pmasks)}", file=sys.stderr, flush=True)
     bad = [r["status"] for r in results if r["status"] != 0]
     if bad:
         raise SystemExit(f"align kernel reported errors: {bad}")

@@ -147,6 +147,9 @@ DevParams to_dev(const cvo_params& p) {
     d.min_step = p.min_step; d.eps = p.eps; d.eps_2 = p.eps_2; d.max_iter = p.max_iter;
     d.skin = 0.25f;
     d.skin_alpha = 0.f;
+    d.nt_min = 0;
+    d.overlap_stop_test = 1;
+    d.predict = 0.7f; d.predict_steps = 8.f;   // lists built / filtered 0.7 of every point's allowance ahead on the path: -10 % culls, +1 % (profiles/r04_predicted_list_centres.txt)
     d.resort = 1;
     d.adopt_kmax = 20; d.adopt_on = 0; d.adopt_inject = 0;
     d.colocate = 1;
@@ -281,6 +284,10 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_WGS_PER_CU")) per_cu = std::max(1, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_SKIN")) { P.skin = (float)std::atof(e); skin_auto = false; }
         if (const char* e = std::getenv("CVO_HIP_SKIN_ALPHA")) { P.skin_alpha = std::max(0.f, std::min(0.2f, (float)std::atof(e))); alpha_auto = false; }
+        if (const char* e = std::getenv("CVO_HIP_PREDICT")) P.predict = std::max(0.f, std::min(0.99f, (float)std::atof(e)));
+        if (const char* e = std::getenv("CVO_HIP_PREDICT_STEPS")) P.predict_steps = std::max(0.f, (float)std::atof(e));
+        if (const char* e = std::getenv("CVO_HIP_OVERLAP_STOP")) P.overlap_stop_test = std::atoi(e) != 0;
+        if (const char* e = std::getenv("CVO_HIP_NT_MIN")) P.nt_min = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("CVO_HIP_RESORT")) P.resort = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_COLOCATE")) P.colocate = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_WIDE")) wide_waves = std::atoi(e) != 0;
@@ -1513,7 +1520,7 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
     A.trace = want_trace ? static_cast<AdaptiveRow*>(d_trace.p) : nullptr; A.trace_cap = want_trace ? trace_cap : 0; A.trace_len = static_cast<int*>(d_len.p);
     A.ell_min = ap.ell_min; A.dl_step = ap.dl_step;
     A.P.sigma = ap.sigma; A.P.sp_thres = ap.sp_thres; A.P.c = ap.c; A.P.d = ap.d; A.P.c_ell = ap.c_ell; A.P.c_sigma = ap.c_sigma;
-    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.skin_alpha = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.colocate = 0;
+    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.skin_alpha = 0.f; A.P.nt_min = 0; A.P.overlap_stop_test = 0; A.P.predict = 0.f; A.P.predict_steps = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.colocate = 0;
     A.partials = static_cast<double*>(d_part.p);
     // a few iterations are queued at a time (five small kernels each, the rows of the sweeps spread over the device); kernels queued behind a
     // stop return at once, and the host looks at the stop flag between the chunks
@@ -1698,6 +1705,12 @@ int cvo_batch_last_pair_spans(cvo_batch b, int n, double* start_s, double* end_s
         start_s[i] = 1e-8 * (double)r[i].clk_t0; end_s[i] = 1e-8 * (double)(r[i].clk_t0 + r[i].clk_ticks);
         if (joined_at) joined_at[i] = r[i].joined_at;
     }
+    return CVO_OK;
+}
+int cvo_batch_last_cull_masks(cvo_batch b, int n, unsigned long long* masks, unsigned long long* predicted) {
+    if (!b || !masks || n <= 0 || n > b->last_n) return fail(CVO_ERR_INVALID, "bad argument");
+    const PairState* r = b->eng.results();
+    for (int i = 0; i < n; ++i) { masks[i] = r[i].cull_mask; if (predicted) predicted[i] = r[i].predict_mask; }
     return CVO_OK;
 }
 int cvo_batch_last_phase_seconds(cvo_batch b, double seconds[10]) {

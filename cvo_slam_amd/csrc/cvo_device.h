@@ -22,6 +22,11 @@ struct DevParams {           // cvo.cpp:35-51
     float skin_alpha;        // depth-proportional part of the list margin: a moving point may travel skin*r + skin_alpha*|y| (its distance from the camera when the lists were
                              // built) before the lists are stale -- a rotation moves far points most, and far rows have few neighbours (density falls with 1/z^2), so their
                              // wider lists cost little; row i's list radius is (r (1 + skin) + skin_alpha |x_i|) / (1 - skin_alpha).  0 = one margin for all rows
+    float predict;           // candidate lists are built around positions extrapolated along the previous iteration's twist, this fraction of every point's allowance ahead
+                             // (0 = at the current positions); predict_steps caps the extrapolation in units of the last iteration's step
+    float predict_steps;
+    int overlap_stop_test;   // the next iteration's transform starts before the second stop test of this one (dist_se3) is done (phase_epilogue); 0 = behind it (CVO_HIP_OVERLAP_STOP)
+    int nt_min;              // experiment (CVO_HIP_NT_MIN): lists of fewer entries than this are read with plain loads instead of non-temporal ones (0 = always non-temporal)
     int resort;              // rows re-sorted after a list refinement: 0 never, 1 when the cost model says it pays (default), 2 always (tests)
     int colocate;            // the workgroups of a pair on ONE XCD (blocks b, b + 8, ... share one): they read the same moving cloud and swap partial sums through
                              // L2 twice per iteration.  Takes a launch whose pair slots are a multiple of 8; 0 = consecutive blocks (four XCDs for G = 4)
@@ -51,6 +56,8 @@ struct PairState {
     long long nonzeros_total; // nonzeros of A summed over the executed iterations (the reference's work: cvo.cpp:166-175 members, :282-306 terms)
     // wall time (100 MHz ticks) workgroup 0 of the pair spent per phase (slots as cvo_batch_last_phase_seconds documents them)
     unsigned long long clk_cycles, clk_ticks;   // shader-clock cycles and 100 MHz ticks workgroup 0 spent on the pair: cycles/ticks*100 MHz = clock
+    unsigned long long predict_mask;            // ... and the cull built its lists around extrapolated positions (DevParams::predict)
+    unsigned long long cull_mask;               // bit min(k, 63) set: iteration k began with a dense cull (diagnostics: when do the lists go stale)
     unsigned long long clk_t0;                  // the device's 100 MHz counter when workgroup 0 took the pair up (one counter for the whole device: launches can be laid on one time axis)
     unsigned long long phase_ticks[10];
 };

@@ -89,8 +89,10 @@ struct __attribute__((aligned(16))) Shared {
     float Rb;              // radius they were built with: its part that is the same for every row, r (1 + skin)
     float alpha_build;     // ... and the depth-proportional part of the margin they were built (or last filtered) with: row i holds every column within
                            // (Rb + alpha_build |x_i|) / (1 - alpha_build) of it (DevParams::skin_alpha)
-    float alpha_next;      // phase_transform -> phase_refine: the alpha the filtered lists can have
+    float reach;           // phase_transform -> phase_refine: how far the points are from where they were listed, beyond what the lists allow for by themselves
     float xmax;            // largest |x_i| of this workgroup's rows (phase_cull)
+    int predicted;         // culls of this pair whose lists were built around extrapolated positions (diagnostics)
+    int twist_ok;          // omega, v, step below are those of the pair's previous iteration (set by this workgroup's own candidate phase and epilogue)
     float ell_build;
     float fred[MAX_WAVES];
     int wsum[MAX_WAVES];
@@ -128,6 +130,8 @@ struct __attribute__((aligned(16))) Shared {
     unsigned launch_tag;   // high 16 bits of every exchange tag: this launch's sequence number (granules of earlier launches never match)
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
     unsigned long long ticks[10];   // thread 0's time per phase (PairState::phase_ticks), summed over the pair's iterations
+    unsigned long long cull_mask;   // PairState::cull_mask
+    unsigned long long predict_mask;
     unsigned long long cand_total;  // list candidates evaluated so far (PairState::candidates_total)
     unsigned long long nnz_total;   // nonzeros of A so far (PairState::nonzeros_total)
 #ifdef CVO_KTRACE
@@ -790,9 +794,13 @@ __device__ __forceinline__ float4 load_y_rt(const Ctx& c, const Lds& L, int y_mo
 // built (exact displacement of the very positions the tests use); rebuild decision.  The first PRE_T points of a thread may
 // arrive pre-loaded (the epilogue of the previous iteration fetches them while one lane does the scalar work).
 constexpr int PRE_T = 4096 / BLOCK_MAX;
+// first_worker = 64: wave 0 takes no points (the epilogue's lane 0 is still busy with the stop test of the iteration when the others start): the points are dealt
+// to threads first_worker .. nthreads - 1, `pre` as the caller loaded it with the same deal.  keep_M_on_stop: the transform was started before the stop test was
+// known; if the iteration turns out to be the pair's last, cvo::transform of that iteration (Shared::M, cvo.cpp:815) stays.
 template <int YM>
-__device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Shared* sh, const float4 (&pre)[PRE_T], bool have_pre) {
+__device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Shared* sh, const float4 (&pre)[PRE_T], bool have_pre, int first_worker = 0, bool keep_M_on_stop = false) {
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int wstride = nthreads - first_worker;
     float M[12];
     {
         float R[9], T[3];
@@ -825,12 +833,12 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
             dmax = fmaxf(dmax, disp - alpha_b * far);
         }
     };
-    int j = tid;
+    int j = tid >= first_worker ? tid - first_worker : c.nm;
     if (have_pre) {
 #pragma unroll
-        for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u]); j += nthreads; }
+        for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u]); j += wstride; }
     }
-    for (; j < c.nm; j += nthreads) one(j, ld4(c.moving + lo_off(j)));
+    for (; j < c.nm; j += wstride) one(j, ld4(c.moving + lo_off(j)));
     dmax = block_max(dmax, sh, tid, nwaves);                        // also makes ybuf / ylds visible to the workgroup
     if (tid == 0) {
         const float ell = sh->ell;
@@ -847,11 +855,10 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
         const float Rn = r_c * (1.0f + sh->P.skin);
         if (rb && have_list && !sh->dense_mode && sh->ell_build != ell && (Rn + reach) * 1.00001f <= sh->Rb) {
             rb = 2;
-            const float room = sh->Rb - (Rn + reach) * 1.00001f;
-            sh->alpha_next = fminf(sh->P.skin_alpha, 0.999f * room / (sh->xmax * 1.0001f + sh->Rb));
+            sh->reach = reach;                                      // phase_refine works the margins of the filtered lists out from it
         }
         sh->rebuild = rb;
-        for (int i = 0; i < 12; ++i) sh->M[i] = M[i];
+        if (!(keep_M_on_stop && sh->stop)) for (int i = 0; i < 12; ++i) sh->M[i] = M[i];
     }
     __syncthreads();
 }
@@ -893,12 +900,48 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     // row i is listed with radius (Rb + alpha |x_i|) / (1 - alpha) (DevParams::skin_alpha; phase_transform's staleness test is its counterpart)
     const float alpha = sh->P.skin_alpha, inv_1ma = 1.0f / (1.0f - alpha);
     float xmax_l = 0.f;
+    // The lists are built around where the cloud is HEADING, not where it is: a list stays valid while every point is within its allowance
+    // (skin r + alpha |b_j|) of the position b_j it was listed at, so with b_j a stretch ahead on the path the same radius covers up to twice the
+    // travel.  The path is extrapolated with the previous iteration's twist (the pose update of cvo.cpp:793-801 applied once more with a longer
+    // step), as far as `predict` of the allowance of every point: y moves by about t (omega x y + v), |.| <= t (|omega| |y| + |v|), so
+    // t = predict * min(skin r / |v|, alpha / |omega|) keeps every point inside.  Whether it really does is checked below, point by point, with
+    // the staleness test's own arithmetic; if not, the lists are built at the current positions after all.
+    float Mp[12];
+    bool predicted = false;
+    if (sh->P.predict > 0.f && sh->twist_ok && y_lds != 2 && sh->ell_build == sh->ell) {
+        float om[3], vv[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { om[q] = sh->omega[q]; vv[q] = sh->v[q]; }
+        const float wn = norm3f(om), vn = norm3f(vv);
+        const float beta = r_c * sh->P.skin;
+        float t = sh->P.predict * fminf(vn > 1.0e-12f ? beta / vn : 1.0e9f, wn > 1.0e-12f ? alpha / wn : 1.0e9f);
+        t = fminf(t, sh->P.predict_steps * sh->step);               // no further ahead than a few of the last iteration's steps
+        if (t > 0.f && t < 1.0e8f) {
+            float dR[9], dT[3], R[9], T[3], RdT[3], Rn[9], Tn[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = sh->R[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) T[i] = sh->T[i];
+            exp_sek3(om, vv, t, dR, dT);
+            mat3_vec(R, dT, RdT);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Tn[q] = RdT[q] + T[q];
+            mat3_mul(R, dR, Rn);
+            make_transform(Rn, Tn, Mp);
+            predicted = true;
+        }
+    }
     const bool planes = y_lds == 2;                                 // columns come straight from the resident y planes: one pass over the whole cloud
     const int span = planes ? max(c.nm, 1) : tile;
     const float* colx = planes ? L.ysx : L.lx; const float* coly = planes ? L.ysy : L.ly; const float* colz = planes ? L.ysz : L.lz;
     const int gplane = (planes ? (((tgeo >> 20) & 0x7FF) << 6) : tile) >> 5;   // stride of the eight bounding-box planes: lo/hi of x, y, z and of y/z
     const int nblk2 = (nrows + 64 * SWEEP_R - 1) / (64 * SWEEP_R);  // row-block pairs of this workgroup
     const float INF = __builtin_inff();
+    if (span < c.nm) predicted = false;                             // (the check below looks at the whole cloud in one tile)
+    bool again;
+    do {                                                            // a second trip only when the extrapolated positions turn out to be too far from the current ones
+    again = false;
+    float off_l = 0.f;
     for (int t0 = 0; t0 < c.nm; t0 += span) {
         const int tn = min(span, c.nm - t0);
         const int tnp = (tn + 31) & ~31;
@@ -910,6 +953,16 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             float lo[4] = {INF, INF, INF, INF}, hi[4] = {-INF, -INF, -INF, -INF};
             if (jj < tn) {
                 y = load_y_rt(c, L, y_lds, t0 + jj);
+                if (predicted) {
+                    const float4 p = ld4(c.moving + lo_off(t0 + jj));
+                    float b0, b1, b2;
+                    apply_transform(Mp, p.x, p.y, p.z, b0, b1, b2);
+                    const float e0 = y.x - b0, e1 = y.y - b1, e2 = y.z - b2;
+                    const float disp = sqrtf(__builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0))) * 1.0001f + 1.0e-5f;
+                    const float far = sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f;
+                    off_l = fmaxf(off_l, disp - alpha * far);       // phase_transform's test of the lists about to be built, at the current positions
+                    y.x = b0; y.y = b1; y.z = b2;
+                }
                 lo[0] = hi[0] = y.x; lo[1] = hi[1] = y.y; lo[2] = hi[2] = y.z;
                 if (y.z > 1.0e-3f) { lo[3] = hi[3] = y.y / y.z; } else { lo[3] = -INF; hi[3] = INF; }   // behind / at the camera: no slope bound
             }
@@ -931,6 +984,11 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
         }
         if (tid == 0) sh->cull_next = 0;
         __syncthreads();
+        if (predicted) {
+            // (all of the cloud is in this one tile when the prediction is on: tile >= nm is required below)
+            off_l = block_max(off_l, sh, tid, nthreads >> 6);
+            if ((r_c + off_l) * 1.00002f > Rb) { again = true; break; }   // the current positions are not inside the lists' reach: once more, at the current positions
+        }
         const int ngr = tnp >> 5;
         // Block pairs are handed out as the waves come for them: a pair's cost follows the hits of its 128 rows (near surfaces have several
         // times the neighbours of far ones) and a fixed deal of three pairs per wave left the workgroup waiting for the unluckiest wave.  A
@@ -1052,8 +1110,14 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             }
         }
     }
+    if (again) predicted = false;
+    } while (again);
     if (alpha > 0.f) xmax_l = block_max(xmax_l, sh, tid, nthreads >> 6);
-    if (tid == 0) { sh->Rb = Rb; sh->alpha_build = alpha; sh->xmax = xmax_l; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1; for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i]; }
+    if (tid == 0) {
+        sh->Rb = Rb; sh->alpha_build = alpha; sh->xmax = xmax_l; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1;
+        for (int i = 0; i < 12; ++i) sh->Mb[i] = predicted ? Mp[i] : sh->M[i];
+        if (predicted) sh->predicted += 1;
+    }
     __syncthreads();
 }
 
@@ -1216,7 +1280,7 @@ __device__ __forceinline__ void fold_entry_e(const float* xi, const float4 y4, c
 }
 
 // every iteration but the first after a rebuild: entries {ck, j} stream in, PF per lane per step, the next step's in flight
-template <int YM, bool FLAT>
+template <int YM, bool FLAT, bool NT = true>
 __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                             double (&acc8)[8]) {
     gv2u* sp = uni_ptr(c.surv + c.fbase + sh->wbase[wave]);
@@ -1231,7 +1295,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
     if (nb > 0) {
         const gv4u* eb0 = uni_ptr((const gv4u*)c.ent + wave_block(0, wave, nwaves) * 64);
 #pragma unroll
-        for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<ENT_NT(YM)>(at_off(eb0, (unsigned)lane + (unsigned)u * rp));
+        for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<(NT && ENT_NT(YM))>(at_off(eb0, (unsigned)lane + (unsigned)u * rp));
     }
     for (int bi = 0; bi < nb; ++bi) {
         const int blk = wave_block(bi, wave, nwaves);
@@ -1249,13 +1313,13 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         if (bi + 1 < nb) {
             const gv4u* eb1 = uni_ptr((const gv4u*)c.ent + wave_block(bi + 1, wave, nwaves) * 64);
 #pragma unroll
-            for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<ENT_NT(YM)>(at_off(eb1, (unsigned)lane + (unsigned)u * rp));
+            for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<(NT && ENT_NT(YM))>(at_off(eb1, (unsigned)lane + (unsigned)u * rp));
         }
         for (int n0 = 0; n0 < lw; n0 += PF) {
             if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
             v4u en4[PF / 2];
 #pragma unroll
-            for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<ENT_NT(YM)>(at_off(eb, eo + (unsigned)u * rp));
+            for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<(NT && ENT_NT(YM))>(at_off(eb, eo + (unsigned)u * rp));
             v2u eq[PF];
 #pragma unroll
             for (int u = 0; u < PF / 2; ++u) { eq[2 * u].x = eq4[u].x; eq[2 * u].y = eq4[u].y; eq[2 * u + 1].x = eq4[u].z; eq[2 * u + 1].y = eq4[u].w; }
@@ -1387,8 +1451,11 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
 
 // ---- R: ell has dropped: the lists shrink to the new radius in place.  The test is the cull's (same fused arithmetic on the
 // current positions), so the result is the list a dense cull would build now, with the colour factors it already carries.
+// shift: the lists are filtered around positions dR^T (y_j - dT) a stretch ahead on the path instead of the current y_j (phase_cull, "where the cloud is heading");
+// |x_i - dR^T (y_j - dT)| = |(dR x_i + dT) - y_j|, so the row moves once instead of every column (sh_rt = {dR row-major, dT}); the radius takes a slack for the
+// rounding of that detour.
 template <int YM>
-__device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* sh, float Rb, float alpha, int lane, int wave, int nwaves) {
+__device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* sh, float Rb, float alpha, bool shift, const float (&sh_rt)[12], int lane, int wave, int nwaves) {
     const float inv_1ma = 1.0f / (1.0f - alpha);
     int kept = 0, nb_left = 0;
     const int nb = sh->wnb[wave];
@@ -1399,7 +1466,14 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
         const int lw = uni((int)sh->blk_lmax[blk]);
         float xi[3]; load_x(c, L, sh->x_lds != 0, slot, xi);
         // the row's new list radius (Rb + alpha |x_i|) / (1 - alpha): the cull's for this ell
-        const float Ri = (Rb + alpha * sqrtf(__builtin_fmaf(xi[2], xi[2], __builtin_fmaf(xi[1], xi[1], xi[0] * xi[0]))) * 1.0001f) * inv_1ma;
+        const float xn = sqrtf(__builtin_fmaf(xi[2], xi[2], __builtin_fmaf(xi[1], xi[1], xi[0] * xi[0])));
+        float Ri = (Rb + alpha * xn * 1.0001f) * inv_1ma;
+        if (shift) {
+            const float s0 = sum3f(sh_rt[0] * xi[0], sh_rt[1] * xi[1], sh_rt[2] * xi[2]) + sh_rt[9], s1 = sum3f(sh_rt[3] * xi[0], sh_rt[4] * xi[1], sh_rt[5] * xi[2]) + sh_rt[10],
+                        s2 = sum3f(sh_rt[6] * xi[0], sh_rt[7] * xi[1], sh_rt[8] * xi[2]) + sh_rt[11];
+            xi[0] = s0; xi[1] = s1; xi[2] = s2;
+            Ri += 4.0e-6f * (1.0f + xn);
+        }
         const float nthr = -(Ri * Ri * 1.00001f);
         gv2u* wp = c.ent + 2 * slot;                                // the kept entries go to the front of the row: never ahead of the reads
         const gv2u* ep = wp;
@@ -1447,8 +1521,78 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
     const int nblk = (c.nrows + 63) >> 6;
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
     const float Rb = r_c * (1.0f + sh->P.skin);
-    const float alpha = sh->alpha_next;                             // what the old lists leave room for (phase_transform)
-    const int kept = y_lds == 1 ? refine_lists<1>(c, L, sh, Rb, alpha, lane, wave, nwaves) : (y_lds == 2 ? refine_lists<2>(c, L, sh, Rb, alpha, lane, wave, nwaves) : refine_lists<0>(c, L, sh, Rb, alpha, lane, wave, nwaves));
+    // Where the filtered lists are centred: at the current positions, or (DevParams::predict) a stretch ahead on the path, as phase_cull does -- if the old lists
+    // hold everything within the new radius of THOSE positions too: the reach of phase_transform's test, taken to the extrapolated positions, point by point.
+    float reach = sh->reach;
+    float sh_rt[12]; bool shift = false;
+    float Mn[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Mn[i] = sh->M[i];
+    if (sh->P.predict > 0.f && sh->twist_ok) {
+        float om[3], vv[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { om[q] = sh->omega[q]; vv[q] = sh->v[q]; }
+        const float wn = norm3f(om), vn = norm3f(vv);
+        float t = sh->P.predict * fminf(vn > 1.0e-12f ? r_c * sh->P.skin / vn : 1.0e9f, wn > 1.0e-12f ? sh->P.skin_alpha / wn : 1.0e9f);
+        t = fminf(t, sh->P.predict_steps * sh->step);
+        if (t > 0.f && t < 1.0e8f) {
+            float dR[9], dT[3];
+            exp_sek3(om, vv, t, dR, dT);
+            // the extrapolated transform dR^T (M p - dT), and how far it takes the points from where they were listed
+            float Mp[12];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Mp[r * 4 + q] = sum3f(dR[0 * 3 + r] * Mn[0 * 4 + q], dR[1 * 3 + r] * Mn[1 * 4 + q], dR[2 * 3 + r] * Mn[2 * 4 + q]);
+                Mp[r * 4 + 3] = sum3f(dR[0 * 3 + r] * (Mn[3] - dT[0]), dR[1 * 3 + r] * (Mn[7] - dT[1]), dR[2 * 3 + r] * (Mn[11] - dT[2]));
+            }
+            float Mbo[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) Mbo[i] = sh->Mb[i];
+            const float alpha_o = sh->alpha_build;
+            float far_l = 0.f;
+            for (int j = tid; j < c.nm; j += nthreads) {
+                const float4 pj = ld4(c.moving + lo_off(j));
+                float n0, n1, n2, b0, b1, b2;
+                apply_transform(Mp, pj.x, pj.y, pj.z, n0, n1, n2);
+                apply_transform(Mbo, pj.x, pj.y, pj.z, b0, b1, b2);
+                const float e0 = n0 - b0, e1 = n1 - b1, e2 = n2 - b2;
+                const float disp = sqrtf(__builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0))) * 1.0001f + 1.0e-5f;
+                const float far = sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f;
+                far_l = fmaxf(far_l, disp - alpha_o * far);
+            }
+            far_l = block_max(far_l, sh, tid, nwaves);
+            if ((Rb + far_l) * 1.00001f <= sh->Rb) {
+                // ... and the CURRENT positions have to be within the reach of lists centred there (this iteration walks them): phase_transform's test of the
+                // lists about to be made, with the margin they will have
+                const float alpha_p = fmaxf(0.f, fminf(sh->P.skin_alpha, 0.999f * (sh->Rb - (Rb + far_l) * 1.00001f) / (sh->xmax * 1.0001f + sh->Rb)));
+                float off_l = 0.f;
+                for (int j = tid; j < c.nm; j += nthreads) {
+                    const float4 pj = ld4(c.moving + lo_off(j));
+                    float n0, n1, n2, y0, y1, y2;
+                    apply_transform(Mp, pj.x, pj.y, pj.z, n0, n1, n2);
+                    apply_transform(Mn, pj.x, pj.y, pj.z, y0, y1, y2);
+                    const float e0 = y0 - n0, e1 = y1 - n1, e2 = y2 - n2;
+                    const float disp = sqrtf(__builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0))) * 1.0001f + 1.0e-5f;
+                    const float far = sqrtf(__builtin_fmaf(n2, n2, __builtin_fmaf(n1, n1, n0 * n0))) * 0.9999f;
+                    off_l = fmaxf(off_l, disp - alpha_p * far);
+                }
+                off_l = block_max(off_l, sh, tid, nwaves);
+                if ((r_c + off_l) * 1.00002f <= Rb) {
+                    shift = true; reach = far_l;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) sh_rt[i] = dR[i];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) sh_rt[9 + q] = dT[q];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) Mn[i] = Mp[i];
+                }
+            }
+        }
+    }
+    // the depth-proportional margin the old lists leave room for (see phase_transform's test)
+    const float alpha = fmaxf(0.f, fminf(sh->P.skin_alpha, 0.999f * (sh->Rb - (Rb + reach) * 1.00001f) / (sh->xmax * 1.0001f + sh->Rb)));
+    const int kept = y_lds == 1 ? refine_lists<1>(c, L, sh, Rb, alpha, shift, sh_rt, lane, wave, nwaves) : (y_lds == 2 ? refine_lists<2>(c, L, sh, Rb, alpha, shift, sh_rt, lane, wave, nwaves) : refine_lists<0>(c, L, sh, Rb, alpha, shift, sh_rt, lane, wave, nwaves));
     if (lane == 0) sh->wsum[wave] = kept;
     __syncthreads();
     if (tid == 0) {
@@ -1457,7 +1601,8 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
         for (int w = 0; w < nwaves; ++w) tot += sh->wsum[w];
         for (int bq = 0; bq < nblk; ++bq) { const int lm = (int)sh->blk_lmax[bq]; lmax_new = max(lmax_new, lm); walked += 64 * PF * ((lm + PF - 1) / PF); }
         sh->total = tot; sh->lmax = lmax_new; sh->Rb = Rb; sh->alpha_build = alpha; sh->ell_build = sh->ell; sh->refines += 1;
-        for (int i = 0; i < 12; ++i) sh->Mb[i] = sh->M[i];          // displacements count from here again
+        for (int i = 0; i < 12; ++i) sh->Mb[i] = Mn[i];             // displacements count from here again
+        if (shift) sh->predicted += 1;
         // Re-sort (below) when it pays: it costs about 25 us + 1.7 ns per list entry (measured: 31 us at 13 k entries, 68 at 48 k, 240 at
         // 126 k -- the lists change columns, 64 cache lines per wave load) and saves 0.28 ns per list slot no longer walked, in every
         // iteration until the next rebuild: those left at this ell by the schedule of cvo.cpp:810-812, 24 assumed at the last one.
@@ -1532,6 +1677,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
         } else
 #endif
         if (fresh_list) { if (gates.poly_ok) CVO_CAND(cand_fresh, true); else CVO_CAND(cand_fresh, false); }
+        else if (y_lds == 1 && gates.poly_ok && sh->total < sh->P.nt_min) cand_steady<1, true, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);   // short lists: plain loads (DevParams::nt_min)
         else { if (gates.poly_ok) CVO_CAND(cand_steady, true); else CVO_CAND(cand_steady, false); }
 #undef CVO_CAND
         if (tid == 0) acc8[7] = (double)sh->total;
@@ -1706,32 +1852,37 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
     // every lane fetches its share of the moving cloud for the NEXT iteration's transform while lane 0 does the scalar work
+    // In the resident float4 layout waves 1 .. n-1 take all the points: they transform them while lane 0 of wave 0 is still at the second stop test (dist_se3,
+    // a third of its scalar work), which the transform does not need -- only R and T.
+    const bool next_T = k + 1 < max_iter;
+    const int first_worker = (y_lds == 1 && blockDim.x > 64 && sh->P.overlap_stop_test) ? 64 : 0;
     float4 pre[PRE_T];
     {
-        int j = threadIdx.x;
+        int j = (int)threadIdx.x >= first_worker ? (int)threadIdx.x - first_worker : c.nm;
 #pragma unroll
-        for (int u = 0; u < PRE_T; ++u) { pre[u] = (j < c.nm) ? ld4(c.moving + lo_off(j)) : make_float4(0.f, 0.f, 0.f, 0.f); j += blockDim.x; }
+        for (int u = 0; u < PRE_T; ++u) { pre[u] = (j < c.nm) ? ld4(c.moving + lo_off(j)) : make_float4(0.f, 0.f, 0.f, 0.f); j += (int)blockDim.x - first_worker; }
     }
 #ifdef CVO_KTRACE
     const unsigned long long ke0 = CVO_NOW();
 #endif
+    // Lane 0's scalar work in two parts with a workgroup barrier between them (every wave passes it once): A = step, first stop test, pose update -- what the
+    // next transform needs; B = second stop test (dist_se3), ell schedule, adoption word, trace.
+    unsigned long long aword = 0;
+    float step = 0.f, ell = 0.f, dR[9], dT[3], omega[3], v[3];
+    double B = 0, C = 0, Dd = 0, E = 0;
+    bool stop_a = false;
     if (threadIdx.x == 0) {
         const DevParams& P = sh->P;
         // has a finished workgroup of the launch asked to help with this pair?  (the load returns under the scalar work below)
-        unsigned long long aword = 0;
         if (sh->adopt_word) aword = __hip_atomic_load((gu64*)sh->adopt_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double B = sh->vals[0], C = sh->vals[1], Dd = sh->vals[2], E = sh->vals[3];
-        float omega[3], v[3];
+        B = sh->vals[0]; C = sh->vals[1]; Dd = sh->vals[2]; E = sh->vals[3];
         for (int q = 0; q < 3; ++q) { omega[q] = sh->omega[q]; v[q] = sh->v[q]; }
-        const float ell = sh->ell;
+        ell = sh->ell;
         const float c3 = (float)(4.0 * float(E)), c2 = (float)(3.0 * float(Dd)), c1 = (float)(2.0 * float(C)), c0 = float(B);   // cvo.cpp:318
-        const float step = cubic_step(c3, c2, c1, c0, P.min_step);
-        float dist = -1.f;
-        int stop = 0;
-        if (norm3f(omega) < P.eps && norm3f(v) < P.eps) {                               // cvo.cpp:782
-            stop = 1;
-        } else {
-            float dR[9], dT[3], R[9], T[3], RdT[3], Rn[9];
+        step = cubic_step(c3, c2, c1, c0, P.min_step);
+        stop_a = norm3f(omega) < P.eps && norm3f(v) < P.eps;                            // cvo.cpp:782
+        if (!stop_a) {
+            float R[9], T[3], RdT[3], Rn[9];
             for (int i = 0; i < 9; ++i) R[i] = sh->R[i];
             for (int i = 0; i < 3; ++i) T[i] = sh->T[i];
             exp_sek3(omega, v, step, dR, dT);                                           // cvo.cpp:793
@@ -1739,6 +1890,16 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
             for (int q = 0; q < 3; ++q) sh->T[q] = RdT[q] + T[q];                        // cvo.cpp:800
             mat3_mul(R, dR, Rn);
             for (int i = 0; i < 9; ++i) sh->R[i] = Rn[i];                                // cvo.cpp:801
+        }
+        sh->stop = 0;
+    }
+    __syncthreads();                                                 // R, T are out
+    if (threadIdx.x == 0) {
+        const DevParams& P = sh->P;
+        float dist = -1.f;
+        int stop = 0;
+        if (stop_a) stop = 1;
+        else {
             dist = dist_se3(dR, dT);
             if (dist < P.eps_2) stop = 1;                                               // cvo.cpp:804
         }
@@ -1750,7 +1911,7 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
             l = (k > 19) ? (float)0.03 : l;
             sh->ell = l;
         }
-        sh->stop = stop; sh->step = step; sh->dist = dist;
+        sh->stop = stop; sh->step = step; sh->dist = dist; sh->twist_ok = 1;
         sh->adopt_req = ((unsigned)(aword >> 32) == (sh->launch_tag | ADOPT_REQUEST)) ? 1 + (int)(unsigned)aword : 0;
         if (sh->adopt_word && (unsigned)(aword >> 32) == (sh->launch_tag | ADOPT_FREE) && !stop) {   // tell would-be helpers how far this pair has come (a CAS: an offer made meanwhile stays)
             unsigned long long e = aword;
@@ -1765,12 +1926,18 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
             *c.trace_len = k + 1;
         }
     }
-    __syncthreads();
 #ifdef CVO_KTRACE
     const unsigned long long ke1 = CVO_NOW();
 #endif
-    if (!sh->stop && k + 1 < max_iter) {                             // T of iteration k+1 (cvo.cpp:770-771)
-        if (y_lds == 1) transform_body_t<1>(c, L, sh, pre, true); else transform_large(Dp, g, G, tgeo, y_lds);
+    if (first_worker && next_T) {
+        // T of iteration k+1 (cvo.cpp:770-771), begun before this iteration's second stop test is known: should it fire, the transformed cloud is simply not
+        // used (the state written back is R, T; Shared::M keeps the transform of the last executed iteration).  Its barriers publish lane 0's part B.
+        transform_body_t<1>(c, L, sh, pre, true, first_worker, true);
+    } else {
+        __syncthreads();                                             // sh->stop and the rest of lane 0's results, for everyone
+        if (!sh->stop && next_T) {                                   // T of iteration k+1 (cvo.cpp:770-771)
+            if (y_lds == 1) transform_body_t<1>(c, L, sh, pre, true); else transform_large(Dp, g, G, tgeo, y_lds);
+        }
     }
 #ifdef CVO_KTRACE
     if (threadIdx.x == 0) { sh->ksub[2] = ke1 - ke0; sh->ksub[3] = CVO_NOW() - ke1; }
@@ -1936,7 +2103,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 #pragma unroll
             for (int i = 0; i < 3; ++i) { Ts[i] = sh->T[i]; sh->T[i] = 0.f; }
             sh->list_valid = 0;
-            sh->P.skin = 0.f; sh->P.skin_alpha = 0.f;                                   // nothing moves any more: the cull's radius is r_c itself (restored below)
+            sh->P.skin = 0.f; sh->P.skin_alpha = 0.f; sh->twist_ok = 0;                                   // nothing moves any more: the cull's radius is r_c itself (restored below)
         }
         __syncthreads();
         transform_body_t<1>(c, L, sh, none, false);                                     // y = p
@@ -2178,8 +2345,8 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             sh->iter_at_break = k_join ? (int)__hip_atomic_load((const CVO_GLOBAL unsigned*)&st->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->iter;
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
             for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
-            sh->cand_total = 0; sh->nnz_total = 0;
-            sh->P.skin = P.skin; sh->P.skin_alpha = P.skin_alpha; sh->alpha_build = 0.f; sh->alpha_next = 0.f; sh->xmax = 0.f; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
+            sh->cand_total = 0; sh->nnz_total = 0; sh->cull_mask = 0ull; sh->predict_mask = 0ull;
+            sh->P.skin = P.skin; sh->P.skin_alpha = P.skin_alpha; sh->alpha_build = 0.f; sh->reach = 0.f; sh->xmax = 0.f; sh->twist_ok = 0; sh->predicted = 0; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
         // a helper has read what the owner published for it: if the pair may grow further, its word takes offers again (not earlier --
@@ -2213,9 +2380,10 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
                     phase_cull(Dp, ge, Ge, tgeo, y_lds);
                     phase_sort(Dp, ge, Ge, tgeo, y_lds);
                 }
-                if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], CVO_NOW() - t_b); }
+                if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], CVO_NOW() - t_b); sh->cull_mask |= 1ull << min(k, 63); if (sh->predicted) { sh->predict_mask |= 1ull << min(k, 63); sh->predicted = 0; } }
             } else if (sh->rebuild == 2) {
                 phase_refine(Dp, ge, Ge, tgeo, y_lds, k);
+                if (tid == 0 && sh->predicted) { sh->predict_mask |= 1ull << min(k, 63); sh->predicted = 0; }
             }
             CVO_PHASE(0);
             phase_candidates(Dp, ge, Ge, tgeo, y_lds, k);
@@ -2332,7 +2500,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             fin.candidates_total = (long long)sh->cand_total; fin.nonzeros_total = (long long)sh->nnz_total;
             for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
             fin.phase_ticks[7] = sh->sub[0]; fin.phase_ticks[9] = sh->sub[1]; fin.phase_ticks[2] = sh->sub[2]; fin.phase_ticks[4] = sh->sub[3];
-            fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0; fin.clk_t0 = clk_t0;
+            fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0; fin.clk_t0 = clk_t0; fin.cull_mask = sh->cull_mask; fin.predict_mask = sh->predict_mask;
             *Dp->state = fin;                                          // device copy: the next launch may start from it
             *Dp->state_host = fin;                                     // pinned host mirror: visible to the host when the kernel has completed
             if (Dp->record) {                                          // the pair's 64-byte record of the cross-GPU gather (ints as floats: exact below 2^24)

@@ -282,6 +282,9 @@ int cvo_batch_last_pair_seconds(cvo_batch b, int n, double* seconds);
 /* the same as spans on the device's own 100 MHz clock (one counter per device: the pairs of launches that ran side by side lie on one time axis), and the iteration
  * at which a finished workgroup joined the pair (0 = none; joined_at may be NULL): the drain of a job, pair by pair (scripts/gpu_timeline.py) */
 int cvo_batch_last_pair_spans(cvo_batch b, int n, double* start_s, double* end_s, int* joined_at);
+/* diagnostics: bit min(k, 63) of masks[i] is set when iteration k of pair i began with a dense cull (the candidate lists had gone stale, or were not there yet);
+ * predicted[i] (may be NULL): the culls that built their lists around extrapolated positions */
+int cvo_batch_last_cull_masks(cvo_batch b, int n, unsigned long long* masks, unsigned long long* predicted);
 /* The last launch's results as records of CVO_RESULT_FLOATS floats {transform[12], iter, A_nonzero, iterations_run, status}: the
  * payload of the cross-GPU RCCL gather.  The align kernel writes them itself when a pair ends (no pack kernel behind the
  * launch): cvo_batch_result_records hands out the DEVICE address of the record table (valid once the launch's stream has drained; it

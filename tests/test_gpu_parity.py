@@ -134,6 +134,9 @@ def test_workgroup_counts_tiles_and_overflow_fallback_agree(hiplib, oracle):
                # depth-proportional list margin (DevParams::skin_alpha): alone, with the constant part, large, under the plane layout and with forced re-sorts
                dict(wgs=1, CVO_HIP_SKIN=0.0, CVO_HIP_SKIN_ALPHA=0.02), dict(wgs=2, CVO_HIP_SKIN=0.05, CVO_HIP_SKIN_ALPHA=0.0125), dict(wgs=3, CVO_HIP_SKIN=0.35, CVO_HIP_SKIN_ALPHA=0.15),
                dict(wgs=1, CVO_HIP_SKIN_ALPHA=0.01, CVO_HIP_Y_MODE=2), dict(wgs=2, CVO_HIP_SKIN=0.1, CVO_HIP_SKIN_ALPHA=0.03, CVO_HIP_RESORT=2), dict(wgs=1, CVO_HIP_SKIN_ALPHA=0.05, CVO_HIP_NO_YLDS=1),
+               # lists built / filtered around extrapolated positions (DevParams::predict): off, far ahead, far ahead with wide margins, under the plane layout
+               dict(wgs=1, CVO_HIP_PREDICT=0.0), dict(wgs=2, CVO_HIP_PREDICT=0.95, CVO_HIP_PREDICT_STEPS=50), dict(wgs=1, CVO_HIP_PREDICT=0.9, CVO_HIP_SKIN=0.3, CVO_HIP_SKIN_ALPHA=0.05, CVO_HIP_PREDICT_STEPS=50),
+               dict(wgs=2, CVO_HIP_PREDICT=0.9, CVO_HIP_Y_MODE=2), dict(wgs=3, CVO_HIP_PREDICT=0.9, CVO_HIP_RESORT=2),
                dict(wgs=1, CVO_HIP_NO_YLDS=1), dict(wgs=3, CVO_HIP_NO_YLDS=1, CVO_HIP_TILE=128),          # transformed cloud in HBM/L2, not LDS
                dict(wgs=1, CVO_HIP_Y_MODE=2), dict(wgs=4, CVO_HIP_Y_MODE=2, CVO_HIP_TILE=256), dict(wgs=2, CVO_HIP_Y_MODE=0),   # 12-byte LDS layout / forced HBM
                dict(wgs=1, CVO_HIP_ROW_CAP=8), dict(wgs=2, CVO_HIP_ROW_CAP=16, CVO_HIP_SKIN=0.6),         # rows longer than the lists hold
