@@ -193,16 +193,19 @@ def latency_probe(ca, pairs, device):
     # one live tracking step from images, the reference's per-frame sequence (local_tracker.cpp:356-431): odometry object
     # match_odometry(frame), keyframe object match_keyframe(frame) + compute_innerproduct; fresh objects per repetition
     (_, _), (fb, db), _ = synth.make_frames(0)
-    tr = []
-    for _ in range(5):
-        odo, kf = ca.Cvo(device=device), ca.Cvo(device=device)
-        odo.set_pcd_images(fa, da, camt); kf.set_pcd_images(fa, da, camt)
-        t0 = time.perf_counter()
-        odo.match_odometry_images(fb, db, camt)
-        tfk = kf.match_keyframe_images(fb, db, camt)
-        kf.compute_innerproduct(tfk.astype(np.float32))
-        tr.append(time.perf_counter() - t0)
-        odo.close(); kf.close()
+    tr, trf = [], []
+    for full in (False, True):     # full: with the odometry object's score block too, as local_tracker.cpp:356-431 has it (the series up to round 3 timed the keyframe object's only)
+        for _ in range(5):
+            odo, kf = ca.Cvo(device=device), ca.Cvo(device=device)
+            odo.set_pcd_images(fa, da, camt); kf.set_pcd_images(fa, da, camt)
+            t0 = time.perf_counter()
+            tfo = odo.match_odometry_images(fb, db, camt)
+            if full:
+                odo.compute_innerproduct(tfo.astype(np.float32))
+            tfk = kf.match_keyframe_images(fb, db, camt)
+            kf.compute_innerproduct(tfk.astype(np.float32))
+            (trf if full else tr).append(time.perf_counter() - t0)
+            odo.close(); kf.close()
     pc = []
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -216,7 +219,7 @@ def latency_probe(ca, pairs, device):
     img_bytes = fa.size + 2 * da.size
     return {"single_pair_align_ms": med(al), "single_pair_score_block_ms": med(sc), "lc_candidates": n,
             "set_pcd_images_ms": med(pg[2:]), "set_pcd_images_points": int(n_pts), "set_pcd_images_input_MB": img_bytes / 1e6,
-            "set_pcd_images_cpu_port_ms": med(pc), "tracker_frame_from_images_ms": med(tr),
+            "set_pcd_images_cpu_port_ms": med(pc), "tracker_frame_from_images_ms": med(tr), "tracker_frame_with_both_score_blocks_ms": med(trf),
             "lc_batch_align_ms": med(la), "lc_batch_score_block_ms": med(ls), "note": "host wall time per call, median of 5, automatic workgroup count"}
 
 

@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_comm_info", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
     "cvo_batch_set_pairs", "cvo_batch_result_records", "cvo_shard_block", "cvo_batch_gather_results_padded", "cvo_batch_padded_records",
-    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds", "cvo_batch_last_pair_spans", "cvo_batch_last_cull_masks", "cvo_batch_last_nonzeros",
+    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds", "cvo_batch_last_pair_spans", "cvo_set_tail_scores", "cvo_batch_last_cull_masks", "cvo_batch_last_nonzeros",
 ]
 
 _lib = None
@@ -216,6 +216,7 @@ def load_library():
     L.cvo_batch_set_tail_scores.argtypes = [vp, C.c_int]
     L.cvo_batch_last_tail_answers.argtypes = [vp, C.c_int, ip]
     L.cvo_batch_last_pair_seconds.argtypes = [vp, C.c_int, dp]
+    L.cvo_set_tail_scores.argtypes = [vp, C.c_int]
     L.cvo_batch_last_pair_spans.argtypes = [vp, C.c_int, dp, dp, C.POINTER(C.c_int)]
     L.cvo_batch_last_cull_masks.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.cvo_batch_last_nonzeros.argtypes = [vp, C.POINTER(C.c_longlong)]
@@ -493,6 +494,10 @@ class Cvo:
 
     def set_workgroups(self, g: int):
         _check(self.L.cvo_set_workgroups(self.h, int(g)))
+
+    def set_tail_scores(self, on: bool):
+        """cvo_set_tail_scores: the align launch answers the tracker's score block itself (default) or leaves it to the score kernel"""
+        _check(self.L.cvo_set_tail_scores(self.h, int(bool(on))))
 
 
 RESULT_FLOATS = 16      # CVO_RESULT_FLOATS

@@ -1100,6 +1100,16 @@ struct cvo_handle_s {
     int iter = 0, A_nonzero = 0;
     int num_want = 3000;                                             // pcd_generator.cpp:22
     Cloud scratch_a, scratch_b;                                      // host clouds handed to function_inner_product / se3_Hessian directly
+    // The tracker calls compute_innerproduct(tran = the transform it has just been given) right behind every match_* (local_tracker.cpp:356-375, 415-431): with
+    // cvo_set_tail_scores(h, 1) the align launch answers that block in its tail (Engine::tail_scores) and the answers wait here for the call -- valid for
+    // exactly these clouds, this ell and this transform; anything else goes to the score kernel as before.  Off by default: one pair alone runs on eight cooperating
+    // workgroups, whose tail (a transform, a cull, two list walks, five exchanges) costs the launch 0.12 ms where the score launch behind it costs 0.07-0.10
+    // (profiles/r04_tracker_path.txt); batches, one workgroup per pair with every CU busy, are where it pays (cvo_batch_set_tail_scores).
+    bool tail_scores = false;
+    bool tail_valid = false;
+    double tail_r[5][24];
+    const Cloud* tail_fixed = nullptr; const Cloud* tail_moving = nullptr;
+    float tail_ell = 0.f, tail_tran[12];
 };
 
 struct cvo_batch_s {
@@ -1131,6 +1141,8 @@ int do_align(cvo_handle_s* h, cvo_trace_row* trace, int trace_cap, int* trace_le
     std::memcpy(st.transform, h->transform.m, sizeof(st.transform));
     std::vector<Engine::PairIn> pairs{{h->fixed.get(), h->moving.get()}};
     const bool want_trace = trace && trace_cap > 0;
+    h->tail_valid = false;
+    h->eng.tail_scores = h->tail_scores;
     int rc = h->eng.launch(pairs, &st, true, nullptr, want_trace, trace_cap); if (rc) return rc;
     if (want_trace) {
         // results copy is already queued; queue the trace copies behind it on the same stream
@@ -1146,6 +1158,12 @@ int do_align(cvo_handle_s* h, cvo_trace_row* trace, int trace_cap, int* trace_le
     h->prev_transform = prev;                                        // cvo.cpp:815
     h->accum_transform = aff_mul(h->accum_transform, prev);          // cvo.cpp:816
     std::memcpy(h->transform.m, r.transform, sizeof(float) * 12);    // update_tf, cvo.cpp:817
+    if (h->eng.last_tail) {                                           // the score block this launch answered in its tail, for the compute_innerproduct that follows
+        std::memcpy(h->tail_r, h->eng.h_tail.p, sizeof(h->tail_r));
+        h->tail_fixed = h->fixed.get(); h->tail_moving = h->moving.get(); h->tail_ell = h->ell;
+        std::memcpy(h->tail_tran, h->transform.m, sizeof(h->tail_tran));
+        h->tail_valid = true;
+    }
     return CVO_OK;
 }
 }  // namespace
@@ -1212,6 +1230,7 @@ int cvo_set_pcd(cvo_handle h, const float* xyz, const float* feat, int n) {
     return CVO_OK;
 }
 
+int cvo_set_tail_scores(cvo_handle h, int on) { if (!h) return fail(CVO_ERR_INVALID, "null handle"); h->tail_scores = on != 0; if (!on) h->tail_valid = false; return CVO_OK; }
 int cvo_set_num_want(cvo_handle h, int num_want) {
     if (!h || num_want <= 0) return fail(CVO_ERR_INVALID, "bad argument");
     h->num_want = num_want; return CVO_OK;
@@ -1366,7 +1385,22 @@ int cvo_compute_innerproduct(cvo_handle h, cvo_inn_p* inn_pre, cvo_inn_p* inn_po
                                     {mv, nullptr, mv, false, h->ell},        // cvo.cpp:497
                                     {mv, tran, fx, true, h->ell}};           // cvo.cpp:500
     double r[5][24];
-    int rc = h->eng.score_many(rq, 5, r); if (rc) return rc;
+    int rc;
+    if (h->tail_valid && h->tail_fixed == fx && h->tail_moving == mv && h->tail_ell == h->ell && std::memcmp(h->tail_tran, tran, sizeof(h->tail_tran)) == 0) {
+        // answered by the align launch itself; what its workgroups could not answer (PairDesc::score_out[23]) goes to the score kernel now
+        std::memcpy(r, h->tail_r, sizeof(r));
+        static const int bit_of[5] = {TAIL_PRE, TAIL_POST, TAIL_FIXED, TAIL_MOVING, TAIL_HESSIAN};
+        const int mask = (int)r[0][23];
+        Engine::ScoreReq miss[5]; int where[5], nmiss = 0;
+        for (int q = 0; q < 5; ++q) if (!(mask & bit_of[q])) { miss[nmiss] = rq[q]; where[nmiss++] = q; }
+        if (nmiss) {
+            double extra[5][24];
+            rc = h->eng.score_many(miss, nmiss, extra); if (rc) return rc;
+            for (int k = 0; k < nmiss; ++k) std::memcpy(r[where[k]], extra[k], sizeof(double) * 24);
+        }
+    } else {
+        rc = h->eng.score_many(rq, 5, r); if (rc) return rc;
+    }
     finish_inn_p(r[0], inn_pre); finish_inn_p(r[1], inn_post); finish_inn_p(r[2], inn_fixed_pcd); finish_inn_p(r[3], inn_moving_pcd);
     *cos_angle = inn_post->value / (sqrtf(inn_fixed_pcd->value) * sqrtf(inn_moving_pcd->value));                  // cvo.cpp:498
     *inliers += (int)r[4][1];                                        // cvo.cpp:708

@@ -797,8 +797,11 @@ constexpr int PRE_T = 4096 / BLOCK_MAX;
 // first_worker = 64: wave 0 takes no points (the epilogue's lane 0 is still busy with the stop test of the iteration when the others start): the points are dealt
 // to threads first_worker .. nthreads - 1, `pre` as the caller loaded it with the same deal.  keep_M_on_stop: the transform was started before the stop test was
 // known; if the iteration turns out to be the pair's last, cvo::transform of that iteration (Shared::M, cvo.cpp:815) stays.
+// preb (may be null): for the pre-loaded points, {where the point was listed (Mb p), alpha_build x its distance from the camera there}: that half of the
+// staleness test does not depend on the new pose, the epilogue works it out while lane 0 is at the step and the pose update.
 template <int YM>
-__device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Shared* sh, const float4 (&pre)[PRE_T], bool have_pre, int first_worker = 0, bool keep_M_on_stop = false) {
+__device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Shared* sh, const float4 (&pre)[PRE_T], bool have_pre, int first_worker = 0, bool keep_M_on_stop = false,
+                                                 const float4* preb = nullptr) {
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int wstride = nthreads - first_worker;
     float M[12];
@@ -818,27 +821,30 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
     // its neighbourhood allow for by themselves (alpha_build x its distance from the camera at build time; 0 with one margin for all rows)
     float dmax = 0.f;
     const float alpha_b = sh->alpha_build;
-    auto one = [&](int j, const float4 lo) {
+    auto one = [&](int j, const float4 lo, const float4* bq) {
         float y0, y1, y2;
         apply_transform(M, lo.x, lo.y, lo.z, y0, y1, y2);
         if (YM == 1) L.ylds[j] = make_float4(y0, y1, y2, lo.w);     // the cloud stays in LDS for the whole iteration ...
         else if (YM == 2) { L.ysx[j] = y0; L.ysy[j] = y1; L.ysz[j] = y2; }
         else c.ybuf.set(j, make_float4(y0, y1, y2, lo.w));          // ... or, too large for that, in HBM/L2
         if (have_list) {                                            // where the point was when the lists were built: the same arithmetic, then
-            float b0, b1, b2;
-            apply_transform(Mb, lo.x, lo.y, lo.z, b0, b1, b2);
+            float b0, b1, b2, afar;
+            if (bq) { b0 = bq->x; b1 = bq->y; b2 = bq->z; afar = bq->w; }
+            else {
+                apply_transform(Mb, lo.x, lo.y, lo.z, b0, b1, b2);
+                afar = alpha_b * (sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f);
+            }
             const float e0 = y0 - b0, e1 = y1 - b1, e2 = y2 - b2;
             const float disp = sqrtf(__builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0))) * 1.0001f + 1.0e-5f;
-            const float far = sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f;
-            dmax = fmaxf(dmax, disp - alpha_b * far);
+            dmax = fmaxf(dmax, disp - afar);
         }
     };
     int j = tid >= first_worker ? tid - first_worker : c.nm;
     if (have_pre) {
 #pragma unroll
-        for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u]); j += wstride; }
+        for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u], preb ? &preb[u] : nullptr); j += wstride; }
     }
-    for (; j < c.nm; j += wstride) one(j, ld4(c.moving + lo_off(j)));
+    for (; j < c.nm; j += wstride) one(j, ld4(c.moving + lo_off(j)), nullptr);
     dmax = block_max(dmax, sh, tid, nwaves);                        // also makes ybuf / ylds visible to the workgroup
     if (tid == 0) {
         const float ell = sh->ell;
@@ -1865,6 +1871,19 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 #ifdef CVO_KTRACE
     const unsigned long long ke0 = CVO_NOW();
 #endif
+    float4 preb[PRE_T];
+    if (first_worker && next_T && (int)threadIdx.x >= first_worker && sh->list_valid) {   // (the waves that wait for lane 0 anyway)
+        float Mb[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Mb[i] = sh->Mb[i];
+        const float alpha_b = sh->alpha_build;
+#pragma unroll
+        for (int u = 0; u < PRE_T; ++u) {
+            float b0, b1, b2;
+            apply_transform(Mb, pre[u].x, pre[u].y, pre[u].z, b0, b1, b2);
+            preb[u] = make_float4(b0, b1, b2, alpha_b * (sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f));
+        }
+    }
     // Lane 0's scalar work in two parts with a workgroup barrier between them (every wave passes it once): A = step, first stop test, pose update -- what the
     // next transform needs; B = second stop test (dist_se3), ell schedule, adoption word, trace.
     unsigned long long aword = 0;
@@ -1932,7 +1951,7 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
     if (first_worker && next_T) {
         // T of iteration k+1 (cvo.cpp:770-771), begun before this iteration's second stop test is known: should it fire, the transformed cloud is simply not
         // used (the state written back is R, T; Shared::M keeps the transform of the last executed iteration).  Its barriers publish lane 0's part B.
-        transform_body_t<1>(c, L, sh, pre, true, first_worker, true);
+        transform_body_t<1>(c, L, sh, pre, true, first_worker, true, preb);
     } else {
         __syncthreads();                                             // sh->stop and the rest of lane 0's results, for everyone
         if (!sh->stop && next_T) {                                   // T of iteration k+1 (cvo.cpp:770-771)

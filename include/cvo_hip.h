@@ -112,6 +112,12 @@ typedef struct cvo_camera { float scaling_factor, fx, fy, cx, cy; } cvo_camera;
 int cvo_set_pcd_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height,
                        const cvo_camera* cam);
 /* pcd_generator::num_want (3000, pcd_generator.cpp:22) for this handle's later cvo_set_pcd_images calls */
+/* The tracker calls compute_innerproduct(tran = the transform match_* has just returned) behind every alignment (local_tracker.cpp:356-375, 415-431;
+ * cvo.cpp:475-503): on = 1 lets the align launch of this handle answer that score block in its tail (as cvo_batch_set_tail_scores does for batches);
+ * cvo_compute_innerproduct then returns those answers when it is asked for exactly that transform on the same clouds, and runs the score kernel for any
+ * other request.  Same numbers either way (tests/test_gpu_tail_scores.py).  Off by default: for one pair alone on its cooperating workgroups the tail
+ * costs more than the score launch it saves. */
+int cvo_set_tail_scores(cvo_handle h, int on);
 int cvo_set_num_want(cvo_handle h, int num_want);
 /* match_odometry / match_keyframe taking the images, exactly as the reference's signatures do */
 int cvo_match_odometry_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height,

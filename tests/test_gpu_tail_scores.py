@@ -139,3 +139,29 @@ def test_members_with_different_list_margins_agree_in_the_tail(hiplib, oracle):
         ref.close(); B.close()
     assert time.perf_counter() - t0 < 3.0                              # nobody waited for an exchange that never came (3 s each)
     assert partly >= 1, partly
+
+
+def test_single_handle_compute_innerproduct_answered_by_the_align_launch(hiplib, oracle):
+    """cvo_set_tail_scores (default on): match_* + compute_innerproduct(tran = the result), the tracker's sequence (local_tracker.cpp:356-375), on ONE handle --
+    the score block comes out of the align launch's tail; against the score-kernel path (tail off) and the oracle, for several workgroup counts; another
+    transform than the result, or a changed ell, must not be answered from the tail."""
+    from cvo_slam_amd import synth
+    for seed, n, wgs in ((41, 700, 1), (42, 1500, 2), (43, 2048, 0), (3, 0, 0), (3, 0, 4)):
+        p = synth.make_pair(seed) if n == 0 else synth.make_small_pair(1700 + seed, n=n)
+        o = oracle.OracleCvo(); o.set_pcd(p.fixed.xyz, p.fixed.feat); rc, _ = o.match(p.moving.xyz, p.moving.feat); assert rc == 0
+        rc, want = o.compute_innerproduct(o.get_state()["transform"]); assert rc == 0
+        got = {}
+        for tail in (True, False):
+            g = hiplib.Cvo(); g.set_workgroups(wgs); g.set_tail_scores(tail)
+            g.set_pcd(p.fixed.xyz, p.fixed.feat)
+            tf = g.match_keyframe(p.moving.xyz, p.moving.feat)
+            got[tail] = g.compute_innerproduct(g.transform)
+            if tail:      # not the align's own transform: the score kernel answers, and differently
+                other = np.array(g.transform, np.float32).copy(); other[0, 3] += 0.01
+                sc2 = g.compute_innerproduct(other)
+                assert sc2["inn_post"][0] != got[True]["inn_post"][0]
+                again = g.compute_innerproduct(g.transform)
+                assert again["inn_post"] == got[True]["inn_post"] and again["inliers"] == got[True]["inliers"]
+            g.close()
+        _check(got[True], got[False], 1e-6)
+        _check(got[True], want, 1e-5)
