@@ -556,6 +556,10 @@ def main():
         last_scores = drain_scored(); torch.cuda.synchronize()
         el2 = time.perf_counter() - t2
         answered = batches[0].last_tail_answers(n) if tail else []
+        if tail and os.environ.get("CVO_BENCH_PHASES"):
+            ts = batches[0].last_tail_seconds(); t_h = time.perf_counter(); batches[0].innerproduct_results_raw(n); t_h = time.perf_counter() - t_h
+            print(f"[bench] score block in the tail, us per pair (workgroup 0): post + Hessian walk {1e6 * ts[0] / n:.1f}, cull for inn_pre {1e6 * ts[1] / n:.1f}, its walk {1e6 * ts[2] / n:.1f}, "
+                  f"all {1e6 * ts[3] / n:.1f}; collecting a step's scores on the host {1e6 * t_h:.0f} us", file=sys.stderr, flush=True)
         for b in batches:
             b.set_tail_scores(False)
         with_scores = {"value": n * k2 / el2, "unit": "alignments/s", "steps": k2, "ms_per_step": 1e3 * el2 / k2,

@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_comm_info", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
     "cvo_batch_set_pairs", "cvo_batch_result_records", "cvo_shard_block", "cvo_batch_gather_results_padded", "cvo_batch_padded_records",
-    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds", "cvo_batch_last_pair_spans", "cvo_set_tail_scores", "cvo_batch_last_cull_masks", "cvo_batch_last_nonzeros",
+    "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds", "cvo_batch_last_pair_spans", "cvo_batch_last_tail_seconds", "cvo_set_tail_scores", "cvo_batch_last_cull_masks", "cvo_batch_last_nonzeros",
 ]
 
 _lib = None
@@ -217,6 +217,7 @@ def load_library():
     L.cvo_batch_last_tail_answers.argtypes = [vp, C.c_int, ip]
     L.cvo_batch_last_pair_seconds.argtypes = [vp, C.c_int, dp]
     L.cvo_set_tail_scores.argtypes = [vp, C.c_int]
+    L.cvo_batch_last_tail_seconds.argtypes = [vp, dp]
     L.cvo_batch_last_pair_spans.argtypes = [vp, C.c_int, dp, dp, C.POINTER(C.c_int)]
     L.cvo_batch_last_cull_masks.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.cvo_batch_last_nonzeros.argtypes = [vp, C.POINTER(C.c_longlong)]
@@ -695,6 +696,9 @@ class CvoBatch:
         t0 = np.zeros(n); t1 = np.zeros(n); j = (C.c_int * n)()
         _check(self.L.cvo_batch_last_pair_spans(self.h, n, t0.ctypes.data_as(C.POINTER(C.c_double)), t1.ctypes.data_as(C.POINTER(C.c_double)), j))
         return t0, t1, np.array(list(j))
+
+    def last_tail_seconds(self):
+        out = np.zeros(4); _check(self.L.cvo_batch_last_tail_seconds(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))); return out
 
     def last_cull_masks(self, n: int):
         m = (C.c_ulonglong * n)(); q = (C.c_ulonglong * n)(); _check(self.L.cvo_batch_last_cull_masks(self.h, n, m, q)); return [int(x) for x in m], [int(x) for x in q]

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <functional>
 
 #include <algorithm>
 #include <cmath>
@@ -139,6 +140,62 @@ struct Cloud {
     float cost_hint = 0.f;          // mean 1/z^2 of a sample of the points (0 = unknown): what a pair costs per iteration follows the density of its clouds
     float* rec() const { return static_cast<float*>(buf.p); }
     ~Cloud() { buf.release(); px.release(); boxes.release(); }
+};
+
+// Copy threads of the hand-over (Engine::upload_many: a batch's host arrays into the pinned ring, 12.6 MB per 64-pair step).  They live as long as the process:
+// starting three threads per hand-over cost 0.1 ms of the host's 0.5 per step, and a step's launch is resubmitted that much later (profiles/r04_upload_pool.txt).
+class CopyPool {
+public:
+    static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }   // never destroyed: its threads may outlive main()'s statics
+    // runs fn(0) .. fn(parts - 1), part 0 on the caller; returns when all are done.  One job at a time (callers queue on the lock).
+    template <class F> void run(int parts, F&& fn) {
+        if (parts <= 1 || workers_.empty()) { for (int i = 0; i < parts; ++i) fn(i); return; }
+        std::unique_lock<std::mutex> job(job_mutex_);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            task_ = [&fn](int i) { fn(i); }; next_ = 1; parts_ = parts; left_ = parts - 1; ++epoch_;
+        }
+        cv_.notify_all();
+        fn(0);
+        for (;;) {                                                    // the caller takes parts too while it waits
+            int mine = -1;
+            { std::lock_guard<std::mutex> lk(m_); if (next_ < parts_) mine = next_++; }
+            if (mine < 0) break;
+            fn(mine);
+            { std::lock_guard<std::mutex> lk(m_); --left_; }
+        }
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return left_ == 0; });
+        task_ = nullptr;
+    }
+private:
+    CopyPool() {
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int n = std::max(0, std::min(7, hw - 1));
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+        for (std::thread& t : workers_) t.detach();
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return epoch_ != seen && next_ < parts_; });
+            if (next_ >= parts_) { seen = epoch_; continue; }
+            const int mine = next_++;
+            if (next_ >= parts_) seen = epoch_;
+            auto task = task_;
+            lk.unlock();
+            task(mine);
+            lk.lock();
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    std::mutex m_, job_mutex_;
+    std::condition_variable cv_, done_;
+    std::function<void(int)> task_;
+    int next_ = 0, parts_ = 0, left_ = 0;
+    unsigned long long epoch_ = 0;
+    std::vector<std::thread> workers_;
 };
 
 DevParams to_dev(const cvo_params& p) {
@@ -300,6 +357,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_UPLOAD_COPY")) upload_copy = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_ORDER_PAIRS")) { order_mode = std::atoi(e); order_pairs = order_mode != 0; }
         if (const char* e = std::getenv("CVO_HIP_INKERNEL_PACK")) inkernel_pack = std::atoi(e) != 0;
+        if (const char* e = std::getenv("CVO_HIP_RING_MIRROR")) ring_mirror = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_UPLOAD_THREADS")) upload_threads = std::max(1, std::min(16, std::atoi(e)));
         upload_threads = std::max(1, std::min(upload_threads, (int)std::thread::hardware_concurrency()));
         return CVO_OK;
@@ -311,10 +369,11 @@ struct Engine {
         release_slots();
         d_scoredescs.release(); h_scoredescs.release(); h_counts.release();
         for (DevBuf* b : {&d_bgr, &d_depth, &d_I0, &d_I1, &d_I2, &d_dx0, &d_dy0, &d_abs0, &d_abs1, &d_abs2, &d_ths, &d_thsS, &d_map, &d_pattern, &d_counts, &d_tiles}) b->release();
-        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_queue, &d_trace, &d_tracelen, &d_partials, &d_raw, &d_records}) b->release();
+        for (DevBuf* b : {&d_descs, &d_states, &d_ybuf, &d_jT, &d_ent, &d_surv, &d_xch, &d_queue, &d_trace, &d_tracelen, &d_partials, &d_raw, &d_ring, &d_records}) b->release();
         for (PinBuf* b : {&h_descs, &h_states, &h_states_in, &h_stage, &h_partials, &h_tail, &h_packdesc, &h_rawtab}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (ev_ring) (void)hipEventDestroy(ev_ring);
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr; ev0 = ev1 = nullptr;
     }
@@ -325,12 +384,19 @@ struct Engine {
     // is only waited for when it wraps.  Large hand-overs (a batch of 64 pairs = 12.6 MB) are copied into the ring by a few threads.
     struct UploadItem { Cloud* c; const float* xyz; const float* feat; int n; };
     DevBuf d_raw;
-    int upload_threads = 4;
+    int upload_threads = 8;
     bool upload_copy = true;
     bool defer_pack = false;          // batches (cvo_batch_create)
     bool order_pairs = true;          // CVO_HIP_ORDER_PAIRS=0: positions take the pairs in index order
     int order_mode = 1;
     bool inkernel_pack = true;        // CVO_HIP_INKERNEL_PACK=0: deferred clouds always go through the pack kernel
+    // Experiment (CVO_HIP_RING_MIRROR=1): a batch's block of the ring is also copied to a device mirror by the copy engine, on the engine's stream, at the hand-over,
+    // and the align launch behind it builds the clouds' planes from the mirror instead of reading the pinned ring over PCIe from inside the kernel.  Measured
+    // interleaved on one lease: with_host_upload / value 0.928-0.965 on the 20-step command against 0.951-0.959 without, 0.959-0.965 against 0.954-0.957 on the
+    // 256-step run: within the run-to-run spread, not kept (profiles/r04_upload_mirror_ab.txt).
+    bool ring_mirror = false;
+    DevBuf d_ring;                    // device mirror of h_stage (same offsets)
+    hipEvent_t ev_ring = nullptr;     // recorded behind the last mirror copy
     std::vector<Cloud*> pending;      // clouds with a hand-over not packed yet (Cloud::raw)
     PinBuf h_packdesc, h_rawtab;
     hipStream_t packdesc_stream = nullptr, ring_reader = nullptr;
@@ -412,12 +478,10 @@ struct Engine {
         const int nthreads = bytes >= ((size_t)2 << 20) ? std::max(1, std::min(upload_threads, (int)pieces.size())) : 1;
         auto copy_range = [&pieces](size_t a, size_t b) { for (size_t i = a; i < b; ++i) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); };
         if (nthreads == 1) copy_range(0, pieces.size());
-        else {
-            std::vector<std::thread> th;
-            const size_t per = (pieces.size() + nthreads - 1) / nthreads;
-            for (int t = 1; t < nthreads; ++t) th.emplace_back(copy_range, std::min(pieces.size(), t * per), std::min(pieces.size(), (t + 1) * per));
-            copy_range(0, std::min(pieces.size(), per));
-            for (std::thread& t : th) t.join();
+        else {                                                        // in 4 x nthreads parts, taken by the pool's threads and the caller as they come free
+            const int parts = std::min((int)pieces.size(), 4 * nthreads);
+            const size_t per = (pieces.size() + parts - 1) / parts;
+            CopyPool::get().run(parts, [&](int t) { copy_range(std::min(pieces.size(), (size_t)t * per), std::min(pieces.size(), (size_t)(t + 1) * per)); });
         }
         // Batches: the clouds stay in the ring as they came; the next align launch packs each pair's clouds itself, reading the ring where
         // it lies (pinned host memory is mapped into the device's address space): no copy-engine transfer and no kernel of its own between
@@ -425,6 +489,12 @@ struct Engine {
         // share the DMA engines, small kernels wait for a compute unit no persistent workgroup occupies).  Anything else that wants the
         // clouds first (a score block, a cooperative launch) runs the pack kernel on them (flush_pending).
         if (defer_pack) {
+            if (ring_mirror && inkernel_pack) {
+                if (d_ring.bytes < h_stage.bytes) { HIP_TRY(hipStreamSynchronize(stream)); if (ring_reader && ring_reader != stream) HIP_TRY(hipStreamSynchronize(ring_reader)); rc = d_ring.ensure(h_stage.bytes); if (rc) return rc; }
+                HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(d_ring.p) + (blk - static_cast<unsigned char*>(h_stage.p)), blk, bytes, hipMemcpyHostToDevice, stream));
+                if (!ev_ring) HIP_TRY(hipEventCreateWithFlags(&ev_ring, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(ev_ring, stream));
+            }
             size_t o2 = 0;
             for (int k = 0; k < count; ++k) {
                 const int n = it[k].n; if (n <= 0) continue;
@@ -706,7 +776,12 @@ struct Engine {
                 if (launched && last_stream) HIP_TRY(hipStreamSynchronize(last_stream));   // an earlier launch of this engine may still read the table
                 if ((rc = h_rawtab.ensure(sizeof(const float*) * 2 * (size_t)n))) return rc;
                 rawtab = static_cast<const float**>(h_rawtab.p);
-                for (int i = 0; i < n; ++i) { rawtab[2 * i] = pairs[i].fixed ? pairs[i].fixed->raw : nullptr; rawtab[2 * i + 1] = pairs[i].moving ? pairs[i].moving->raw : nullptr; }
+                // (the clouds' raw pointers are host addresses in the ring; with the mirror the kernel gets the same offsets in the device copy)
+                const bool mir = ring_mirror && d_ring.p && d_ring.bytes >= h_stage.bytes && ev_ring;
+                const ptrdiff_t shift = mir ? (static_cast<const unsigned char*>(d_ring.p) - static_cast<const unsigned char*>(h_stage.p)) : 0;
+                auto dev = [&](const float* r) -> const float* { return r ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(r) + shift) : nullptr; };
+                for (int i = 0; i < n; ++i) { rawtab[2 * i] = dev(pairs[i].fixed ? pairs[i].fixed->raw : nullptr); rawtab[2 * i + 1] = dev(pairs[i].moving ? pairs[i].moving->raw : nullptr); }
+                if (mir && s != stream) HIP_TRY(hipStreamWaitEvent(s, ev_ring, 0));
             } else if ((rc = flush_pending(s))) return rc;
         }
         if (tails) {
@@ -1038,9 +1113,12 @@ void polar_rotation(const float* L, float* Rout) {
 
 void sym_eig6(const double* Hin, double* ev) {   // cyclic Jacobi
     double A[36]; std::memcpy(A, Hin, sizeof(A));
+    // (the eigenvalues are rounded to f32 by the caller, cvo.cpp:728: off-diagonal mass below 1e-30 of the diagonal's moves them by far less than half an ulp of
+    //  that; running on until it underflowed took eight to ten sweeps instead of four or five -- 0.5 ms of host time per 64-pair score block)
+    double diag2 = 0; for (int i = 0; i < 6; ++i) diag2 += A[i * 6 + i] * A[i * 6 + i];
     for (int sweep = 0; sweep < 64; ++sweep) {
         double off = 0; for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += A[i * 6 + j] * A[i * 6 + j];
-        if (off < 1e-300) break;
+        if (off < 1e-300 || off <= 1e-30 * (diag2 + off)) break;
         for (int p = 0; p < 6; ++p) for (int q = p + 1; q < 6; ++q) {
             if (A[p * 6 + q] == 0.0) continue;
             const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2.0 * A[p * 6 + q]);
@@ -1739,6 +1817,12 @@ int cvo_batch_last_pair_spans(cvo_batch b, int n, double* start_s, double* end_s
         start_s[i] = 1e-8 * (double)r[i].clk_t0; end_s[i] = 1e-8 * (double)(r[i].clk_t0 + r[i].clk_ticks);
         if (joined_at) joined_at[i] = r[i].joined_at;
     }
+    return CVO_OK;
+}
+int cvo_batch_last_tail_seconds(cvo_batch b, double seconds[4]) {
+    if (!b || !seconds) return fail(CVO_ERR_INVALID, "null argument");
+    const PairState* r = b->eng.results();
+    for (int q = 0; q < 4; ++q) { seconds[q] = 0; for (int i = 0; i < b->last_n; ++i) seconds[q] += 1e-8 * (double)r[i].tail_ticks[q]; }
     return CVO_OK;
 }
 int cvo_batch_last_cull_masks(cvo_batch b, int n, unsigned long long* masks, unsigned long long* predicted) {

@@ -56,6 +56,7 @@ struct PairState {
     long long nonzeros_total; // nonzeros of A summed over the executed iterations (the reference's work: cvo.cpp:166-175 members, :282-306 terms)
     // wall time (100 MHz ticks) workgroup 0 of the pair spent per phase (slots as cvo_batch_last_phase_seconds documents them)
     unsigned long long clk_cycles, clk_ticks;   // shader-clock cycles and 100 MHz ticks workgroup 0 spent on the pair: cycles/ticks*100 MHz = clock
+    unsigned long long tail_ticks[4];           // the score block in the kernel's tail (phase_tail_scores), 100 MHz ticks of workgroup 0: transform + list walk (inn_post, Hessian), the cull for inn_pre, its walk, all of it
     unsigned long long predict_mask;            // ... and the cull built its lists around extrapolated positions (DevParams::predict)
     unsigned long long cull_mask;               // bit min(k, 63) set: iteration k began with a dense cull (diagnostics: when do the lists go stale)
     unsigned long long clk_t0;                  // the device's 100 MHz counter when workgroup 0 took the pair up (one counter for the whole device: launches can be laid on one time axis)

@@ -131,6 +131,7 @@ struct __attribute__((aligned(16))) Shared {
     unsigned long long sub[4];   // thread 0's time inside the candidate phase: prologue, row loop, workgroup reduction, exchange
     unsigned long long ticks[10];   // thread 0's time per phase (PairState::phase_ticks), summed over the pair's iterations
     unsigned long long cull_mask;   // PairState::cull_mask
+    unsigned long long tail_ticks[4];
     unsigned long long predict_mask;
     unsigned long long cand_total;  // list candidates evaluated so far (PairState::candidates_total)
     unsigned long long nnz_total;   // nonzeros of A so far (PairState::nonzeros_total)
@@ -2039,6 +2040,8 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
     }
     // (the same decision on every workgroup of the pair: they exchange partial sums below.  A member in dense mode -- its rows' candidates did
     //  not fit its lists -- has no lists to walk and says so through the last reduction's spare slot)
+    const unsigned long long tt0 = CVO_NOW();
+    unsigned long long tt1 = tt0, tt2 = tt0, tt3 = tt0;
     const bool can = (y_lds == 1) && sh->list_valid && (G > 1 || sh->status == 0);
     const bool dense = sh->dense_mode != 0;
     const bool own = g == 0;                                                            // the pair's first workgroup writes the answers
@@ -2114,6 +2117,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
             const double no_lists = __shfl(r0, 7, 64);                                  // (wave 0 holds the totals; thread 0 decides)
             if (tid == 0 && no_lists == 0.0) answered |= TAIL_POST | TAIL_HESSIAN;
         }
+        tt1 = CVO_NOW();
         // ---- fip(moving, fixed): the untransformed cloud against the fixed one, one cull at this radius
         float Rs[9], Ts[3];
         if (tid == 0) {
@@ -2128,6 +2132,7 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
         transform_body_t<1>(c, L, sh, none, false);                                     // y = p
         const int rebuilds_before = sh->rebuilds;
         phase_cull(Dp, g, G, tgeo, y_lds);                                              // the rows' neighbours within (1 + skin) r_c of the untransformed cloud, by row
+        tt2 = CVO_NOW();
         {
             double sumA = 0; int count = 0, hcount = 0; float H[21];
 #pragma unroll
@@ -2188,6 +2193,8 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
         }
         out[23] = (double)answered;
     }
+    tt3 = CVO_NOW();
+    if (tid == 0) { sh->tail_ticks[0] = tt1 - tt0; sh->tail_ticks[1] = tt2 - tt1; sh->tail_ticks[2] = tt3 - tt2; sh->tail_ticks[3] = tt3 - tt0; }
     __syncthreads();
 }
 
@@ -2364,7 +2371,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             sh->iter_at_break = k_join ? (int)__hip_atomic_load((const CVO_GLOBAL unsigned*)&st->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->iter;
             for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
             for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
-            sh->cand_total = 0; sh->nnz_total = 0; sh->cull_mask = 0ull; sh->predict_mask = 0ull;
+            sh->cand_total = 0; sh->nnz_total = 0; sh->cull_mask = 0ull; sh->predict_mask = 0ull; for (int i = 0; i < 4; ++i) sh->tail_ticks[i] = 0ull;
             sh->P.skin = P.skin; sh->P.skin_alpha = P.skin_alpha; sh->alpha_build = 0.f; sh->reach = 0.f; sh->xmax = 0.f; sh->twist_ok = 0; sh->predicted = 0; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
         }
         __syncthreads();
@@ -2519,7 +2526,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             fin.candidates_total = (long long)sh->cand_total; fin.nonzeros_total = (long long)sh->nnz_total;
             for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
             fin.phase_ticks[7] = sh->sub[0]; fin.phase_ticks[9] = sh->sub[1]; fin.phase_ticks[2] = sh->sub[2]; fin.phase_ticks[4] = sh->sub[3];
-            fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0; fin.clk_t0 = clk_t0; fin.cull_mask = sh->cull_mask; fin.predict_mask = sh->predict_mask;
+            fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0; fin.clk_t0 = clk_t0; fin.cull_mask = sh->cull_mask; fin.predict_mask = sh->predict_mask; for (int i = 0; i < 4; ++i) fin.tail_ticks[i] = sh->tail_ticks[i];
             *Dp->state = fin;                                          // device copy: the next launch may start from it
             *Dp->state_host = fin;                                     // pinned host mirror: visible to the host when the kernel has completed
             if (Dp->record) {                                          // the pair's 64-byte record of the cross-GPU gather (ints as floats: exact below 2^24)

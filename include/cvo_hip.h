@@ -288,6 +288,9 @@ int cvo_batch_last_pair_seconds(cvo_batch b, int n, double* seconds);
 /* the same as spans on the device's own 100 MHz clock (one counter per device: the pairs of launches that ran side by side lie on one time axis), and the iteration
  * at which a finished workgroup joined the pair (0 = none; joined_at may be NULL): the drain of a job, pair by pair (scripts/gpu_timeline.py) */
 int cvo_batch_last_pair_spans(cvo_batch b, int n, double* start_s, double* end_s, int* joined_at);
+/* where the score block in the tail of the last launch spent its time (cvo_batch_set_tail_scores): seconds summed over pairs, workgroup 0 of each:
+ * [0] final transform + list walk (inn_post, Hessian)   [1] the cull for inn_pre   [2] its walk + the rest   [3] all of it */
+int cvo_batch_last_tail_seconds(cvo_batch b, double seconds[4]);
 /* diagnostics: bit min(k, 63) of masks[i] is set when iteration k of pair i began with a dense cull (the candidate lists had gone stale, or were not there yet);
  * predicted[i] (may be NULL): the culls that built their lists around extrapolated positions */
 int cvo_batch_last_cull_masks(cvo_batch b, int n, unsigned long long* masks, unsigned long long* predicted);
