@@ -92,6 +92,7 @@ struct __attribute__((aligned(16))) Shared {
     float reach;           // phase_transform -> phase_refine: how far the points are from where they were listed, beyond what the lists allow for by themselves
     float xmax;            // largest |x_i| of this workgroup's rows (phase_cull)
     int predicted;         // culls of this pair whose lists were built around extrapolated positions (diagnostics)
+    float skin0, alpha0;   // the launch's list margins (a pair that falls back to the dense-scene margin changes P.skin / P.skin_alpha for itself)
     int twist_ok;          // omega, v, step below are those of the pair's previous iteration (set by this workgroup's own candidate phase and epilogue)
     float ell_build;
     float fred[MAX_WAVES];
@@ -2207,6 +2208,238 @@ static __device__ __noinline__ void phase_tail_scores(const PairDesc* Dp_in, int
 // From the join on the pair runs as G = 2: rows dealt anew (pair_rows), lists rebuilt, partial sums exchanged -- the path G > 1
 // launches always take.  A pair's results do not depend on G beyond the order of the double-precision partial sums (section 4.1).
 
+// One pair from its start state to the state written back: everything a workgroup does between taking a pair up (its own slot's, a pull from the pair queue,
+// a pair it has offered to help with) and going back for the next.  A function of its own so that the kernel's pull / adoption loop and the iteration loop do not
+// share one register allocation: together they kept more than a hundred uniform values alive across every phase call, spilled to lanes of vector registers that
+// were themselves spilled to scratch around the calls (the three-waves-per-SIMD build: 158 scratch accesses per iteration in the loop; -Rpass-analysis in DESIGN.md).
+static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in, int slot_in, int slots_in, int ge_in, int Ge_in, unsigned k_join_in, unsigned launch_tag_in,
+                                            int tgeo_in, int y_lds_in, unsigned long long* queue_in, const float* const* raw_table_in, int adopt_launch_in) {
+    const PairDesc* descs = uni_ptr(descs_in); const float* const* raw_table = uni_ptr(raw_table_in); gu64* queue = (gu64*)uni_ptr(queue_in);
+    const int slot = uni(slot_in), slots = uni(slots_in), tgeo = uni(tgeo_in), y_lds = uni(y_lds_in);
+    int ge = uni(ge_in), Ge = uni(Ge_in);
+    const unsigned k_join = (unsigned)uni((int)k_join_in), launch_tag = (unsigned)uni((int)launch_tag_in);
+    const bool adopt_launch = uni(adopt_launch_in) != 0;
+    Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
+    const int tid = threadIdx.x;
+    const int max_iter = sh->P.max_iter;
+    int p = uni(ps_in);
+    // `p` so far is a position of the launch (a slot, or a pull from the queue): the pair it stands for is the host's choice (densest clouds first)
+    const int ps = p;
+    p = descs[ps].run_pair;
+    const PairDesc* Dp = descs + p;
+    const int nf = Dp->nf, nm = Dp->nm;
+    if (raw_table && !k_join) {
+        // The pair's clouds as the caller handed them over (cvo_batch_set_pair(s): n x 3 positions AoS, data_type.h:30, then 5 channel-major
+        // feature arrays, data_type.h:75), still in the host's pinned staging ring: this workgroup builds the two float4 planes itself --
+        // the points cross PCIe here, once.  (A helper that joins later sees the planes behind the owner's release, like the pair's state.)
+        const float* const raws[2] = {raw_table[2 * p], raw_table[2 * p + 1]};
+        float* const dsts[2] = {const_cast<float*>(Dp->fixed), const_cast<float*>(Dp->moving)};
+        const int ns[2] = {nf, nm};
+        for (int q = 0; q < 2; ++q) {
+            const float* xyz = raws[q]; if (!xyz) continue;
+            const int n = ns[q]; const float* feat = xyz + 3 * (size_t)n;
+            for (int i = tid; i < n; i += blockDim.x) {
+                float4 lo, hi;
+                lo.x = xyz[3 * (size_t)i]; lo.y = xyz[3 * (size_t)i + 1]; lo.z = xyz[3 * (size_t)i + 2]; lo.w = feat[i];
+                hi.x = feat[(size_t)n + i]; hi.y = feat[2 * (size_t)n + i]; hi.z = feat[3 * (size_t)n + i]; hi.w = feat[4 * (size_t)n + i];
+                *reinterpret_cast<float4*>(dsts[q] + lo_off(i)) = lo;
+                *reinterpret_cast<float4*>(dsts[q] + hi_off(n, i)) = hi;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const int rows_per = ((((nf + ROW_DEAL - 1) / ROW_DEAL) + Ge - 1) / Ge) * ROW_DEAL;
+    const PairState* st_from = k_join ? (const PairState*)Dp->state : Dp->state_in;   // a helper starts from what the pair's owner published
+    if (tid < 25) {                                               // R[9], T[3], ell, transform[12]: the head of PairState, one lane per word
+        const float v = __uint_as_float(__hip_atomic_load((const CVO_GLOBAL unsigned*)st_from + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (tid < 9) sh->R[tid] = v; else if (tid < 12) sh->T[tid - 9] = v; else if (tid == 12) sh->ell = v; else sh->M[tid - 13] = v;
+    }
+    if (tid == 32) {
+        const PairState* st = st_from;
+        int rp, nr; pair_rows(nf, ge, Ge, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
+        sh->ws_slot = k_join ? ps : slot;                         // (one slot per pair when workgroups help each other)
+        store_ctx(Dp, ge, Ge);
+        sh->adopt_req = 0; sh->adopt_word = nullptr; sh->joined_at = 0; sh->retracted = 0;
+        if (adopt_launch && !k_join) {                            // this pair may be helped: its word says so from now on
+            __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_FREE) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh->adopt_word = (unsigned long long*)&queue[1 + slot];
+        }
+        sh->stop = 0; sh->status = 0; sh->nnz = 0; sh->cand = 0;
+        sh->iter_at_break = k_join ? (int)__hip_atomic_load((const CVO_GLOBAL unsigned*)&st->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->iter;
+        for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
+        for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
+        sh->cand_total = 0; sh->nnz_total = 0; sh->cull_mask = 0ull; sh->predict_mask = 0ull; for (int i = 0; i < 4; ++i) sh->tail_ticks[i] = 0ull;
+        sh->P.skin = sh->skin0; sh->P.skin_alpha = sh->alpha0; sh->alpha_build = 0.f; sh->reach = 0.f; sh->xmax = 0.f; sh->twist_ok = 0; sh->predicted = 0; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
+    }
+    __syncthreads();
+    // a helper has read what the owner published for it: if the pair may grow further, its word takes offers again (not earlier --
+    // the owner publishes the next newcomer's state in the same place)
+    if (k_join && Ge < ADOPT_GMAX && tid == 0)
+        __hip_atomic_store(&queue[1 + ps], ((unsigned long long)(launch_tag | ADOPT_FREE) << 32) | k_join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    int k = (int)k_join;
+    // phase timers and counters live in LDS, bumped by thread 0 with fire-and-forget ds_add: as registers of this function they were
+    // saved and restored around every phase call (the phases are out of line), ~1 us of lane moves per iteration
+    unsigned long long t_prev = CVO_NOW();
+#ifdef CVO_KTRACE
+    unsigned long long kt_prev[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ksub_prev[4] = {0, 0, 0, 0};
+#endif
+    const unsigned long long clk_t0 = t_prev, clk_c0 = __builtin_amdgcn_s_memtime();
+#define CVO_PHASE(idx) do { const unsigned long long t_now = CVO_NOW(); if (tid == 0) atomicAdd(&sh->ticks[idx], t_now - t_prev); t_prev = t_now; } while (0)
+    const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
+    if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
+
+    if (ok_pair && k < max_iter) phase_transform(Dp, ge, Ge, tgeo, y_lds);   // later iterations: done by the epilogue before them
+    for (; ok_pair && k < max_iter; ++k) {
+        if (sh->rebuild == 1) {
+            const unsigned long long t_a = CVO_NOW();
+            phase_cull(Dp, ge, Ge, tgeo, y_lds);
+            const unsigned long long t_b = CVO_NOW();
+            phase_sort(Dp, ge, Ge, tgeo, y_lds);
+            if (sh->dense_mode && sh->P.skin > SKIN_DENSE_SCENE) {   // the lists of this margin do not fit (a surface a few decimetres from the camera): once more with the
+                __syncthreads();                                     // narrow margin, kept for the rest of the pair, before the rows fall back to dense sweeps
+                if (tid == 0) { sh->P.skin = SKIN_DENSE_SCENE; sh->P.skin_alpha = 0.f; sh->dense_fallbacks -= 1; }
+                __syncthreads();
+                phase_cull(Dp, ge, Ge, tgeo, y_lds);
+                phase_sort(Dp, ge, Ge, tgeo, y_lds);
+            }
+            if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], CVO_NOW() - t_b); sh->cull_mask |= 1ull << min(k, 63); if (sh->predicted) { sh->predict_mask |= 1ull << min(k, 63); sh->predicted = 0; } }
+        } else if (sh->rebuild == 2) {
+            phase_refine(Dp, ge, Ge, tgeo, y_lds, k);
+            if (tid == 0 && sh->predicted) { sh->predict_mask |= 1ull << min(k, 63); sh->predicted = 0; }
+        }
+        CVO_PHASE(0);
+        phase_candidates(Dp, ge, Ge, tgeo, y_lds, k);
+        if (tid == 0) { atomicAdd(&sh->cand_total, (unsigned long long)sh->cand); atomicAdd(&sh->nnz_total, (unsigned long long)sh->nnz); }
+        CVO_PHASE(1);
+        if (sh->status != 0) break;
+        phase_linesearch(Dp, ge, Ge, tgeo, y_lds, k);
+        CVO_PHASE(3);
+        if (sh->status != 0) break;
+        phase_epilogue(Dp, ge, Ge, tgeo, y_lds, k, max_iter);
+        CVO_PHASE(5);
+#ifdef CVO_KTRACE   // experiment builds only: the trace row's B..E carry this iteration's phase times (100 MHz ticks) instead
+        if (tid == 0 && ge == 0 && Dp->trace && k < Dp->trace_cap) {
+            TraceRow& tr = Dp->trace[k];
+            unsigned long long ticks[10];
+            for (int q = 0; q < 10; ++q) ticks[q] = sh->ticks[q];
+            tr.B = (double)(ticks[0] - kt_prev[0]); tr.C = (double)(ticks[1] - kt_prev[1]); tr.D = (double)(ticks[3] - kt_prev[3]); tr.E = (double)(ticks[5] - kt_prev[5]);
+            // omega = candidate phase (prologue, row walk, wait + reduction), v = line-search walk, its reduction, epilogue scalar part; step = fused transform
+            tr.omega[0] = (float)(sh->sub[0] - ksub_prev[0]); tr.omega[1] = (float)(sh->sub[1] - ksub_prev[1]); tr.omega[2] = (float)(sh->sub[2] - ksub_prev[2]);
+            tr.v[0] = (float)sh->ksub[0]; tr.v[1] = (float)sh->ksub[1]; tr.v[2] = (float)sh->ksub[2]; tr.step = (float)sh->ksub[3];
+            for (int q = 0; q < 4; ++q) ksub_prev[q] = sh->sub[q];
+            for (int q = 0; q < 10; ++q) kt_prev[q] = ticks[q];
+        }
+#endif
+        if (sh->stop) { ++k; break; }
+        if (adopt_launch && (Ge > 1 || sh->adopt_req) && k + 1 < max_iter) {
+            // Members of a pair that has (or is about to get) helpers agree on the member count of the next iteration: the owner
+            // decides -- it accepts an offer it saw in its epilogue, if the pair may still grow -- and writes {iteration, members}
+            // into the pair's control word; the helpers wait for that word.  On a change every member deals its rows anew
+            // (pair_rows) and the lists are rebuilt; the newcomer starts from the state the owner published (the head of
+            // PairState: R, T, ell, the current transform; iter) as member `old count`.
+            if (tid == 0) {
+                int g_next = Ge;
+                gu64* ctrl = &queue[1 + slots + (ge == 0 ? slot : (int)sh->ws_slot)];
+                if (ge == 0) {
+                    if (sh->adopt_req && Ge < ADOPT_GMAX) {
+                        CVO_GLOBAL unsigned* pub = (CVO_GLOBAL unsigned*)Dp->state;
+                        for (int i = 0; i < 9; ++i) pub[i] = __float_as_uint(sh->R[i]);
+                        for (int i = 0; i < 3; ++i) pub[9 + i] = __float_as_uint(sh->T[i]);
+                        pub[12] = __float_as_uint(sh->ell);
+                        for (int i = 0; i < 12; ++i) pub[13 + i] = __float_as_uint(sh->M[i]);
+                        ((CVO_GLOBAL PairState*)Dp->state)->iter = sh->iter_at_break;
+                        unsigned long long e = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)(sh->adopt_req - 1);
+                        const unsigned long long acc = ((unsigned long long)(launch_tag | ADOPT_ACCEPT) << 32) | ((unsigned)(Ge + 1) << 24) | ((unsigned)Ge << 16) | (unsigned)((k + 1) & 0xFFFF);
+                        if (__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e, acc, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            // The helper polls this word and confirms within a microsecond or two (ACCEPT -> CONFIRMED, its CAS).  Only then does the pair count on
+                            // it: should no confirmation come (the helper is gone), the owner takes the acceptance back (ACCEPT -> FREE, its CAS -- one of the two
+                            // wins) and the pair carries on with the members it has, instead of waiting for a member that never sends its partial sums.
+                            bool joined = false;
+                            const unsigned long long t_acc = __builtin_amdgcn_s_memrealtime();
+                            for (;;) {
+                                const unsigned long long x = __hip_atomic_load((gu64*)sh->adopt_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((unsigned)(x >> 32) != (launch_tag | ADOPT_ACCEPT)) { joined = true; break; }
+                                if (__builtin_amdgcn_s_memrealtime() - t_acc > ADOPT_CONFIRM_TICKS) {
+                                    unsigned long long e2 = acc;
+                                    joined = !__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e2, ((unsigned long long)(launch_tag | ADOPT_FREE) << 32) | (unsigned)(k + 1),
+                                                                                    __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            if (joined) {
+                                g_next = Ge + 1;
+                                if (!sh->joined_at) sh->joined_at = k + 1;
+                                if (g_next >= ADOPT_GMAX) sh->adopt_word = nullptr;     // full: no more offers are looked at (the newcomer leaves the word as it is)
+                            } else sh->retracted += 1;
+                        }
+                    }
+                    if (g_next > 1) __hip_atomic_store(ctrl, ((unsigned long long)(launch_tag | (unsigned)((k + 1) & 0xFFFF)) << 32) | (unsigned)g_next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        const unsigned long long x = __hip_atomic_load(ctrl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(x >> 32) == (launch_tag | (unsigned)((k + 1) & 0xFFFF))) { g_next = (int)(unsigned)x; break; }
+                        if (__builtin_amdgcn_s_memrealtime() - t_start > 300000000ull) { sh->status = 6; break; }   // 3 s: the owner is gone
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                sh->adopt_req = g_next;
+                if (g_next != Ge) {
+                    int rp, nr; pair_rows(nf, ge, g_next, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
+                    store_ctx(Dp, ge, g_next);
+                    sh->list_valid = 0; sh->rebuild = 1; sh->dense_mode = 0;
+                }
+            }
+            __syncthreads();
+            Ge = sh->adopt_req;
+            __syncthreads();
+            if (sh->status != 0) break;
+        }
+    }
+
+    // ---- after the loop: the tracker's score block for this pair, when asked for (one workgroup per pair; a helped pair is left to the host)
+    __syncthreads();
+    if (Dp->score_out && ok_pair) phase_tail_scores(Dp, ge, Ge, tgeo, y_lds, k);   // every workgroup of the pair: each holds the lists of its own rows
+    // ---- (cvo.cpp:815-817): write the pair's state back
+    __syncthreads();
+    if (tid == 0 && ge == 0) {
+        if (adopt_launch) __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_CLOSED) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody joins any more
+        PairState fin;
+        float R[9], T[3], M[12];
+        for (int i = 0; i < 9; ++i) { R[i] = sh->R[i]; fin.R[i] = R[i]; }
+        for (int i = 0; i < 3; ++i) { T[i] = sh->T[i]; fin.T[i] = T[i]; }
+        make_transform(R, T, M);                                                            // final update_tf, cvo.cpp:817
+        for (int i = 0; i < 12; ++i) { fin.prev_transform[i] = sh->M[i]; fin.transform[i] = M[i]; }
+        fin.ell = sh->ell;
+        fin.iter = sh->iter_at_break;                                                       // unchanged (stale) if no break: Q4
+        fin.A_nonzero = sh->nnz;
+        fin.iterations_run = k;
+        fin.status = sh->status;
+        fin.rebuilds = sh->rebuilds;
+        fin.joined_at = sh->joined_at; fin.adopt_retracted = sh->retracted;
+        fin.dense_fallbacks = sh->dense_fallbacks;
+        fin.candidates_total = (long long)sh->cand_total; fin.nonzeros_total = (long long)sh->nnz_total;
+        for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
+        fin.phase_ticks[7] = sh->sub[0]; fin.phase_ticks[9] = sh->sub[1]; fin.phase_ticks[2] = sh->sub[2]; fin.phase_ticks[4] = sh->sub[3];
+        fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0; fin.clk_t0 = clk_t0; fin.cull_mask = sh->cull_mask; fin.predict_mask = sh->predict_mask; for (int i = 0; i < 4; ++i) fin.tail_ticks[i] = sh->tail_ticks[i];
+        *Dp->state = fin;                                          // device copy: the next launch may start from it
+        *Dp->state_host = fin;                                     // pinned host mirror: visible to the host when the kernel has completed
+        if (Dp->record) {                                          // the pair's 64-byte record of the cross-GPU gather (ints as floats: exact below 2^24)
+            gv4f* rec = (gv4f*)Dp->record;
+            v4f r0, r1, r2, r3;
+            r0.x = M[0]; r0.y = M[1]; r0.z = M[2]; r0.w = M[3]; r1.x = M[4]; r1.y = M[5]; r1.z = M[6]; r1.w = M[7]; r2.x = M[8]; r2.y = M[9]; r2.z = M[10]; r2.w = M[11];
+            r3.x = (float)fin.iter; r3.y = (float)fin.A_nonzero; r3.z = (float)fin.iterations_run; r3.w = (float)fin.status;
+            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3;
+        }
+    }
+    __syncthreads();
+}
+
+
 __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
                                                                          unsigned launch_tag, int tab_cols, unsigned long long* __restrict__ queue_in, DevParams P,
                                                                          const unsigned* wgs_submitted /* host-mapped */, unsigned* wgs_started,
@@ -2222,7 +2455,8 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
     // "is anything queued on the device?" (adoption): every workgroup the library submits counts itself as started, whatever kind of launch it belongs to
     if (wgs_started != nullptr && tid == 0) atomicAdd(wgs_started, 1u);
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
-    if (tid == 0) { sh->P = P; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
+    if (tid == 0) { sh->P = P; sh->skin0 = P.skin; sh->alpha0 = P.skin_alpha; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
+    __syncthreads();                                                // (run_pair reads the parameters from there)
     const bool adopting = wgs_started != nullptr && P.adopt_on != 0;   // set by the host for launches of one workgroup and one slot per pair
     const int tgeo = pack_geometry(tile, rows_cap, y_cap);
     gu64* queue = (gu64*)queue_in;
@@ -2324,220 +2558,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             __syncthreads();
             if (p >= n_pairs) break;
         }
-        // `p` so far is a position of the launch (a slot, or a pull from the queue): the pair it stands for is the host's choice (densest clouds first)
-        const int ps = p;
-        p = descs[ps].run_pair;
-        const PairDesc* Dp = descs + p;
-        const int nf = Dp->nf, nm = Dp->nm;
-        if (raw_table && !k_join) {
-            // The pair's clouds as the caller handed them over (cvo_batch_set_pair(s): n x 3 positions AoS, data_type.h:30, then 5 channel-major
-            // feature arrays, data_type.h:75), still in the host's pinned staging ring: this workgroup builds the two float4 planes itself --
-            // the points cross PCIe here, once.  (A helper that joins later sees the planes behind the owner's release, like the pair's state.)
-            const float* const raws[2] = {raw_table[2 * p], raw_table[2 * p + 1]};
-            float* const dsts[2] = {const_cast<float*>(Dp->fixed), const_cast<float*>(Dp->moving)};
-            const int ns[2] = {nf, nm};
-            for (int q = 0; q < 2; ++q) {
-                const float* xyz = raws[q]; if (!xyz) continue;
-                const int n = ns[q]; const float* feat = xyz + 3 * (size_t)n;
-                for (int i = tid; i < n; i += blockDim.x) {
-                    float4 lo, hi;
-                    lo.x = xyz[3 * (size_t)i]; lo.y = xyz[3 * (size_t)i + 1]; lo.z = xyz[3 * (size_t)i + 2]; lo.w = feat[i];
-                    hi.x = feat[(size_t)n + i]; hi.y = feat[2 * (size_t)n + i]; hi.z = feat[3 * (size_t)n + i]; hi.w = feat[4 * (size_t)n + i];
-                    *reinterpret_cast<float4*>(dsts[q] + lo_off(i)) = lo;
-                    *reinterpret_cast<float4*>(dsts[q] + hi_off(n, i)) = hi;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        const int rows_per = ((((nf + ROW_DEAL - 1) / ROW_DEAL) + Ge - 1) / Ge) * ROW_DEAL;
-        const PairState* st_from = k_join ? (const PairState*)Dp->state : Dp->state_in;   // a helper starts from what the pair's owner published
-        if (tid < 25) {                                               // R[9], T[3], ell, transform[12]: the head of PairState, one lane per word
-            const float v = __uint_as_float(__hip_atomic_load((const CVO_GLOBAL unsigned*)st_from + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (tid < 9) sh->R[tid] = v; else if (tid < 12) sh->T[tid - 9] = v; else if (tid == 12) sh->ell = v; else sh->M[tid - 13] = v;
-        }
-        if (tid == 32) {
-            const PairState* st = st_from;
-            int rp, nr; pair_rows(nf, ge, Ge, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
-            sh->ws_slot = k_join ? ps : slot;                         // (one slot per pair when workgroups help each other)
-            store_ctx(Dp, ge, Ge);
-            sh->adopt_req = 0; sh->adopt_word = nullptr; sh->joined_at = 0; sh->retracted = 0;
-            if (adopt_launch && !k_join) {                            // this pair may be helped: its word says so from now on
-                __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_FREE) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh->adopt_word = (unsigned long long*)&queue[1 + slot];
-            }
-            sh->stop = 0; sh->status = 0; sh->nnz = 0; sh->cand = 0;
-            sh->iter_at_break = k_join ? (int)__hip_atomic_load((const CVO_GLOBAL unsigned*)&st->iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->iter;
-            for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
-            for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
-            sh->cand_total = 0; sh->nnz_total = 0; sh->cull_mask = 0ull; sh->predict_mask = 0ull; for (int i = 0; i < 4; ++i) sh->tail_ticks[i] = 0ull;
-            sh->P.skin = P.skin; sh->P.skin_alpha = P.skin_alpha; sh->alpha_build = 0.f; sh->reach = 0.f; sh->xmax = 0.f; sh->twist_ok = 0; sh->predicted = 0; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
-        }
-        __syncthreads();
-        // a helper has read what the owner published for it: if the pair may grow further, its word takes offers again (not earlier --
-        // the owner publishes the next newcomer's state in the same place)
-        if (k_join && Ge < ADOPT_GMAX && tid == 0)
-            __hip_atomic_store(&queue[1 + ps], ((unsigned long long)(launch_tag | ADOPT_FREE) << 32) | k_join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-        int k = (int)k_join;
-        // phase timers and counters live in LDS, bumped by thread 0 with fire-and-forget ds_add: as registers of this function they were
-        // saved and restored around every phase call (the phases are out of line), ~1 us of lane moves per iteration
-        unsigned long long t_prev = CVO_NOW();
-#ifdef CVO_KTRACE
-        unsigned long long kt_prev[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ksub_prev[4] = {0, 0, 0, 0};
-#endif
-        const unsigned long long clk_t0 = t_prev, clk_c0 = __builtin_amdgcn_s_memtime();
-#define CVO_PHASE(idx) do { const unsigned long long t_now = CVO_NOW(); if (tid == 0) atomicAdd(&sh->ticks[idx], t_now - t_prev); t_prev = t_now; } while (0)
-        const bool ok_pair = (nf > 0 && nm > 0 && rows_per <= MAX_ROWS_PER_WG);
-        if (!ok_pair && tid == 0) sh->status = (nf > 0 && nm > 0) ? 4 : 2;   // CVO_ERR_INVALID / CVO_ERR_EMPTY_CLOUD (reference: assert / UB, Q8)
-
-        if (ok_pair && k < P.max_iter) phase_transform(Dp, ge, Ge, tgeo, y_lds);   // later iterations: done by the epilogue before them
-        for (; ok_pair && k < P.max_iter; ++k) {
-            if (sh->rebuild == 1) {
-                const unsigned long long t_a = CVO_NOW();
-                phase_cull(Dp, ge, Ge, tgeo, y_lds);
-                const unsigned long long t_b = CVO_NOW();
-                phase_sort(Dp, ge, Ge, tgeo, y_lds);
-                if (sh->dense_mode && sh->P.skin > SKIN_DENSE_SCENE) {   // the lists of this margin do not fit (a surface a few decimetres from the camera): once more with the
-                    __syncthreads();                                     // narrow margin, kept for the rest of the pair, before the rows fall back to dense sweeps
-                    if (tid == 0) { sh->P.skin = SKIN_DENSE_SCENE; sh->P.skin_alpha = 0.f; sh->dense_fallbacks -= 1; }
-                    __syncthreads();
-                    phase_cull(Dp, ge, Ge, tgeo, y_lds);
-                    phase_sort(Dp, ge, Ge, tgeo, y_lds);
-                }
-                if (tid == 0) { atomicAdd(&sh->ticks[6], t_b - t_a); atomicAdd(&sh->ticks[8], CVO_NOW() - t_b); sh->cull_mask |= 1ull << min(k, 63); if (sh->predicted) { sh->predict_mask |= 1ull << min(k, 63); sh->predicted = 0; } }
-            } else if (sh->rebuild == 2) {
-                phase_refine(Dp, ge, Ge, tgeo, y_lds, k);
-                if (tid == 0 && sh->predicted) { sh->predict_mask |= 1ull << min(k, 63); sh->predicted = 0; }
-            }
-            CVO_PHASE(0);
-            phase_candidates(Dp, ge, Ge, tgeo, y_lds, k);
-            if (tid == 0) { atomicAdd(&sh->cand_total, (unsigned long long)sh->cand); atomicAdd(&sh->nnz_total, (unsigned long long)sh->nnz); }
-            CVO_PHASE(1);
-            if (sh->status != 0) break;
-            phase_linesearch(Dp, ge, Ge, tgeo, y_lds, k);
-            CVO_PHASE(3);
-            if (sh->status != 0) break;
-            phase_epilogue(Dp, ge, Ge, tgeo, y_lds, k, P.max_iter);
-            CVO_PHASE(5);
-#ifdef CVO_KTRACE   // experiment builds only: the trace row's B..E carry this iteration's phase times (100 MHz ticks) instead
-            if (tid == 0 && ge == 0 && Dp->trace && k < Dp->trace_cap) {
-                TraceRow& tr = Dp->trace[k];
-                unsigned long long ticks[10];
-                for (int q = 0; q < 10; ++q) ticks[q] = sh->ticks[q];
-                tr.B = (double)(ticks[0] - kt_prev[0]); tr.C = (double)(ticks[1] - kt_prev[1]); tr.D = (double)(ticks[3] - kt_prev[3]); tr.E = (double)(ticks[5] - kt_prev[5]);
-                // omega = candidate phase (prologue, row walk, wait + reduction), v = line-search walk, its reduction, epilogue scalar part; step = fused transform
-                tr.omega[0] = (float)(sh->sub[0] - ksub_prev[0]); tr.omega[1] = (float)(sh->sub[1] - ksub_prev[1]); tr.omega[2] = (float)(sh->sub[2] - ksub_prev[2]);
-                tr.v[0] = (float)sh->ksub[0]; tr.v[1] = (float)sh->ksub[1]; tr.v[2] = (float)sh->ksub[2]; tr.step = (float)sh->ksub[3];
-                for (int q = 0; q < 4; ++q) ksub_prev[q] = sh->sub[q];
-                for (int q = 0; q < 10; ++q) kt_prev[q] = ticks[q];
-            }
-#endif
-            if (sh->stop) { ++k; break; }
-            if (adopt_launch && (Ge > 1 || sh->adopt_req) && k + 1 < P.max_iter) {
-                // Members of a pair that has (or is about to get) helpers agree on the member count of the next iteration: the owner
-                // decides -- it accepts an offer it saw in its epilogue, if the pair may still grow -- and writes {iteration, members}
-                // into the pair's control word; the helpers wait for that word.  On a change every member deals its rows anew
-                // (pair_rows) and the lists are rebuilt; the newcomer starts from the state the owner published (the head of
-                // PairState: R, T, ell, the current transform; iter) as member `old count`.
-                if (tid == 0) {
-                    int g_next = Ge;
-                    gu64* ctrl = &queue[1 + slots + (ge == 0 ? slot : (int)sh->ws_slot)];
-                    if (ge == 0) {
-                        if (sh->adopt_req && Ge < ADOPT_GMAX) {
-                            CVO_GLOBAL unsigned* pub = (CVO_GLOBAL unsigned*)Dp->state;
-                            for (int i = 0; i < 9; ++i) pub[i] = __float_as_uint(sh->R[i]);
-                            for (int i = 0; i < 3; ++i) pub[9 + i] = __float_as_uint(sh->T[i]);
-                            pub[12] = __float_as_uint(sh->ell);
-                            for (int i = 0; i < 12; ++i) pub[13 + i] = __float_as_uint(sh->M[i]);
-                            ((CVO_GLOBAL PairState*)Dp->state)->iter = sh->iter_at_break;
-                            unsigned long long e = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)(sh->adopt_req - 1);
-                            const unsigned long long acc = ((unsigned long long)(launch_tag | ADOPT_ACCEPT) << 32) | ((unsigned)(Ge + 1) << 24) | ((unsigned)Ge << 16) | (unsigned)((k + 1) & 0xFFFF);
-                            if (__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e, acc, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                // The helper polls this word and confirms within a microsecond or two (ACCEPT -> CONFIRMED, its CAS).  Only then does the pair count on
-                                // it: should no confirmation come (the helper is gone), the owner takes the acceptance back (ACCEPT -> FREE, its CAS -- one of the two
-                                // wins) and the pair carries on with the members it has, instead of waiting for a member that never sends its partial sums.
-                                bool joined = false;
-                                const unsigned long long t_acc = __builtin_amdgcn_s_memrealtime();
-                                for (;;) {
-                                    const unsigned long long x = __hip_atomic_load((gu64*)sh->adopt_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    if ((unsigned)(x >> 32) != (launch_tag | ADOPT_ACCEPT)) { joined = true; break; }
-                                    if (__builtin_amdgcn_s_memrealtime() - t_acc > ADOPT_CONFIRM_TICKS) {
-                                        unsigned long long e2 = acc;
-                                        joined = !__hip_atomic_compare_exchange_strong((gu64*)sh->adopt_word, &e2, ((unsigned long long)(launch_tag | ADOPT_FREE) << 32) | (unsigned)(k + 1),
-                                                                                        __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        break;
-                                    }
-                                    __builtin_amdgcn_s_sleep(1);
-                                }
-                                if (joined) {
-                                    g_next = Ge + 1;
-                                    if (!sh->joined_at) sh->joined_at = k + 1;
-                                    if (g_next >= ADOPT_GMAX) sh->adopt_word = nullptr;     // full: no more offers are looked at (the newcomer leaves the word as it is)
-                                } else sh->retracted += 1;
-                            }
-                        }
-                        if (g_next > 1) __hip_atomic_store(ctrl, ((unsigned long long)(launch_tag | (unsigned)((k + 1) & 0xFFFF)) << 32) | (unsigned)g_next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                        for (;;) {
-                            const unsigned long long x = __hip_atomic_load(ctrl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((unsigned)(x >> 32) == (launch_tag | (unsigned)((k + 1) & 0xFFFF))) { g_next = (int)(unsigned)x; break; }
-                            if (__builtin_amdgcn_s_memrealtime() - t_start > 300000000ull) { sh->status = 6; break; }   // 3 s: the owner is gone
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                    }
-                    sh->adopt_req = g_next;
-                    if (g_next != Ge) {
-                        int rp, nr; pair_rows(nf, ge, g_next, rp, nr); sh->ctx_rows_per = rp; sh->ctx_nrows = nr;
-                        store_ctx(Dp, ge, g_next);
-                        sh->list_valid = 0; sh->rebuild = 1; sh->dense_mode = 0;
-                    }
-                }
-                __syncthreads();
-                Ge = sh->adopt_req;
-                __syncthreads();
-                if (sh->status != 0) break;
-            }
-        }
-
-        // ---- after the loop: the tracker's score block for this pair, when asked for (one workgroup per pair; a helped pair is left to the host)
-        __syncthreads();
-        if (Dp->score_out && ok_pair) phase_tail_scores(Dp, ge, Ge, tgeo, y_lds, k);   // every workgroup of the pair: each holds the lists of its own rows
-        // ---- (cvo.cpp:815-817): write the pair's state back
-        __syncthreads();
-        if (tid == 0 && ge == 0) {
-            if (adopt_launch) __hip_atomic_store(&queue[1 + slot], (unsigned long long)(launch_tag | ADOPT_CLOSED) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody joins any more
-            PairState fin;
-            float R[9], T[3], M[12];
-            for (int i = 0; i < 9; ++i) { R[i] = sh->R[i]; fin.R[i] = R[i]; }
-            for (int i = 0; i < 3; ++i) { T[i] = sh->T[i]; fin.T[i] = T[i]; }
-            make_transform(R, T, M);                                                            // final update_tf, cvo.cpp:817
-            for (int i = 0; i < 12; ++i) { fin.prev_transform[i] = sh->M[i]; fin.transform[i] = M[i]; }
-            fin.ell = sh->ell;
-            fin.iter = sh->iter_at_break;                                                       // unchanged (stale) if no break: Q4
-            fin.A_nonzero = sh->nnz;
-            fin.iterations_run = k;
-            fin.status = sh->status;
-            fin.rebuilds = sh->rebuilds;
-            fin.joined_at = sh->joined_at; fin.adopt_retracted = sh->retracted;
-            fin.dense_fallbacks = sh->dense_fallbacks;
-            fin.candidates_total = (long long)sh->cand_total; fin.nonzeros_total = (long long)sh->nnz_total;
-            for (int i = 0; i < 10; ++i) fin.phase_ticks[i] = sh->ticks[i];
-            fin.phase_ticks[7] = sh->sub[0]; fin.phase_ticks[9] = sh->sub[1]; fin.phase_ticks[2] = sh->sub[2]; fin.phase_ticks[4] = sh->sub[3];
-            fin.clk_cycles = __builtin_amdgcn_s_memtime() - clk_c0; fin.clk_ticks = __builtin_amdgcn_s_memrealtime() - clk_t0; fin.clk_t0 = clk_t0; fin.cull_mask = sh->cull_mask; fin.predict_mask = sh->predict_mask; for (int i = 0; i < 4; ++i) fin.tail_ticks[i] = sh->tail_ticks[i];
-            *Dp->state = fin;                                          // device copy: the next launch may start from it
-            *Dp->state_host = fin;                                     // pinned host mirror: visible to the host when the kernel has completed
-            if (Dp->record) {                                          // the pair's 64-byte record of the cross-GPU gather (ints as floats: exact below 2^24)
-                gv4f* rec = (gv4f*)Dp->record;
-                v4f r0, r1, r2, r3;
-                r0.x = M[0]; r0.y = M[1]; r0.z = M[2]; r0.w = M[3]; r1.x = M[4]; r1.y = M[5]; r1.z = M[6]; r1.w = M[7]; r2.x = M[8]; r2.y = M[9]; r2.z = M[10]; r2.w = M[11];
-                r3.x = (float)fin.iter; r3.y = (float)fin.A_nonzero; r3.z = (float)fin.iterations_run; r3.w = (float)fin.status;
-                rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3;
-            }
-        }
-        __syncthreads();
+        run_pair(descs, p, slot, slots, ge, Ge, k_join, launch_tag, tgeo, y_lds, queue_in, raw_table, adopt_launch ? 1 : 0);
     }
 }
 
