@@ -203,7 +203,7 @@ DevParams to_dev(const cvo_params& p) {
     d.sigma = p.sigma; d.sp_thres = p.sp_thres; d.c = p.c; d.d = p.d; d.c_ell = p.c_ell; d.c_sigma = p.c_sigma;
     d.min_step = p.min_step; d.eps = p.eps; d.eps_2 = p.eps_2; d.max_iter = p.max_iter;
     d.skin = 0.25f;
-    d.skin_alpha = 0.f;
+    d.skin_alpha = 0.f; d.alpha_gamma = 0.f;
     d.nt_min = 0;
     d.overlap_stop_test = 1;
     d.predict = 0.7f; d.predict_steps = 8.f;   // lists built / filtered 0.7 of every point's allowance ahead on the path: -10 % culls, +1 % (profiles/r04_predicted_list_centres.txt)
@@ -274,6 +274,7 @@ struct Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
     bool wide_waves = true;          // CVO_HIP_WIDE=0: plane-layout launches run the two-waves-per-SIMD build as well
+    bool gamma_set = false;          // CVO_HIP_ALPHA_GAMMA given: else the depth-proportional margin falls with ell (gamma 1) in the float4 layout: +1 % (profiles/r04_list_margin_gamma.txt)
     bool alpha_auto = true;          // ... and its depth-proportional part (CVO_HIP_SKIN_ALPHA fixes it; CVO_HIP_SKIN alone = one margin for all rows, alpha 0)
     bool skin_auto = true;           // the list radius margin follows the layout: 0.35 with the cloud resident as 16-byte points (3 k-point shape), 0.30 otherwise -- measured with
                                      // the device full (profiles/r03_skin_sweep.txt): a cull costs LDS and issue time only, a longer list costs memory traffic, and that is dearer
@@ -341,6 +342,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_WGS_PER_CU")) per_cu = std::max(1, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_SKIN")) { P.skin = (float)std::atof(e); skin_auto = false; }
         if (const char* e = std::getenv("CVO_HIP_SKIN_ALPHA")) { P.skin_alpha = std::max(0.f, std::min(0.2f, (float)std::atof(e))); alpha_auto = false; }
+        if (const char* e = std::getenv("CVO_HIP_ALPHA_GAMMA")) { P.alpha_gamma = std::max(0.f, std::min(4.f, (float)std::atof(e))); gamma_set = true; }
         if (const char* e = std::getenv("CVO_HIP_PREDICT")) P.predict = std::max(0.f, std::min(0.99f, (float)std::atof(e)));
         if (const char* e = std::getenv("CVO_HIP_PREDICT_STEPS")) P.predict_steps = std::max(0.f, (float)std::atof(e));
         if (const char* e = std::getenv("CVO_HIP_OVERLAP_STOP")) P.overlap_stop_test = std::atoi(e) != 0;
@@ -897,7 +899,7 @@ struct Engine {
         // The list margin: a moving point may travel skin * r + skin_alpha * (its distance from the camera) before the lists are stale (DevParams::skin_alpha).  Round 3 had one
         // margin for all rows (0.35 r / 0.30 r by layout); with the depth-proportional part the constant part shrinks to what a translation needs, the lists of the near (dense) rows
         // get shorter and the pairs cull 2.0-2.3 times instead of 3.3-3.8: +10 % at 3 k points, +6 % at 9 k (profiles/r04_list_margin_sweep.txt; other motion mixes: r04_list_margin_motion.txt)
-        if (skin_auto && alpha_auto) { Pl.skin = y_mode == 1 ? 0.05f : 0.15f; Pl.skin_alpha = y_mode == 1 ? 0.0125f : 0.01f; }
+        if (skin_auto && alpha_auto) { Pl.skin = y_mode == 1 ? 0.05f : 0.15f; Pl.skin_alpha = y_mode == 1 ? 0.0125f : 0.01f; if (!gamma_set) Pl.alpha_gamma = y_mode == 1 ? 1.0f : 0.f; }
         else if (skin_auto) Pl.skin = y_mode == 1 ? 0.35f : 0.30f;   // CVO_HIP_SKIN_ALPHA given alone: the constant part as round 3 had it
         Pl.adopt_on = ac ? 1 : 0;
         if (qc) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
@@ -1632,7 +1634,7 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
     A.trace = want_trace ? static_cast<AdaptiveRow*>(d_trace.p) : nullptr; A.trace_cap = want_trace ? trace_cap : 0; A.trace_len = static_cast<int*>(d_len.p);
     A.ell_min = ap.ell_min; A.dl_step = ap.dl_step;
     A.P.sigma = ap.sigma; A.P.sp_thres = ap.sp_thres; A.P.c = ap.c; A.P.d = ap.d; A.P.c_ell = ap.c_ell; A.P.c_sigma = ap.c_sigma;
-    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.skin_alpha = 0.f; A.P.nt_min = 0; A.P.overlap_stop_test = 0; A.P.predict = 0.f; A.P.predict_steps = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.colocate = 0;
+    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.skin_alpha = 0.f; A.P.alpha_gamma = 0.f; A.P.nt_min = 0; A.P.overlap_stop_test = 0; A.P.predict = 0.f; A.P.predict_steps = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.colocate = 0;
     A.partials = static_cast<double*>(d_part.p);
     // a few iterations are queued at a time (five small kernels each, the rows of the sweeps spread over the device); kernels queued behind a
     // stop return at once, and the host looks at the stop flag between the chunks

@@ -673,6 +673,11 @@ template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
+// the depth-proportional list margin at the present ell: skin_alpha at the first ell (0.15, cvo.cpp:35), falling with ell to the power alpha_gamma -- the cloud moves less
+// from iteration to iteration as the alignment converges, and at ell = 0.03 a margin of 0.0125 |x| is as large as the radius itself (DevParams::alpha_gamma)
+__device__ __forceinline__ float list_alpha(const DevParams& P, float ell) {
+    return P.alpha_gamma > 0.f ? P.skin_alpha * __powf(fminf(ell * (1.0f / 0.15f), 1.0f), P.alpha_gamma) : P.skin_alpha;
+}
 constexpr int PF = 4;                 // list entries a lane evaluates side by side
 constexpr int NCLS = 128;             // list-length classes (ceil(len / PF), the last one open-ended) the rows are sorted by
 // The transformed moving cloud lives in LDS as float4 {y, g0} (mode 1), as three float planes when that does not fit but
@@ -906,7 +911,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
     const float Rb = r_c * (1.0f + sh->P.skin);
     // row i is listed with radius (Rb + alpha |x_i|) / (1 - alpha) (DevParams::skin_alpha; phase_transform's staleness test is its counterpart)
-    const float alpha = sh->P.skin_alpha, inv_1ma = 1.0f / (1.0f - alpha);
+    const float alpha = list_alpha(sh->P, sh->ell), inv_1ma = 1.0f / (1.0f - alpha);
     float xmax_l = 0.f;
     // The lists are built around where the cloud is HEADING, not where it is: a list stays valid while every point is within its allowance
     // (skin r + alpha |b_j|) of the position b_j it was listed at, so with b_j a stretch ahead on the path the same radius covers up to twice the
@@ -1541,7 +1546,7 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
 #pragma unroll
         for (int q = 0; q < 3; ++q) { om[q] = sh->omega[q]; vv[q] = sh->v[q]; }
         const float wn = norm3f(om), vn = norm3f(vv);
-        float t = sh->P.predict * fminf(vn > 1.0e-12f ? r_c * sh->P.skin / vn : 1.0e9f, wn > 1.0e-12f ? sh->P.skin_alpha / wn : 1.0e9f);
+        float t = sh->P.predict * fminf(vn > 1.0e-12f ? r_c * sh->P.skin / vn : 1.0e9f, wn > 1.0e-12f ? list_alpha(sh->P, sh->ell) / wn : 1.0e9f);
         t = fminf(t, sh->P.predict_steps * sh->step);
         if (t > 0.f && t < 1.0e8f) {
             float dR[9], dT[3];
@@ -1573,7 +1578,7 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
             if ((Rb + far_l) * 1.00001f <= sh->Rb) {
                 // ... and the CURRENT positions have to be within the reach of lists centred there (this iteration walks them): phase_transform's test of the
                 // lists about to be made, with the margin they will have
-                const float alpha_p = fmaxf(0.f, fminf(sh->P.skin_alpha, 0.999f * (sh->Rb - (Rb + far_l) * 1.00001f) / (sh->xmax * 1.0001f + sh->Rb)));
+                const float alpha_p = fmaxf(0.f, fminf(list_alpha(sh->P, sh->ell), 0.999f * (sh->Rb - (Rb + far_l) * 1.00001f) / (sh->xmax * 1.0001f + sh->Rb)));
                 float off_l = 0.f;
                 for (int j = tid; j < c.nm; j += nthreads) {
                     const float4 pj = ld4(c.moving + lo_off(j));
@@ -1599,7 +1604,7 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
         }
     }
     // the depth-proportional margin the old lists leave room for (see phase_transform's test)
-    const float alpha = fmaxf(0.f, fminf(sh->P.skin_alpha, 0.999f * (sh->Rb - (Rb + reach) * 1.00001f) / (sh->xmax * 1.0001f + sh->Rb)));
+    const float alpha = fmaxf(0.f, fminf(list_alpha(sh->P, sh->ell), 0.999f * (sh->Rb - (Rb + reach) * 1.00001f) / (sh->xmax * 1.0001f + sh->Rb)));
     const int kept = y_lds == 1 ? refine_lists<1>(c, L, sh, Rb, alpha, shift, sh_rt, lane, wave, nwaves) : (y_lds == 2 ? refine_lists<2>(c, L, sh, Rb, alpha, shift, sh_rt, lane, wave, nwaves) : refine_lists<0>(c, L, sh, Rb, alpha, shift, sh_rt, lane, wave, nwaves));
     if (lane == 0) sh->wsum[wave] = kept;
     __syncthreads();
