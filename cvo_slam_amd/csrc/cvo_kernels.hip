@@ -909,9 +909,11 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int nrows = c.nrows;
     const float r_c = sqrtf(gate_d2_align(sh->ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
-    const float Rb = r_c * (1.0f + sh->P.skin);
+    // the pair's first lists (no twist yet to extrapolate the path with, and the cloud moves fastest in its first iterations) take `first_scale` times the margins
+    const float mscale = sh->twist_ok ? 1.0f : sh->P.first_scale;
+    const float Rb = r_c * (1.0f + sh->P.skin * mscale);
     // row i is listed with radius (Rb + alpha |x_i|) / (1 - alpha) (DevParams::skin_alpha; phase_transform's staleness test is its counterpart)
-    const float alpha = list_alpha(sh->P, sh->ell), inv_1ma = 1.0f / (1.0f - alpha);
+    const float alpha = list_alpha(sh->P, sh->ell) * mscale, inv_1ma = 1.0f / (1.0f - alpha);
     float xmax_l = 0.f;
     // The lists are built around where the cloud is HEADING, not where it is: a list stays valid while every point is within its allowance
     // (skin r + alpha |b_j|) of the position b_j it was listed at, so with b_j a stretch ahead on the path the same radius covers up to twice the
@@ -2303,9 +2305,10 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
             phase_cull(Dp, ge, Ge, tgeo, y_lds);
             const unsigned long long t_b = CVO_NOW();
             phase_sort(Dp, ge, Ge, tgeo, y_lds);
-            if (sh->dense_mode && sh->P.skin > SKIN_DENSE_SCENE) {   // the lists of this margin do not fit (a surface a few decimetres from the camera): once more with the
-                __syncthreads();                                     // narrow margin, kept for the rest of the pair, before the rows fall back to dense sweeps
-                if (tid == 0) { sh->P.skin = SKIN_DENSE_SCENE; sh->P.skin_alpha = 0.f; sh->dense_fallbacks -= 1; }
+            if (sh->dense_mode && (sh->P.skin > SKIN_DENSE_SCENE || sh->P.skin_alpha > 0.f)) {   // the lists of this margin do not fit (a surface a few decimetres from the camera;
+                __syncthreads();                                     // clouds far from the origin, whose depth-proportional margin is metres): once more with a narrow constant
+                                                                     // margin, kept for the rest of the pair, before the rows fall back to dense sweeps
+                if (tid == 0) { sh->P.skin = fminf(sh->P.skin, SKIN_DENSE_SCENE); sh->P.skin_alpha = 0.f; sh->dense_fallbacks -= 1; }
                 __syncthreads();
                 phase_cull(Dp, ge, Ge, tgeo, y_lds);
                 phase_sort(Dp, ge, Ge, tgeo, y_lds);

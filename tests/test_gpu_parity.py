@@ -272,6 +272,26 @@ def test_dense_near_surface_keeps_the_list_path(hiplib, oracle):
     B.close()
 
 
+def test_clouds_far_from_the_origin_fall_back_to_the_constant_list_margin(hiplib, oracle):
+    """The depth-proportional part of the list margin (DevParams::skin_alpha) is metres for clouds given in a frame whose origin is far away (a world frame,
+    say): the lists of that margin do not fit, the pair takes the narrow constant margin instead -- no dense per-row sweeps, and the oracle's result."""
+    from cvo_slam_amd import synth
+    p = synth.make_small_pair(91, n=1400)
+    shift = np.array([40.0, -25.0, 12.0], np.float32)                      # both clouds 48 m from the origin; the alignment itself is translation-invariant up to rounding
+    fixed, moving = (p.fixed.xyz + shift, p.fixed.feat), (p.moving.xyz + shift, p.moving.feat)
+    o = oracle.OracleCvo(); o.set_pcd(*fixed); o.set_pcd(*moving); rc, _ = o.align(); assert rc == 0
+    ost = o.get_state()
+    B = hiplib.CvoBatch(1)
+    B.set_pair(0, fixed[0], fixed[1], moving[0], moving[1])
+    for wgs in (1, 3):
+        B.set_workgroups(wgs); B.reset_states()
+        r = B.align(1)[0]
+        assert r["status"] == 0 and r["dense_fallbacks"] == 0, r
+        re, te = rot_trans_err(r["transform"], ost["transform"])
+        assert re <= 1e-6 and te <= 1e-5 and r["iter"] == ost["iter"] and r["A_nonzero"] == ost["A_nonzero"], (re, te, r["iter"], ost["iter"])
+    B.close()
+
+
 def test_eth3d_shape_pair_tile_sweep(hiplib, oracle):
     """BASELINE config 5: ETH3D-shape 736x456 pair, ~9 k points per cloud (dense sampling).  The transformed cloud no longer
     fits in LDS (HBM/L2 path), a workgroup owns at most 4096 rows (G >= 3), and the cull tile is swept over
