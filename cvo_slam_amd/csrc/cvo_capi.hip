@@ -203,7 +203,7 @@ DevParams to_dev(const cvo_params& p) {
     d.sigma = p.sigma; d.sp_thres = p.sp_thres; d.c = p.c; d.d = p.d; d.c_ell = p.c_ell; d.c_sigma = p.c_sigma;
     d.min_step = p.min_step; d.eps = p.eps; d.eps_2 = p.eps_2; d.max_iter = p.max_iter;
     d.skin = 0.25f;
-    d.skin_alpha = 0.f; d.alpha_gamma = 0.f; d.first_scale = 1.f;
+    d.skin_alpha = 0.f; d.alpha_gamma = 0.f; d.first_scale = 1.f; d.fuse_refine = 1;
     d.nt_min = 0;
     d.overlap_stop_test = 1;
     d.predict = 0.7f; d.predict_steps = 8.f;   // lists built / filtered 0.7 of every point's allowance ahead on the path: -10 % culls, +1 % (profiles/r04_predicted_list_centres.txt)
@@ -343,6 +343,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_SKIN")) { P.skin = (float)std::atof(e); skin_auto = false; }
         if (const char* e = std::getenv("CVO_HIP_SKIN_ALPHA")) { P.skin_alpha = std::max(0.f, std::min(0.2f, (float)std::atof(e))); alpha_auto = false; }
         if (const char* e = std::getenv("CVO_HIP_ALPHA_GAMMA")) { P.alpha_gamma = std::max(0.f, std::min(4.f, (float)std::atof(e))); gamma_set = true; }
+        if (const char* e = std::getenv("CVO_HIP_FUSE_REFINE")) P.fuse_refine = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_FIRST_SCALE")) P.first_scale = std::max(0.f, std::min(16.f, (float)std::atof(e)));
         if (const char* e = std::getenv("CVO_HIP_PREDICT")) P.predict = std::max(0.f, std::min(0.99f, (float)std::atof(e)));
         if (const char* e = std::getenv("CVO_HIP_PREDICT_STEPS")) P.predict_steps = std::max(0.f, (float)std::atof(e));
@@ -1643,7 +1644,7 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
     A.trace = want_trace ? static_cast<AdaptiveRow*>(d_trace.p) : nullptr; A.trace_cap = want_trace ? trace_cap : 0; A.trace_len = static_cast<int*>(d_len.p);
     A.ell_min = ap.ell_min; A.dl_step = ap.dl_step;
     A.P.sigma = ap.sigma; A.P.sp_thres = ap.sp_thres; A.P.c = ap.c; A.P.d = ap.d; A.P.c_ell = ap.c_ell; A.P.c_sigma = ap.c_sigma;
-    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.skin_alpha = 0.f; A.P.alpha_gamma = 0.f; A.P.first_scale = 1.f; A.P.nt_min = 0; A.P.overlap_stop_test = 0; A.P.predict = 0.f; A.P.predict_steps = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.colocate = 0;
+    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.skin_alpha = 0.f; A.P.alpha_gamma = 0.f; A.P.first_scale = 1.f; A.P.fuse_refine = 0; A.P.nt_min = 0; A.P.overlap_stop_test = 0; A.P.predict = 0.f; A.P.predict_steps = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.colocate = 0;
     A.partials = static_cast<double*>(d_part.p);
     // a few iterations are queued at a time (five small kernels each, the rows of the sweeps spread over the device); kernels queued behind a
     // stop return at once, and the host looks at the stop flag between the chunks

@@ -22,6 +22,7 @@ struct DevParams {           // cvo.cpp:35-51
     float skin_alpha;        // depth-proportional part of the list margin: a moving point may travel skin*r + skin_alpha*|y| (its distance from the camera when the lists were
                              // built) before the lists are stale -- a rotation moves far points most, and far rows have few neighbours (density falls with 1/z^2), so their
                              // wider lists cost little; row i's list radius is (r (1 + skin) + skin_alpha |x_i|) / (1 - skin_alpha).  0 = one margin for all rows
+    int fuse_refine;         // the last candidate walk at an ell also makes the next ell's lists (cand_steady<REFINE>) instead of a filter pass of its own at the drop (CVO_HIP_FUSE_REFINE)
     float first_scale;       // the margins of a pair's first lists (built before any twist is known) are this many times skin / skin_alpha
     float alpha_gamma;       // skin_alpha applies at ell = 0.15 and falls with (ell / 0.15)^alpha_gamma (0 = the same at every ell)
     float predict;           // candidate lists are built around positions extrapolated along the previous iteration's twist, this fraction of every point's allowance ahead

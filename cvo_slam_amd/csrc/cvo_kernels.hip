@@ -114,6 +114,9 @@ struct __attribute__((aligned(16))) Shared {
     int rebuilds;
     int refines;           // list rebuilds done by filtering the old lists (ell drops)
     int resort;            // this refinement re-sorts the rows by their new list lengths (phase_refine)
+    int resort_pending;    // ... asked for by a candidate walk that filtered the lists on its way; done before the next iteration's walk (phase_resort)
+    int fused;             // list refinements made by a candidate walk on its way (diagnostics)
+    float reach_now;       // this iteration's reach (phase_transform), for the candidate walk that makes the next ell's lists
     int cull_next;         // next block pair of the cull to hand out
     int ws_slot;           // pair slot of the launch whose work buffers this workgroup uses (its own, or the one of the pair it helps with)
     int adopt_req;         // a finished workgroup of the launch has asked to help with this pair (1 + its block index), seen by the epilogue
@@ -497,12 +500,13 @@ __device__ __forceinline__ float se_kernel_value_ck(const float* xi, const float
 // se_kernel_value_flat for PFN entries of one row at once
 template <int PFN>
 __device__ __forceinline__ void se_kernel_values_flat(const float* xi, const float4 (&yj)[PFN], const float (&ck)[PFN], const bool (&active)[PFN], const Gates& G,
-                                                      float (&a_out)[PFN], float (&e_out)[PFN][3]) {
+                                                      float (&a_out)[PFN], float (&e_out)[PFN][3], float* d2_out = nullptr) {
     double x[PFN], p[PFN]; bool pass[PFN];
 #pragma unroll
     for (int u = 0; u < PFN; ++u) {
         const float e0 = xi[0] - yj[u].x, e1 = xi[1] - yj[u].y, e2 = xi[2] - yj[u].z;
         float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;              // nanoflann.hpp:403-406
+        if (d2_out) d2_out[u] = d2;
         pass[u] = active[u] & (d2 < G.d2_thres);
         // inside the radius the exponent is in [-0.25, 0] (Gates::poly_ok): twelve terms leave 2.4e-18 of exp there.  Outside it
         // the polynomial returns some finite or infinite number that `pass` throws away; no clamp needed
@@ -808,7 +812,7 @@ constexpr int PRE_T = 4096 / BLOCK_MAX;
 // staleness test does not depend on the new pose, the epilogue works it out while lane 0 is at the step and the pose update.
 template <int YM>
 __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Shared* sh, const float4 (&pre)[PRE_T], bool have_pre, int first_worker = 0, bool keep_M_on_stop = false,
-                                                 const float4* preb = nullptr) {
+                                                 bool have_preb = false, const float4* preb = nullptr) {
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int wstride = nthreads - first_worker;
     float M[12];
@@ -828,7 +832,7 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
     // its neighbourhood allow for by themselves (alpha_build x its distance from the camera at build time; 0 with one margin for all rows)
     float dmax = 0.f;
     const float alpha_b = sh->alpha_build;
-    auto one = [&](int j, const float4 lo, const float4* bq) {
+    auto one = [&](int j, const float4 lo, bool have_b, const float4 bq) {   // (have_b a flag of its own, not a null test of a pointer to a local array: see cand_steady)
         float y0, y1, y2;
         apply_transform(M, lo.x, lo.y, lo.z, y0, y1, y2);
         if (YM == 1) L.ylds[j] = make_float4(y0, y1, y2, lo.w);     // the cloud stays in LDS for the whole iteration ...
@@ -836,7 +840,7 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
         else c.ybuf.set(j, make_float4(y0, y1, y2, lo.w));          // ... or, too large for that, in HBM/L2
         if (have_list) {                                            // where the point was when the lists were built: the same arithmetic, then
             float b0, b1, b2, afar;
-            if (bq) { b0 = bq->x; b1 = bq->y; b2 = bq->z; afar = bq->w; }
+            if (have_b) { b0 = bq.x; b1 = bq.y; b2 = bq.z; afar = bq.w; }
             else {
                 apply_transform(Mb, lo.x, lo.y, lo.z, b0, b1, b2);
                 afar = alpha_b * (sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f);
@@ -849,9 +853,9 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
     int j = tid >= first_worker ? tid - first_worker : c.nm;
     if (have_pre) {
 #pragma unroll
-        for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u], preb ? &preb[u] : nullptr); j += wstride; }
+        for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u], have_preb, have_preb ? preb[u] : make_float4(0.f, 0.f, 0.f, 0.f)); j += wstride; }
     }
-    for (; j < c.nm; j += wstride) one(j, ld4(c.moving + lo_off(j)), nullptr);
+    for (; j < c.nm; j += wstride) one(j, ld4(c.moving + lo_off(j)), false, make_float4(0.f, 0.f, 0.f, 0.f));
     dmax = block_max(dmax, sh, tid, nwaves);                        // also makes ybuf / ylds visible to the workgroup
     if (tid == 0) {
         const float ell = sh->ell;
@@ -860,6 +864,7 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
         // within D < r_c + (its point's displacement) <= r_c + reach + a |y_j| <= r_c + reach + a (|x_i| + D) then: inside the list while
         // r_c + reach <= Rb.  (a = 0: the lists hold every pair within Rb, reach = the largest displacement.)
         const float reach = have_list ? dmax : 1.0e-5f;
+        sh->reach_now = reach;
         int rb = (!have_list || (sh->ell_build != ell) || (r_c + reach) * 1.00001f > sh->Rb) ? 1 : 0;
         // ell has dropped (cvo.cpp:810-812) and the old, wider lists still hold every pair within the NEW list radius of the
         // current positions: filter them in place instead of a dense cull (2 = refine).  Not in dense mode (no lists to filter).
@@ -1295,13 +1300,18 @@ __device__ __forceinline__ void fold_entry_e(const float* xi, const float4 y4, c
 }
 
 // every iteration but the first after a rebuild: entries {ck, j} stream in, PF per lane per step, the next step's in flight
-template <int YM, bool FLAT, bool NT = true>
+// REFINE: this is the last iteration at the present ell (cvo.cpp:810-812 is a schedule by iteration count), and the walk also makes the lists of the NEXT ell: it has
+// every entry and its squared distance at hand anyway, so the in-place filter of phase_refine (same rule: kept within the next radius of the current positions,
+// row i with (Rn + alpha |x_i|) / (1 - alpha)) costs it a compare and a store per kept entry instead of a pass of its own over the lists.  Rn, alpha: phase_candidates.
+template <int YM, bool FLAT, bool NT = true, bool REFINE = false>
 __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
-                                            double (&acc8)[8]) {
+                                            double (&acc8)[8], float Rn = 0.f, float alpha_n = 0.f, bool do_shift = false, const float* shift_rt = nullptr) {
     gv2u* sp = uni_ptr(c.surv + c.fbase + sh->wbase[wave]);
     const bool x_lds = sh->x_lds != 0;
     int wcount = 0;
     const int nb = sh->wnb[wave];
+    int kept_w = 0, nb_left = 0;
+    const float inv_1ma_n = 1.0f / (1.0f - alpha_n);
     const unsigned rp = (unsigned)c.rows_pad, estep = (PF / 2) * rp;      // in 16-byte words
     // the first entries of a block are fetched while the block before it is walked: in the late iterations a row holds only a
     // handful of entries, and a block would otherwise start with an exposed memory round trip
@@ -1322,6 +1332,21 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         const gv4u* eb = uni_ptr((const gv4u*)c.ent + (slot - lane)); // scalar base of the block's entries + 32-bit lane offsets
         unsigned eo = (unsigned)lane;
         const unsigned stag = (unsigned)slot << 16;
+        int cnt = 0; float thr_n = 0.f; gv2u* wp = nullptr; unsigned woff = 0u;
+        float xs[3] = {xi[0], xi[1], xi[2]};                        // the row as the next lists see it: moved by the inverse of the extrapolated motion (refine_lists, `shift`)
+        if (REFINE) {
+            const float xn = sqrtf(__builtin_fmaf(xi[2], xi[2], __builtin_fmaf(xi[1], xi[1], xi[0] * xi[0])));
+            float Ri = (Rn + alpha_n * xn * 1.0001f) * inv_1ma_n;
+            if (do_shift) {
+                xs[0] = sum3f(shift_rt[0] * xi[0], shift_rt[1] * xi[1], shift_rt[2] * xi[2]) + shift_rt[9];
+                xs[1] = sum3f(shift_rt[3] * xi[0], shift_rt[4] * xi[1], shift_rt[5] * xi[2]) + shift_rt[10];
+                xs[2] = sum3f(shift_rt[6] * xi[0], shift_rt[7] * xi[1], shift_rt[8] * xi[2]) + shift_rt[11];
+                Ri += 4.0e-6f * (1.0f + xn);
+            }
+            thr_n = Ri * Ri * 1.0001f;                              // (the margin covers the rounding of the un-fused sums against the cull's fused one many times over)
+            wp = uni_ptr(c.ent + 2 * (slot - lane));                // the kept entries go to the front of the row (never ahead of the reads): scalar base of the block + 32-bit offsets
+            woff = 2u * (unsigned)lane;                             // entry n of the lane's slot at 2 ((n >> 1) rows_pad + slot) + (n & 1)
+        }
         v4u eq4[PF / 2];
 #pragma unroll
         for (int u = 0; u < PF / 2; ++u) eq4[u] = ehead[u];
@@ -1347,10 +1372,18 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
                 ckv[u] = __uint_as_float(eq[u].x);
             }
             if (FLAT) {
-                float ev[PF][3];
-                se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av, ev);   // PF exp chains side by side
+                float ev[PF][3], d2v[PF];
+                se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av, ev, REFINE ? d2v : nullptr);   // PF exp chains side by side
 #pragma unroll
                 for (int u = 0; u < PF; ++u) fold_entry_e(xi, yv4[u], ev[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, wcount, lane);
+                if (REFINE) {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        float dn = d2v[u];
+                        if (do_shift) { const float q0 = xs[0] - yv4[u].x, q1 = xs[1] - yv4[u].y, q2 = xs[2] - yv4[u].z; dn = __builtin_fmaf(q2, q2, __builtin_fmaf(q1, q1, q0 * q0)); }
+                        if (actv[u] && dn < thr_n) { st_rf(at_off(wp, woff), eq[u]); woff += (cnt & 1) ? 2u * rp - 1u : 1u; ++cnt; }
+                    }
+                }
             } else {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) av[u] = actv[u] ? se_kernel_value_ck(xi, yv4[u], ckv[u], gates) : 0.f;
@@ -1362,8 +1395,22 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) { acc8[q] += (double)(inv_c * rs.sw[q]); acc8[3 + q] += (double)(inv_d * rs.sv[q]); }   // cvo.cpp:222-223
+        if (REFINE) {                                               // the block's lists as they are walked from the next iteration on (cf. refine_lists)
+            L.lenS[slot] = (uint16_t)cnt;
+            kept_w += cnt;
+            int cmax = cnt;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off, 64));
+            if (lane == 0) sh->blk_lmax[blk] = (unsigned short)cmax;
+            if (cmax > 0) nb_left = bi + 1;
+        }
     }
     if (lane == 0) { sh->wcnt[wave] = wcount; acc8[6] = (double)wcount; }
+    if (REFINE) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kept_w += __shfl_xor(kept_w, off, 64);
+        if (lane == 0) { sh->wnb[wave] = nb_left; sh->wsum[wave] = kept_w; }
+    }
 }
 
 // the first iteration on new lists: columns come from the cull's raw lists (by row), the colour gate and factor
@@ -1528,6 +1575,10 @@ __device__ __forceinline__ int refine_lists(const Ctx& c, const Lds& L, Shared* 
     return kept;
 }
 
+__device__ __forceinline__ void lists_filtered_impl(const Ctx& c, Shared* sh, int nwaves, int nblk, float Rb, float alpha, float ell_of_lists, int k);
+__device__ __forceinline__ void resort_lists_impl(const Ctx& c, const Lds& L, Shared* sh, int tile, int tid, int nthreads);
+__device__ __forceinline__ void lists_filtered(const Ctx& c, Shared* sh, int nwaves, int nblk, float Rb, float alpha, float ell_of_lists, int k) { lists_filtered_impl(c, sh, nwaves, nblk, Rb, alpha, ell_of_lists, k); }
+__device__ __forceinline__ void resort_lists(const Ctx& c, const Lds& L, Shared* sh, int tile, int tid, int nthreads) { resort_lists_impl(c, L, sh, tile, tid, nthreads); }
 static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
@@ -1611,13 +1662,23 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
     if (lane == 0) sh->wsum[wave] = kept;
     __syncthreads();
     if (tid == 0) {
+        for (int i = 0; i < 12; ++i) sh->Mb[i] = Mn[i];             // displacements count from here again
+        if (shift) sh->predicted += 1;
+        lists_filtered(c, sh, nwaves, nblk, Rb, alpha, sh->ell, k);
+    }
+    __syncthreads();
+    if (!sh->resort) return;
+    resort_lists(c, L, sh, tile, tid, nthreads);
+}
+
+// what follows an in-place filter of the lists (phase_refine, or the candidate walk that made the next ell's lists on its way): totals, the radius and margin the
+// lists now stand for, and whether the rows are worth re-sorting.  One thread; sh->wsum[w] = entries wave w kept.
+__device__ __forceinline__ void lists_filtered_impl(const Ctx& c, Shared* sh, int nwaves, int nblk, float Rb, float alpha, float ell_of_lists, int k) {
         int tot = 0, lmax_new = 0;
         long long walked = 0;                                        // list slots a walk evaluates in the present order: 64 rows x the longest list of each block, in steps of PF
         for (int w = 0; w < nwaves; ++w) tot += sh->wsum[w];
         for (int bq = 0; bq < nblk; ++bq) { const int lm = (int)sh->blk_lmax[bq]; lmax_new = max(lmax_new, lm); walked += 64 * PF * ((lm + PF - 1) / PF); }
-        sh->total = tot; sh->lmax = lmax_new; sh->Rb = Rb; sh->alpha_build = alpha; sh->ell_build = sh->ell; sh->refines += 1;
-        for (int i = 0; i < 12; ++i) sh->Mb[i] = Mn[i];             // displacements count from here again
-        if (shift) sh->predicted += 1;
+        sh->total = tot; sh->lmax = lmax_new; sh->Rb = Rb; sh->alpha_build = alpha; sh->ell_build = ell_of_lists; sh->refines += 1;
         // Re-sort (below) when it pays: it costs about 25 us + 1.7 ns per list entry (measured: 31 us at 13 k entries, 68 at 48 k, 240 at
         // 126 k -- the lists change columns, 64 cache lines per wave load) and saves 0.28 ns per list slot no longer walked, in every
         // iteration until the next rebuild: those left at this ell by the schedule of cvo.cpp:810-812, 24 assumed at the last one.
@@ -1626,9 +1687,12 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
         const float gain_ns = 0.28f * (float)left * ((float)walked - 1.3f * (float)tot), cost_ns = 25000.f + 1.7f * (float)tot;
         const int mode = sh->P.resort;                               // CVO_HIP_RESORT: 0 never, 1 by the cost model, 2 always
         sh->resort = (mode && lmax_new > 0 && (long long)((lmax_new + 1) & ~1) * c.rows_pad <= (long long)c.flat_cap && (mode == 2 || gain_ns > cost_ns)) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!sh->resort) return;
+}
+
+// Every thread; the record buffer must be idle (between the line search of one iteration and the candidate phase of the next).
+__device__ __forceinline__ void resort_lists_impl(const Ctx& c, const Lds& L, Shared* sh, int tile, int tid, int nthreads) {
+    const int lane = tid & 63, nwaves = nthreads >> 6, wave = tid >> 6;
+    const int nblk = (c.nrows + 63) >> 6;
     // The filter keeps a third to a half of every list, unevenly: rows that were neighbours in the old length order now differ by a factor
     // of two and more, and a wave walks its 64 rows for as long as the longest of them lasts (at ell = 0.03 the walk would evaluate 2.8 list
     // slots per listed candidate).  So the rows are sorted again by their new lengths and the lists move to their new slots -- through the
@@ -1667,6 +1731,16 @@ static __device__ __noinline__ void phase_refine(const PairDesc* Dp_in, int g_in
     finish_slots(c, L, sh, tile, tid, nthreads, false);
 }
 
+// the re-sort a candidate walk has asked for (it filtered the lists for the next ell on its way and found the rows worth re-sorting: Shared::resort_pending)
+static __device__ __noinline__ void phase_resort(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+    const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), tile = tgeo & 0x1FFF, y_lds = uni(y_lds_in);
+    const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
+    const Ctx c = make_ctx(Dp, g, G);
+    resort_lists(c, L, sh, tile, threadIdx.x, blockDim.x);
+    if (threadIdx.x == 0) sh->resort_pending = 0;
+    __syncthreads();
+}
+
 static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
@@ -1677,6 +1751,10 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
     const Gates gates = make_gates(sh->ell, sh->P);
     const bool dense_mode = sh->dense_mode != 0, fresh_list = sh->rebuild == 1;
     const float inv_c = 1 / sh->P.c, inv_d = 1 / sh->P.d;
+    const float ell_now = sh->ell;
+    bool fused = false, shifted = false; float Rn_f = 0.f, alpha_f = 0.f, ell_f = 0.f, Mb_f[12], shift_f[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { Mb_f[i] = 0.f; shift_f[i] = 0.f; }
     double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // omega[3], v[3], nnz, candidates
     const unsigned long long ts1 = CVO_NOW();
     if (!dense_mode) {
@@ -1693,7 +1771,77 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 #endif
         if (fresh_list) { if (gates.poly_ok) CVO_CAND(cand_fresh, true); else CVO_CAND(cand_fresh, false); }
         else if (y_lds == 1 && gates.poly_ok && sh->total < sh->P.nt_min) cand_steady<1, true, false>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8);   // short lists: plain loads (DevParams::nt_min)
-        else { if (gates.poly_ok) CVO_CAND(cand_steady, true); else CVO_CAND(cand_steady, false); }
+        else {
+            // Is this the last iteration at the present ell (cvo.cpp:810-812: the schedule goes by the iteration count), and do the lists hold everything within the
+            // NEXT ell's list radius of the current positions (phase_transform's condition for filtering them in place)?  Then this walk makes the next lists itself.
+            float ell_next = ell_now;
+            ell_next = (k > 2) ? (float)0.10 : ell_next; ell_next = (k > 9) ? (float)0.06 : ell_next; ell_next = (k > 19) ? (float)0.03 : ell_next;
+            if (sh->P.fuse_refine && y_lds == 1 && gates.poly_ok && ell_next != ell_now && sh->list_valid && sh->ell_build == ell_now && k + 1 < sh->P.max_iter) {
+                const float rcn = sqrtf(gate_d2_align(ell_next, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
+                Rn_f = rcn * (1.0f + sh->P.skin);
+                const float room = sh->Rb - (Rn_f + sh->reach_now) * 1.00001f;
+                if (room >= 0.f) {
+                    fused = true;
+                    float reach_f = sh->reach_now;
+                    ell_f = ell_next;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) Mb_f[i] = sh->M[i];
+                    // the next lists centred a stretch ahead on the path (phase_refine does the same for a filter pass of its own): the twist of the previous iteration
+                    // once more; the old lists must hold everything within the next radius of THOSE positions -- checked point by point.  (That the positions of the
+                    // first use, one pose update from here, are within reach of lists centred there is phase_transform's test at the start of the next iteration.)
+                    if (sh->P.predict > 0.f && sh->twist_ok) {
+                        float om[3], vv[3];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { om[q] = sh->omega[q]; vv[q] = sh->v[q]; }
+                        const float wn = norm3f(om), vn = norm3f(vv);
+                        float t = sh->P.predict * fminf(vn > 1.0e-12f ? rcn * sh->P.skin / vn : 1.0e9f, wn > 1.0e-12f ? list_alpha(sh->P, ell_next) / wn : 1.0e9f);
+                        t = fminf(t, sh->P.predict_steps * sh->step);
+                        if (t > 0.f && t < 1.0e8f) {
+                            float dR[9], dT[3], Mp[12], Mbo[12];
+                            exp_sek3(om, vv, t, dR, dT);
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                                for (int q = 0; q < 3; ++q) Mp[r * 4 + q] = sum3f(dR[0 * 3 + r] * Mb_f[0 * 4 + q], dR[1 * 3 + r] * Mb_f[1 * 4 + q], dR[2 * 3 + r] * Mb_f[2 * 4 + q]);
+                                Mp[r * 4 + 3] = sum3f(dR[0 * 3 + r] * (Mb_f[3] - dT[0]), dR[1 * 3 + r] * (Mb_f[7] - dT[1]), dR[2 * 3 + r] * (Mb_f[11] - dT[2]));
+                            }
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) Mbo[i] = sh->Mb[i];
+                            const float alpha_o = sh->alpha_build;
+                            float far_l = 0.f;
+                            for (int j = tid; j < c.nm; j += nthreads) {
+                                const float4 pj = ld4(c.moving + lo_off(j));
+                                float n0, n1, n2, b0, b1, b2;
+                                apply_transform(Mp, pj.x, pj.y, pj.z, n0, n1, n2);
+                                apply_transform(Mbo, pj.x, pj.y, pj.z, b0, b1, b2);
+                                const float e0 = n0 - b0, e1 = n1 - b1, e2 = n2 - b2;
+                                const float disp = sqrtf(__builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0))) * 1.0001f + 1.0e-5f;
+                                const float far = sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f;
+                                far_l = fmaxf(far_l, disp - alpha_o * far);
+                            }
+                            far_l = block_max(far_l, sh, tid, nwaves);
+                            if ((Rn_f + far_l) * 1.00001f <= sh->Rb) {
+                                shifted = true; reach_f = far_l;
+#pragma unroll
+                                for (int i = 0; i < 9; ++i) shift_f[i] = dR[i];
+#pragma unroll
+                                for (int q = 0; q < 3; ++q) shift_f[9 + q] = dT[q];
+#pragma unroll
+                                for (int i = 0; i < 12; ++i) Mb_f[i] = Mp[i];
+                            }
+                        }
+                    }
+                    alpha_f = fmaxf(0.f, fminf(list_alpha(sh->P, ell_next), 0.999f * (sh->Rb - (Rn_f + reach_f) * 1.00001f) / (sh->xmax * 1.0001f + sh->Rb)));
+                }
+            }
+            if (fused) {
+                float srt[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) srt[i] = uni_f(shift_f[i]);
+                cand_steady<1, true, true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8, Rn_f, alpha_f, shifted, srt);   // (a flag of its own: the compiler folds a null test of a pointer to a promoted local array the wrong way)
+            }
+            else if (gates.poly_ok) CVO_CAND(cand_steady, true); else CVO_CAND(cand_steady, false);
+        }
 #undef CVO_CAND
         if (tid == 0) acc8[7] = (double)sh->total;
     } else {
@@ -1740,6 +1888,12 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
         else if (tid == 7) sh->cand = (int)mine;
     }
     if (tid == 0) {
+        if (fused) {                                                 // (behind the reduction's barrier: every wave has left its kept count in sh->wsum)
+            for (int i = 0; i < 12; ++i) sh->Mb[i] = Mb_f[i];       // the new lists are those of the current positions, or of the positions a stretch ahead
+            if (shifted) sh->predicted += 1;
+            lists_filtered(c, sh, nwaves, (c.nrows + 63) >> 6, Rn_f, alpha_f, ell_f, k + 1);
+            sh->resort_pending = sh->resort; sh->fused += 1;
+        }
         const unsigned long long ts4 = CVO_NOW();
         sh->sub[0] += ts1 - ts0; sh->sub[1] += ts2 - ts1; sh->sub[2] += ts3 - ts2; sh->sub[3] += ts4 - ts3;
     }
@@ -1960,7 +2114,7 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
     if (first_worker && next_T) {
         // T of iteration k+1 (cvo.cpp:770-771), begun before this iteration's second stop test is known: should it fire, the transformed cloud is simply not
         // used (the state written back is R, T; Shared::M keeps the transform of the last executed iteration).  Its barriers publish lane 0's part B.
-        transform_body_t<1>(c, L, sh, pre, true, first_worker, true, preb);
+        transform_body_t<1>(c, L, sh, pre, true, first_worker, true, sh->list_valid != 0, preb);
     } else {
         __syncthreads();                                             // sh->stop and the rest of lane 0's results, for everyone
         if (!sh->stop && next_T) {                                   // T of iteration k+1 (cvo.cpp:770-771)
@@ -2278,7 +2432,7 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
         for (int i = 0; i < 4; ++i) sh->sub[i] = 0;
         for (int i = 0; i < 10; ++i) sh->ticks[i] = 0;
         sh->cand_total = 0; sh->nnz_total = 0; sh->cull_mask = 0ull; sh->predict_mask = 0ull; for (int i = 0; i < 4; ++i) sh->tail_ticks[i] = 0ull;
-        sh->P.skin = sh->skin0; sh->P.skin_alpha = sh->alpha0; sh->alpha_build = 0.f; sh->reach = 0.f; sh->xmax = 0.f; sh->twist_ok = 0; sh->predicted = 0; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
+        sh->P.skin = sh->skin0; sh->P.skin_alpha = sh->alpha0; sh->alpha_build = 0.f; sh->reach = 0.f; sh->xmax = 0.f; sh->twist_ok = 0; sh->predicted = 0; sh->resort_pending = 0; sh->fused = 0; sh->reach_now = 0.f; sh->list_valid = 0; sh->dense_mode = 0; sh->total = 0; sh->rebuilds = 0; sh->refines = 0; sh->dense_fallbacks = 0; sh->Rb = 0.f; sh->ell_build = -1.f;
     }
     __syncthreads();
     // a helper has read what the owner published for it: if the pair may grow further, its word takes offers again (not earlier --
@@ -2317,6 +2471,10 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
         } else if (sh->rebuild == 2) {
             phase_refine(Dp, ge, Ge, tgeo, y_lds, k);
             if (tid == 0 && sh->predicted) { sh->predict_mask |= 1ull << min(k, 63); sh->predicted = 0; }
+        }
+        if (sh->resort_pending) {
+            if (sh->rebuild == 0) phase_resort(Dp, ge, Ge, tgeo, y_lds);
+            else { __syncthreads(); if (tid == 0) sh->resort_pending = 0; __syncthreads(); }   // (the lists have been rebuilt or filtered again meanwhile)
         }
         CVO_PHASE(0);
         phase_candidates(Dp, ge, Ge, tgeo, y_lds, k);
