@@ -1776,7 +1776,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
             // NEXT ell's list radius of the current positions (phase_transform's condition for filtering them in place)?  Then this walk makes the next lists itself.
             float ell_next = ell_now;
             ell_next = (k > 2) ? (float)0.10 : ell_next; ell_next = (k > 9) ? (float)0.06 : ell_next; ell_next = (k > 19) ? (float)0.03 : ell_next;
-            if (sh->P.fuse_refine && y_lds == 1 && gates.poly_ok && ell_next != ell_now && sh->list_valid && sh->ell_build == ell_now && k + 1 < sh->P.max_iter) {
+            if (sh->P.fuse_refine && y_lds != 0 && gates.poly_ok && ell_next != ell_now && sh->list_valid && sh->ell_build == ell_now && k + 1 < sh->P.max_iter) {
                 const float rcn = sqrtf(gate_d2_align(ell_next, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
                 Rn_f = rcn * (1.0f + sh->P.skin);
                 const float room = sh->Rb - (Rn_f + sh->reach_now) * 1.00001f;
@@ -1838,7 +1838,9 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
                 float srt[12];
 #pragma unroll
                 for (int i = 0; i < 12; ++i) srt[i] = uni_f(shift_f[i]);
-                cand_steady<1, true, true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8, Rn_f, alpha_f, shifted, srt);   // (a flag of its own: the compiler folds a null test of a pointer to a promoted local array the wrong way)
+                // (the shift as a flag of its own: the compiler folds a null test of a pointer to a promoted local array the wrong way)
+                if (y_lds == 1) cand_steady<1, true, true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8, Rn_f, alpha_f, shifted, srt);
+                else cand_steady<2, true, true, true>(c, L, sh, gates, lane, wave, nwaves, inv_c, inv_d, acc8, Rn_f, alpha_f, shifted, srt);
             }
             else if (gates.poly_ok) CVO_CAND(cand_steady, true); else CVO_CAND(cand_steady, false);
         }
