@@ -182,14 +182,19 @@ def latency_probe(ca, pairs, device):
     B.close()
     # the point-cloud generator (cvo.set_pcd on the images): GPU vs the oracle's CPU restatement
     from cvo_slam_amd import synth
-    (fa, da), _, _ = synth.make_frames(0)
+    (fa, da), (fb0, db0), _ = synth.make_frames(0)
     camt = synth.camera_tuple(synth.TUM1)
     g = ca.Cvo(device=device)
-    pg = []
-    for _ in range(7):
-        t0 = time.perf_counter(); g.set_pcd_images(fa, da, camt); pg.append(time.perf_counter() - t0)
+    pg, pg_same = [], []
+    for i in range(8):                                     # the two frames in turn: every call generates (a frame repeated on the same thread is taken over, below)
+        fr = (fa, da) if i % 2 == 0 else (fb0, db0)
+        t0 = time.perf_counter(); g.set_pcd_images(fr[0], fr[1], camt); pg.append(time.perf_counter() - t0)
+    g.set_pcd_images(fa, da, camt)
     n_pts = g.get_fixed_and_moving_number()[1] or g.get_cloud(0)[0].shape[0]
-    g.close()
+    g2 = ca.Cvo(device=device)
+    for _ in range(5):                                     # the frame the thread's last generation saw: compared byte for byte, the cloud copied on the device
+        t0 = time.perf_counter(); g2.set_pcd_images(fa, da, camt); pg_same.append(time.perf_counter() - t0)
+    g.close(); g2.close()
     # one live tracking step from images, the reference's per-frame sequence (local_tracker.cpp:356-431): odometry object
     # match_odometry(frame), keyframe object match_keyframe(frame) + compute_innerproduct; fresh objects per repetition
     (_, _), (fb, db), _ = synth.make_frames(0)
@@ -197,6 +202,7 @@ def latency_probe(ca, pairs, device):
     for full in (False, True):     # full: with the odometry object's score block too, as local_tracker.cpp:356-431 has it (the series up to round 3 timed the keyframe object's only)
         for _ in range(5):
             odo, kf = ca.Cvo(device=device), ca.Cvo(device=device)
+            odo.set_tail_scores(True); kf.set_tail_scores(True)       # what the adaptor sets for the tracker's two objects: every alignment queues its score block behind itself
             odo.set_pcd_images(fa, da, camt); kf.set_pcd_images(fa, da, camt)
             t0 = time.perf_counter()
             tfo = odo.match_odometry_images(fb, db, camt)
@@ -205,6 +211,7 @@ def latency_probe(ca, pairs, device):
             tfk = kf.match_keyframe_images(fb, db, camt)
             kf.compute_innerproduct(tfk.astype(np.float32))
             (trf if full else tr).append(time.perf_counter() - t0)
+            shared = kf.shared_cloud_count()                          # 2: the keyframe object took both frames' clouds over from the odometry object's generation (same images)
             odo.close(); kf.close()
     pc = []
     try:
@@ -218,8 +225,8 @@ def latency_probe(ca, pairs, device):
     med = lambda v: 1e3 * float(np.median(v))
     img_bytes = fa.size + 2 * da.size
     return {"single_pair_align_ms": med(al), "single_pair_score_block_ms": med(sc), "lc_candidates": n,
-            "set_pcd_images_ms": med(pg[2:]), "set_pcd_images_points": int(n_pts), "set_pcd_images_input_MB": img_bytes / 1e6,
-            "set_pcd_images_cpu_port_ms": med(pc), "tracker_frame_from_images_ms": med(tr), "tracker_frame_with_both_score_blocks_ms": med(trf),
+            "set_pcd_images_ms": med(pg[2:]), "set_pcd_images_same_frame_ms": med(pg_same), "set_pcd_images_points": int(n_pts), "set_pcd_images_input_MB": img_bytes / 1e6,
+            "set_pcd_images_cpu_port_ms": med(pc), "tracker_frame_from_images_ms": med(tr), "tracker_frame_with_both_score_blocks_ms": med(trf), "tracker_frame_clouds_taken_over": shared,
             "lc_batch_align_ms": med(la), "lc_batch_score_block_ms": med(ls), "note": "host wall time per call, median of 5, automatic workgroup count"}
 
 

@@ -86,7 +86,7 @@ ABI_SYMBOLS = [
     "cvo_batch_create", "cvo_batch_destroy", "cvo_batch_set_pair", "cvo_batch_set_state", "cvo_batch_set_workgroups",
     "cvo_batch_reset_states", "cvo_batch_align_async", "cvo_batch_wait", "cvo_batch_last_launch",
     "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds", "cvo_batch_compute_innerproduct_lc",
-    "cvo_set_pcd_images", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
+    "cvo_set_pcd_images", "cvo_shared_cloud_count", "cvo_queued_score_count", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
     "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups", "cvo_batch_set_adoption", "cvo_batch_last_adoptions", "cvo_batch_last_adoption_retractions",
@@ -173,6 +173,8 @@ def load_library():
     L.cvo_batch_compute_innerproduct_lc.argtypes = [vp, C.c_int, fp, fp, fp, C.POINTER(LcScores)]
     L.cvo_set_pcd_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera)]
     L.cvo_set_num_want.argtypes = [vp, C.c_int]
+    L.cvo_shared_cloud_count.argtypes = [vp, C.POINTER(C.c_int)]
+    L.cvo_queued_score_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.cvo_match_odometry_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera), dp]
     L.cvo_match_keyframe_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera), dp]
     L.cvo_get_cloud.argtypes = [vp, C.c_int, fp, fp, C.c_int, ip]
@@ -496,9 +498,18 @@ class Cvo:
     def set_workgroups(self, g: int):
         _check(self.L.cvo_set_workgroups(self.h, int(g)))
 
-    def set_tail_scores(self, on: bool):
-        """cvo_set_tail_scores: the align launch answers the tracker's score block itself (default) or leaves it to the score kernel"""
-        _check(self.L.cvo_set_tail_scores(self.h, int(bool(on))))
+    def set_tail_scores(self, on):
+        """cvo_set_tail_scores: the alignment queues the tracker's score block behind itself and compute_innerproduct(the result) only collects.
+        False / 0 never, True / 1 every alignment, 2 (the handle's default) when the previous alignment was followed by that question"""
+        _check(self.L.cvo_set_tail_scores(self.h, int(on)))
+
+    def queued_score_count(self) -> int:
+        """cvo_queued_score_count: score blocks answered by what an alignment of this object had queued behind itself"""
+        n = C.c_int(0); _check(self.L.cvo_queued_score_count(self.h, C.byref(n))); return n.value
+
+    def shared_cloud_count(self) -> int:
+        """cvo_shared_cloud_count: clouds this object took from the thread's previous generation (same images) instead of generating them"""
+        n = C.c_int(0); _check(self.L.cvo_shared_cloud_count(self.h, C.byref(n))); return n.value
 
 
 RESULT_FLOATS = 16      # CVO_RESULT_FLOATS

@@ -11,6 +11,7 @@
 #include <functional>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -141,6 +142,22 @@ struct Cloud {
     float* rec() const { return static_cast<float*>(buf.p); }
     ~Cloud() { buf.release(); px.release(); boxes.release(); }
 };
+
+// The images a cloud was generated from, as they were staged for the device (pinned host memory): kept after the generation so that a second handle given the
+// SAME frame -- the tracker's cvo_odometry and cvo_keyframe objects build their MOVING cloud from one image with a deterministic selector (local_tracker.cpp:356,415;
+// SURVEY appendix B) -- can recognise it byte for byte and take a device copy of the finished cloud instead of generating it again (cvo_set_pcd_images).  `stamp`
+// is raised before the owner overwrites the buffer: a compare that saw the same stamp before and after has read one image.
+struct ImageStage {
+    PinBuf buf; std::atomic<unsigned long long> stamp{0};
+    ~ImageStage() { buf.release(); }
+};
+struct LastGenerated {          // per host thread: the handles of one thread are used one after the other, so whoever shares never races with the generator
+    std::shared_ptr<ImageStage> stage; unsigned long long stamp = 0;
+    int device = -1, w = 0, h = 0, num_want = 0; cvo_camera cam{};
+    std::shared_ptr<Cloud> cloud;
+};
+LastGenerated& last_generated() { static thread_local LastGenerated g; return g; }
+bool share_generated_clouds() { static const bool on = [] { const char* e = std::getenv("CVO_HIP_SHARE_CLOUDS"); return !e || std::atoi(e) != 0; }(); return on; }
 
 // Copy threads of the hand-over (Engine::upload_many: a batch's host arrays into the pinned ring, 12.6 MB per 64-pair step).  They live as long as the process:
 // starting three threads per hand-over cost 0.1 ms of the host's 0.5 per step, and a step's launch is resubmitted that much later (profiles/r04_upload_pool.txt).
@@ -527,6 +544,7 @@ struct Engine {
     // ---- pcd_generator on the GPU (cvo_pcd_kernels.hip).  Image-sized scratch lives with the engine.
     DevBuf d_bgr, d_depth, d_I0, d_I1, d_I2, d_dx0, d_dy0, d_abs0, d_abs1, d_abs2, d_ths, d_thsS, d_map, d_pattern, d_counts, d_tiles;
     PinBuf h_counts;
+    std::shared_ptr<ImageStage> img_stage;                          // the frame's images as staged for the copy to the device (ImageStage above)
     int pattern_len = 0;
     // glibc srand(seed); rand() & 0xFF, n times (PixelSelector2.cpp:36-38): TYPE_3 additive feedback generator
     static void rand_pattern(unsigned seed, unsigned char* out, size_t n) {
@@ -561,9 +579,9 @@ struct Engine {
         if ((rc = d_map.ensure(n))) return rc;
         if ((rc = d_counts.ensure(sizeof(int) * 8))) return rc;
         if ((rc = h_counts.ensure(sizeof(int) * 8))) return rc;
-        if ((rc = drain_ring())) return rc;                             // nothing reads the staging ring any more
-        if ((rc = h_stage.ensure(5 * n))) return rc;
-        stage_used = (5 * n + 255) & ~(size_t)255;                      // the images are staged at the start of the ring
+        if (!img_stage) img_stage = std::make_shared<ImageStage>();     // (the copies of the previous generation have run: it ended with a synchronize)
+        img_stage->stamp.fetch_add(1, std::memory_order_acq_rel);       // whoever compares against the old content sees that it is going
+        if ((rc = img_stage->buf.ensure(5 * n))) return rc;
         if (pattern_len != (int)n) {                                    // the byte pattern only depends on w*h: made once
             if ((rc = d_pattern.ensure(n))) return rc;
             std::vector<unsigned char> pat(n);
@@ -571,7 +589,7 @@ struct Engine {
             HIP_TRY(hipMemcpy(d_pattern.p, pat.data(), n, hipMemcpyHostToDevice));
             pattern_len = (int)n;
         }
-        unsigned char* st = static_cast<unsigned char*>(h_stage.p);
+        unsigned char* st = static_cast<unsigned char*>(img_stage->buf.p);
         std::memcpy(st, bgr8, 3 * n); std::memcpy(st + 3 * n, depth16, 2 * n);
         HIP_TRY(hipMemcpyAsync(d_bgr.p, st, 3 * n, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_depth.p, st + 3 * n, 2 * n, hipMemcpyHostToDevice, stream));
@@ -966,6 +984,16 @@ struct Engine {
         HIP_TRY(hipEventElapsedTime(&last_ms, ev0, ev1));
         return CVO_OK;
     }
+    // the align kernel has finished (its states are in h_states, which it writes itself); work queued behind it on the stream may still run
+    int wait_align_only() {
+        HIP_TRY(hipSetDevice(device));
+        if (!launched) return fail(CVO_ERR_INVALID, "no launch to wait for");
+        const hipError_t es = hipEventSynchronize(ev1);
+        release_slots();
+        if (es != hipSuccess) return fail(CVO_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(es));
+        HIP_TRY(hipEventElapsedTime(&last_ms, ev0, ev1));
+        return CVO_OK;
+    }
     const PairState* results() const { return static_cast<const PairState*>(h_states.p); }
 
     // function_inner_product / se3_Hessian: out[0]=sum_A, out[1]=count, out[2..22]=Hessian terms
@@ -1182,7 +1210,7 @@ void finish_hessian(const double* terms21, int inliers, double Hout[36]) {
 struct cvo_handle_s {
     cvo_params prm;
     Engine eng;
-    std::unique_ptr<Cloud> fixed, moving, previous;     // ptr_fixed_pcd / ptr_moving_pcd / ptr_previous_pcd, cvo.hpp:91-94
+    std::shared_ptr<Cloud> fixed, moving, previous;     // ptr_fixed_pcd / ptr_moving_pcd / ptr_previous_pcd, cvo.hpp:91-94 (shared with last_generated() only: never written again)
     bool pre_pc_init = false, init = false, first_frame = true;
     int num_fixed = 0, num_moving = 0;
     float R[9], T[3], ell;
@@ -1195,7 +1223,20 @@ struct cvo_handle_s {
     // exactly these clouds, this ell and this transform; anything else goes to the score kernel as before.  Off by default: one pair alone runs on eight cooperating
     // workgroups, whose tail (a transform, a cull, two list walks, five exchanges) costs the launch 0.12 ms where the score launch behind it costs 0.07-0.10
     // (profiles/r04_tracker_path.txt); batches, one workgroup per pair with every CU busy, are where it pays (cvo_batch_set_tail_scores).
-    bool tail_scores = false;
+    // What "answers" means for a handle (CVO_HIP_HANDLE_TAIL=queue|kernel, default queue): the score kernel for {mv, fx, the result's transform and ell} is QUEUED right behind the
+    // align kernel, before the host starts waiting for the alignment (transform and ell come from the device-resident state, as cvo_batch_enqueue_innerproduct has it);
+    // cvo_align returns when the alignment is in, the score kernel runs while the caller looks at the transform, and compute_innerproduct(tran = that transform) only
+    // collects.  "kernel" is the batches' way (the align launch's own tail), slower for one pair on eight workgroups (above).
+    // cvo_set_tail_scores: 0 never, 1 always, 2 (default) when the handle's previous alignment was followed by exactly that question -- the tracker's two objects are asked
+    // after every frame (local_tracker.cpp:375, 431) and queue from their second frame on; a loop-closure object (compute_innerproduct_lc) never does.
+    int tail_mode = 2;
+    bool asked_after_align = false;                                  // compute_innerproduct(tran = the last alignment's transform) came since that alignment
+    bool tail_scores = false;                                        // this alignment starts the block (decided per alignment from the two above)
+    bool tail_in_kernel = false;
+    bool queued_valid = false;                                       // a score block for (queued_fixed, queued_moving, h->transform, h->ell) is queued or done on eng.score_stream
+    const Cloud* queued_fixed = nullptr; const Cloud* queued_moving = nullptr; float queued_ell = 0.f, queued_tran[12];
+    int queued_hits = 0;                                             // score blocks answered by what an alignment had queued
+    int shared_hits = 0;                                             // clouds this handle took from last_generated() instead of generating them
     bool tail_valid = false;
     double tail_r[5][24];
     const Cloud* tail_fixed = nullptr; const Cloud* tail_moving = nullptr;
@@ -1217,6 +1258,13 @@ Cloud* slot_cloud(cvo_handle_s* h, int slot) {
     switch (slot) { case CVO_SLOT_FIXED: return h->fixed.get(); case CVO_SLOT_MOVING: return h->moving.get(); case CVO_SLOT_PREVIOUS: return h->previous.get(); }
     return nullptr;
 }
+void slots_changed(cvo_handle_s* h) { h->tail_valid = false; h->queued_valid = false; }   // answers held for the clouds that were there are void (a new cloud may live at an old one's address)
+std::shared_ptr<Cloud>& slot_to_fill(cvo_handle_s* h) {            // cvo.cpp:352-366: the first cloud is the FIXED one, every later one MOVING
+    slots_changed(h);
+    if (!h->init) { if (!h->fixed || h->fixed.use_count() > 1 || h->fixed->n > 0) h->fixed = std::make_shared<Cloud>(); return h->fixed; }
+    h->moving = std::make_shared<Cloud>();
+    return h->moving;
+}
 void fresh_state(PairState& s, float ell) {
     std::memset(&s, 0, sizeof(s));
     s.R[0] = s.R[4] = s.R[8] = 1.f; s.ell = ell;
@@ -1231,15 +1279,25 @@ int do_align(cvo_handle_s* h, cvo_trace_row* trace, int trace_cap, int* trace_le
     std::memcpy(st.transform, h->transform.m, sizeof(st.transform));
     std::vector<Engine::PairIn> pairs{{h->fixed.get(), h->moving.get()}};
     const bool want_trace = trace && trace_cap > 0;
-    h->tail_valid = false;
-    h->eng.tail_scores = h->tail_scores;
+    h->tail_valid = false; h->queued_valid = false;
+    h->tail_scores = h->tail_mode == 1 || (h->tail_mode == 2 && h->asked_after_align);
+    h->asked_after_align = false;
+    h->eng.tail_scores = h->tail_scores && h->tail_in_kernel;
     int rc = h->eng.launch(pairs, &st, true, nullptr, want_trace, trace_cap); if (rc) return rc;
     if (want_trace) {
         // results copy is already queued; queue the trace copies behind it on the same stream
         HIP_TRY(hipMemcpyAsync(trace, h->eng.d_trace.p, sizeof(TraceRow) * trace_cap, hipMemcpyDeviceToHost, h->eng.stream));
         HIP_TRY(hipMemcpyAsync(trace_len, h->eng.d_tracelen.p, sizeof(int), hipMemcpyDeviceToHost, h->eng.stream));
     }
-    rc = h->eng.wait(); if (rc) return rc;
+    bool queued = false;
+    if (h->tail_scores && !h->tail_in_kernel && !want_trace) {       // the tracker's score block (cvo.cpp:489-500) behind the align kernel, transform and ell from the pair's state
+        const Cloud* fx = h->fixed.get(); const Cloud* mv = h->moving.get();
+        const Engine::ScoreReq rq[5] = {{mv, nullptr, fx, false, 0.f, 0, false}, {mv, nullptr, fx, false, 0.f, 0, true}, {fx, nullptr, fx, false, 0.f, 0, false},
+                                        {mv, nullptr, mv, false, 0.f, 0, false}, {mv, nullptr, fx, true, 0.f, 0, true}};
+        queued = h->eng.score_enqueue(rq, 5, h->eng.last_stream) == CVO_OK;
+    }
+    rc = queued ? h->eng.wait_align_only() : h->eng.wait(); if (rc) { h->eng.score_pending = 0; return rc; }
+    if (queued) { h->queued_valid = true; h->queued_fixed = h->fixed.get(); h->queued_moving = h->moving.get(); }   // (ell and transform: below, from the result)
     const PairState& r = h->eng.results()[0];
     if (r.status != CVO_OK) return fail(r.status, "align kernel reported an error (6 = inter-workgroup wait timed out)");
     std::memcpy(h->R, r.R, sizeof(h->R)); std::memcpy(h->T, r.T, sizeof(h->T));
@@ -1248,6 +1306,7 @@ int do_align(cvo_handle_s* h, cvo_trace_row* trace, int trace_cap, int* trace_le
     h->prev_transform = prev;                                        // cvo.cpp:815
     h->accum_transform = aff_mul(h->accum_transform, prev);          // cvo.cpp:816
     std::memcpy(h->transform.m, r.transform, sizeof(float) * 12);    // update_tf, cvo.cpp:817
+    if (h->queued_valid) { h->queued_ell = h->ell; std::memcpy(h->queued_tran, h->transform.m, sizeof(h->queued_tran)); }
     if (h->eng.last_tail) {                                           // the score block this launch answered in its tail, for the compute_innerproduct that follows
         std::memcpy(h->tail_r, h->eng.h_tail.p, sizeof(h->tail_r));
         h->tail_fixed = h->fixed.get(); h->tail_moving = h->moving.get(); h->tail_ell = h->ell;
@@ -1307,39 +1366,82 @@ int cvo_destroy(cvo_handle h) {
 
 int cvo_set_pcd(cvo_handle h, const float* xyz, const float* feat, int n) {
     if (!h) return fail(CVO_ERR_INVALID, "null handle");
-    if (!h->init) {                                                  // cvo.cpp:352-360
-        if (!h->fixed) h->fixed.reset(new Cloud());
-        int rc = h->eng.upload(*h->fixed, xyz, feat, n); if (rc) return rc;
-        h->init = true;
-        return CVO_OK;
-    }
-    h->moving.reset(new Cloud());                                    // cvo.cpp:362-366
-    int rc = h->eng.upload(*h->moving, xyz, feat, n); if (rc) return rc;
+    const bool first = !h->init;
+    std::shared_ptr<Cloud>& c = slot_to_fill(h);
+    int rc = h->eng.upload(*c, xyz, feat, n); if (rc) return rc;
+    if (first) { h->init = true; return CVO_OK; }                    // cvo.cpp:352-360
     h->num_fixed = h->fixed ? h->fixed->n : 0; h->num_moving = h->moving->n;   // cvo.cpp:370-371
     h->A_nonzero = 0;                                                // cvo.cpp:385
     return CVO_OK;
 }
 
-int cvo_set_tail_scores(cvo_handle h, int on) { if (!h) return fail(CVO_ERR_INVALID, "null handle"); h->tail_scores = on != 0; if (!on) h->tail_valid = false; return CVO_OK; }
+int cvo_set_tail_scores(cvo_handle h, int on) {
+    if (!h) return fail(CVO_ERR_INVALID, "null handle");
+    if (on < 0 || on > 2) return fail(CVO_ERR_INVALID, "cvo_set_tail_scores: 0 (never), 1 (always) or 2 (when the previous alignment was asked)");
+    h->tail_mode = on; h->asked_after_align = false;
+    if (const char* e = std::getenv("CVO_HIP_HANDLE_TAIL")) h->tail_in_kernel = std::strcmp(e, "kernel") == 0;
+    if (!on) slots_changed(h);
+    return CVO_OK;
+}
 int cvo_set_num_want(cvo_handle h, int num_want) {
     if (!h || num_want <= 0) return fail(CVO_ERR_INVALID, "bad argument");
     h->num_want = num_want; return CVO_OK;
 }
 
+namespace {
+// The frame this thread's last cloud was generated from, byte for byte?  Then `c` becomes a device copy of that cloud (positions + features, selected pixels:
+// 100 KB at 3 k points, queued on the handle's stream) and nothing is generated: 0.22 ms -> the compare of 1.5 MB the staging copy would have read anyway.
+// A different frame differs within the first bytes and costs nothing.
+int take_generated(cvo_handle_s* h, Cloud& c, const unsigned char* bgr8, const unsigned short* depth16, int w, int hh, const cvo_camera& cam, bool* taken) {
+    *taken = false;
+    LastGenerated& g = last_generated();
+    if (!share_generated_clouds() || !g.cloud || !g.stage || g.device != h->eng.device || g.w != w || g.h != hh || g.num_want != h->num_want ||
+        std::memcmp(&g.cam, &cam, sizeof(cam)) != 0 || !bgr8 || !depth16) return CVO_OK;
+    const size_t n = (size_t)w * hh;
+    if (g.stage->stamp.load(std::memory_order_acquire) != g.stamp || g.stage->buf.bytes < 5 * n) return CVO_OK;
+    const unsigned char* st = static_cast<const unsigned char*>(g.stage->buf.p);
+    if (std::memcmp(st, bgr8, 3 * n) != 0 || std::memcmp(st + 3 * n, depth16, 2 * n) != 0) return CVO_OK;
+    if (g.stage->stamp.load(std::memory_order_acquire) != g.stamp) return CVO_OK;
+    const Cloud& src = *g.cloud;
+    HIP_TRY(hipSetDevice(h->eng.device));
+    c.n = src.n; c.n_px = src.n_px; c.cost_hint = src.cost_hint; c.boxes_valid = false; c.raw = nullptr;
+    if (src.n > 0) {
+        int rc = c.buf.ensure((size_t)src.n * REC * sizeof(float)); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c.buf.p, src.buf.p, (size_t)src.n * REC * sizeof(float), hipMemcpyDeviceToDevice, h->eng.stream));
+    }
+    if (src.n_px > 0) {
+        int rc = c.px.ensure((size_t)src.n_px * 2 * sizeof(uint16_t)); if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c.px.p, src.px.p, (size_t)src.n_px * 2 * sizeof(uint16_t), hipMemcpyDeviceToDevice, h->eng.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->eng.stream));                    // complete when the call returns, as a generated cloud is (any stream may read it next)
+    ++h->shared_hits;
+    *taken = true;
+    return CVO_OK;
+}
+}  // namespace
+
 int cvo_set_pcd_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera* cam) {
     if (!h || !cam) return fail(CVO_ERR_INVALID, "null argument");
-    if (!h->init) {                                                  // cvo.cpp:352-360
-        if (!h->fixed) h->fixed.reset(new Cloud());
-        int rc = h->eng.generate_pcd(*h->fixed, bgr8, depth16, width, height, *cam, h->num_want); if (rc) return rc;
-        h->init = true;
-        return CVO_OK;
+    const bool first = !h->init;
+    std::shared_ptr<Cloud>& c = slot_to_fill(h);
+    bool taken = false;
+    int rc = take_generated(h, *c, bgr8, depth16, width, height, *cam, &taken); if (rc) return rc;
+    if (!taken) {
+        LastGenerated& g = last_generated();
+        g.cloud.reset();                                             // (frees the previous frame's cloud unless a handle still holds it)
+        rc = h->eng.generate_pcd(*c, bgr8, depth16, width, height, *cam, h->num_want); if (rc) return rc;
+        if (share_generated_clouds()) {
+            g.stage = h->eng.img_stage; g.stamp = g.stage->stamp.load(std::memory_order_acquire);
+            g.device = h->eng.device; g.w = width; g.h = height; g.num_want = h->num_want; g.cam = *cam; g.cloud = c;
+        }
     }
-    h->moving.reset(new Cloud());                                    // cvo.cpp:362-366
-    int rc = h->eng.generate_pcd(*h->moving, bgr8, depth16, width, height, *cam, h->num_want); if (rc) return rc;
+    if (first) { h->init = true; return CVO_OK; }                    // cvo.cpp:352-360
     h->num_fixed = h->fixed ? h->fixed->n : 0; h->num_moving = h->moving->n;   // cvo.cpp:370-371
     h->A_nonzero = 0;                                                // cvo.cpp:385
     return CVO_OK;
 }
+int cvo_queued_score_count(cvo_handle h, int* count) { if (!h || !count) return fail(CVO_ERR_INVALID, "null argument"); *count = h->queued_hits; return CVO_OK; }
+int cvo_shared_cloud_count(cvo_handle h, int* count) { if (!h || !count) return fail(CVO_ERR_INVALID, "null argument"); *count = h->shared_hits; return CVO_OK; }
 
 int cvo_get_cloud(cvo_handle h, int slot, float* xyz, float* feat, int cap, int* n) {
     if (!h || !n) return fail(CVO_ERR_INVALID, "null argument");
@@ -1476,7 +1578,14 @@ int cvo_compute_innerproduct(cvo_handle h, cvo_inn_p* inn_pre, cvo_inn_p* inn_po
                                     {mv, tran, fx, true, h->ell}};           // cvo.cpp:500
     double r[5][24];
     int rc;
-    if (h->tail_valid && h->tail_fixed == fx && h->tail_moving == mv && h->tail_ell == h->ell && std::memcmp(h->tail_tran, tran, sizeof(h->tail_tran)) == 0) {
+    if (h->eng.launched && std::memcmp(h->transform.m, tran, sizeof(float) * 12) == 0) h->asked_after_align = true;   // the tracker's pattern: the next alignment starts this block itself (mode 2)
+    if (h->queued_valid && h->eng.score_pending == 5) {
+        // queued behind the align kernel for the alignment's own transform and ell (do_align): for exactly that question the answers are on their way or there
+        const bool same = h->queued_fixed == fx && h->queued_moving == mv && h->queued_ell == h->ell && std::memcmp(h->queued_tran, tran, sizeof(h->queued_tran)) == 0;
+        h->queued_valid = false;
+        rc = h->eng.score_collect(5, r); if (rc) return rc;          // (collected either way: the pinned block is free again)
+        if (!same) { rc = h->eng.score_many(rq, 5, r); if (rc) return rc; } else ++h->queued_hits;
+    } else if (h->tail_valid && h->tail_fixed == fx && h->tail_moving == mv && h->tail_ell == h->ell && std::memcmp(h->tail_tran, tran, sizeof(h->tail_tran)) == 0) {
         // answered by the align launch itself; what its workgroups could not answer (PairDesc::score_out[23]) goes to the score kernel now
         std::memcpy(r, h->tail_r, sizeof(r));
         static const int bit_of[5] = {TAIL_PRE, TAIL_POST, TAIL_FIXED, TAIL_MOVING, TAIL_HESSIAN};
@@ -1526,10 +1635,10 @@ int cvo_compute_innerproduct_lc(cvo_handle h, cvo_inn_p* inn_prior, cvo_inn_p* i
     return CVO_OK;
 }
 
-int cvo_update_fixed_pcd(cvo_handle h) { if (!h) return fail(CVO_ERR_INVALID, "null handle"); h->fixed = std::move(h->moving); return CVO_OK; }
+int cvo_update_fixed_pcd(cvo_handle h) { if (!h) return fail(CVO_ERR_INVALID, "null handle"); slots_changed(h); h->fixed = std::move(h->moving); return CVO_OK; }
 int cvo_update_previous_pcd(cvo_handle h) {
     if (!h) return fail(CVO_ERR_INVALID, "null handle");
-    h->previous = std::move(h->moving); h->pre_pc_init = true; return CVO_OK;
+    slots_changed(h); h->previous = std::move(h->moving); h->pre_pc_init = true; return CVO_OK;
 }
 int cvo_reset_transform(cvo_handle h, const float odometry[12]) {
     if (!h || !odometry) return fail(CVO_ERR_INVALID, "null argument");
@@ -1537,6 +1646,7 @@ int cvo_reset_transform(cvo_handle h, const float odometry[12]) {
 }
 int cvo_reset_keyframe(cvo_handle h, const float odometry[12]) {
     if (!h || !odometry) return fail(CVO_ERR_INVALID, "null argument");
+    slots_changed(h);
     if (!h->pre_pc_init) { h->fixed = std::move(h->moving); }
     else { h->fixed = std::move(h->previous); cvo_update_previous_pcd(h); }
     return cvo_reset_transform(h, odometry);

@@ -722,7 +722,10 @@ __device__ __forceinline__ Lds lds_layout(int tgeo, int y_mode) {
 // one pair as seen by workgroup g of its G: the fixed cloud is cut into blocks of ROW_DEAL consecutive rows (scan order:
 // a thin slab of the image, so the cull's boxes stay tight) and the blocks are dealt round-robin (near surfaces have many
 // more neighbours per row than far ones: whole bands of the image per workgroup would be unbalanced)
-constexpr int ROW_DEAL = 128;
+#ifndef CVO_ROW_DEAL
+#define CVO_ROW_DEAL 128
+#endif
+constexpr int ROW_DEAL = CVO_ROW_DEAL;
 struct Ctx {
     const gfloat* fixed; const gfloat* moving;
     int nf, nm, nrows, rows_per, rows_pad, capn, nm_pad, flat_cap, g, G;

@@ -107,17 +107,27 @@ int cvo_align_traced(cvo_handle h, cvo_trace_row* trace, int trace_cap, int* tra
  * and (B,G,R,dx,dy) features (pcd_generator.cpp:456-499, 590-612), written straight into the HBM cloud the
  * alignment reads.  bgr8: height x width x 3 bytes (cv::Mat CV_8UC3, row stride 3*width); depth16: height x
  * width uint16 (0 = invalid); cam = cvo::camera_info (data_type.h:33-39, read from the calib file by the ctor).
- * Same slot semantics as cvo_set_pcd. */
+ * Same slot semantics as cvo_set_pcd.
+ * The tracker hands one frame to two objects (cvo_odometry->match_odometry(frame), cvo_keyframe->match_keyframe(frame), local_tracker.cpp:356, 415) and the
+ * selector is deterministic, so the two MOVING clouds are the same cloud: a handle that is given, on the same host thread and device, byte for byte the images
+ * (and camera, num_want) the thread's previous generation was given takes a device copy of that cloud instead of generating it again (the staged images are kept
+ * for the compare; a different frame differs within its first bytes).  Same bits either way (tests/test_gpu_pcd.py); CVO_HIP_SHARE_CLOUDS=0 generates always.
+ * cvo_shared_cloud_count: how many of this handle's clouds were taken that way. */
 typedef struct cvo_camera { float scaling_factor, fx, fy, cx, cy; } cvo_camera;
 int cvo_set_pcd_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height,
                        const cvo_camera* cam);
-/* pcd_generator::num_want (3000, pcd_generator.cpp:22) for this handle's later cvo_set_pcd_images calls */
+int cvo_shared_cloud_count(cvo_handle h, int* count);
 /* The tracker calls compute_innerproduct(tran = the transform match_* has just returned) behind every alignment (local_tracker.cpp:356-375, 415-431;
- * cvo.cpp:475-503): on = 1 lets the align launch of this handle answer that score block in its tail (as cvo_batch_set_tail_scores does for batches);
- * cvo_compute_innerproduct then returns those answers when it is asked for exactly that transform on the same clouds, and runs the score kernel for any
- * other request.  Same numbers either way (tests/test_gpu_tail_scores.py).  Off by default: for one pair alone on its cooperating workgroups the tail
- * costs more than the score launch it saves. */
+ * cvo.cpp:475-503).  An alignment of this handle can start that score block itself -- the score kernel is queued behind the align kernel with the transform
+ * and ell taken from the pair's device-resident state, cvo_align returns as soon as the alignment is in, and cvo_compute_innerproduct only collects when it is
+ * asked for exactly that transform on the same clouds at the same ell; any other request runs the score kernel as before.  Same numbers either way
+ * (tests/test_gpu_tail_scores.py).  on = 0: never; 1: every alignment; 2 (the default): an alignment does when the handle's PREVIOUS alignment was followed by
+ * exactly that question -- the tracker's two objects from their second frame on, a loop-closure object (cvo_compute_innerproduct_lc) never, and an alignment nobody
+ * scores queues nothing after the first miss.  CVO_HIP_HANDLE_TAIL=kernel: the batches' way instead (the align launch's own tail, cvo_batch_set_tail_scores),
+ * slower for one pair alone on its cooperating workgroups. */
 int cvo_set_tail_scores(cvo_handle h, int on);
+int cvo_queued_score_count(cvo_handle h, int* count);   /* score blocks of this handle that were answered by what an alignment had queued */
+/* pcd_generator::num_want (3000, pcd_generator.cpp:22) for this handle's later cvo_set_pcd_images calls */
 int cvo_set_num_want(cvo_handle h, int num_want);
 /* match_odometry / match_keyframe taking the images, exactly as the reference's signatures do */
 int cvo_match_odometry_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height,

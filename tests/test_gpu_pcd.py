@@ -83,3 +83,49 @@ def test_tracking_from_images_matches_oracle(hiplib, oracle):
     re, te = rot_trans_err(tf_g, true_tf)
     assert re < 5e-3 and te < 2e-2
     g.close()
+
+
+def test_two_handles_given_one_frame_generate_its_cloud_once(hiplib, oracle):
+    """The tracker's pattern (local_tracker.cpp:356, 415): cvo_odometry and cvo_keyframe are handed the same frame.  The second handle takes a device
+    copy of the cloud the first one generated -- identical to the oracle's and to a cloud generated from scratch; a frame that differs in ONE byte (same buffer, changed in
+    place), another num_want or another camera is generated; the copies are independent objects (the first handle moves on, the second keeps its cloud)."""
+    from cvo_slam_amd import synth
+    (fa, da), (fb, db), camt, _ = frames(3, synth.TUM1)
+    want_a, want_b = oracle.pcd_generate(fa, da, camt), oracle.pcd_generate(fb, db, camt)
+    odo, kf = hiplib.Cvo(), hiplib.Cvo()
+    odo.set_pcd_images(fa, da, camt); kf.set_pcd_images(fa, da, camt)                     # FIXED clouds of both objects: one frame
+    assert odo.shared_cloud_count() == 0 and kf.shared_cloud_count() == 1
+    check_cloud(hiplib, odo, 0, want_a); check_cloud(hiplib, kf, 0, want_a)
+    tf_o = odo.match_odometry_images(fb, db, camt); tf_k = kf.match_keyframe_images(fb, db, camt)   # MOVING clouds: one frame again
+    assert odo.shared_cloud_count() == 0 and kf.shared_cloud_count() == 2
+    check_cloud(hiplib, odo, 1, want_b); check_cloud(hiplib, kf, 1, want_b)
+    np.testing.assert_array_equal(tf_o, tf_k)                                               # same clouds, same start: same alignment
+    # the first object moves on (update_fixed_pcd, a new frame); the second one's clouds stay what they were
+    odo.update_fixed_pcd(); odo.match_odometry_images(fa, da, camt)
+    check_cloud(hiplib, kf, 1, want_b); check_cloud(hiplib, kf, 0, want_a); check_cloud(hiplib, odo, 0, want_b); check_cloud(hiplib, odo, 1, want_a)
+    # one byte of the frame changed in place: not the same frame
+    third = hiplib.Cvo()
+    fa2 = fa.copy(); third.set_pcd_images(fa2, da, camt)
+    assert third.shared_cloud_count() == 1                                                   # (fa was the thread's last generated frame: odo's second match)
+    fa2[-1, -1, 2] ^= 1
+    fourth = hiplib.Cvo(); fourth.set_pcd_images(fa2, da, camt)
+    assert fourth.shared_cloud_count() == 0
+    check_cloud(hiplib, fourth, 0, oracle.pcd_generate(fa2, da, camt))
+    da2 = da.copy(); da2[-1, -1] ^= 1
+    fifth = hiplib.Cvo(); fifth.set_pcd_images(fa2, da2, camt)
+    assert fifth.shared_cloud_count() == 0
+    sixth = hiplib.Cvo(); sixth.set_num_want(1000); sixth.set_pcd_images(fa2, da2, camt)
+    assert sixth.shared_cloud_count() == 0
+    check_cloud(hiplib, sixth, 0, oracle.pcd_generate(fa2, da2, camt, num_want=1000))
+    cam2 = list(camt); cam2[1] *= 1.01
+    seventh = hiplib.Cvo(); seventh.set_num_want(1000); seventh.set_pcd_images(fa2, da2, tuple(cam2))
+    assert seventh.shared_cloud_count() == 0
+    eighth = hiplib.Cvo(); eighth.set_num_want(1000); eighth.set_pcd_images(fa2, da2, tuple(cam2))
+    assert eighth.shared_cloud_count() == 1
+    a, b = seventh.get_cloud(0), eighth.get_cloud(0)
+    np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+    # the generator of the shared frame closes first: the copy lives on
+    seventh.close()
+    b2 = eighth.get_cloud(0); np.testing.assert_array_equal(b[0], b2[0])
+    for g in (odo, kf, third, fourth, fifth, sixth, eighth):
+        g.close()

@@ -142,26 +142,83 @@ def test_members_with_different_list_margins_agree_in_the_tail(hiplib, oracle):
 
 
 def test_single_handle_compute_innerproduct_answered_by_the_align_launch(hiplib, oracle):
-    """cvo_set_tail_scores (default on): match_* + compute_innerproduct(tran = the result), the tracker's sequence (local_tracker.cpp:356-375), on ONE handle --
-    the score block comes out of the align launch's tail; against the score-kernel path (tail off) and the oracle, for several workgroup counts; another
-    transform than the result, or a changed ell, must not be answered from the tail."""
+    """cvo_set_tail_scores: match_* + compute_innerproduct(tran = the result), the tracker's sequence (local_tracker.cpp:356-375), on ONE handle -- the score block is
+    started by the alignment itself ("queue": the score kernel queued behind the align kernel, the default; "kernel": the align launch's own tail); against the
+    score-kernel path (off) and the oracle, for several workgroup counts; another transform than the result must not be answered from what was started, nor may
+    answers survive a change of the clouds."""
+    import os
     from cvo_slam_amd import synth
     for seed, n, wgs in ((41, 700, 1), (42, 1500, 2), (43, 2048, 0), (3, 0, 0), (3, 0, 4)):
         p = synth.make_pair(seed) if n == 0 else synth.make_small_pair(1700 + seed, n=n)
         o = oracle.OracleCvo(); o.set_pcd(p.fixed.xyz, p.fixed.feat); rc, _ = o.match(p.moving.xyz, p.moving.feat); assert rc == 0
         rc, want = o.compute_innerproduct(o.get_state()["transform"]); assert rc == 0
         got = {}
-        for tail in (True, False):
-            g = hiplib.Cvo(); g.set_workgroups(wgs); g.set_tail_scores(tail)
+        for tail in ("queue", "kernel", None):
+            g = hiplib.Cvo(); g.set_workgroups(wgs)
+            if tail:
+                os.environ["CVO_HIP_HANDLE_TAIL"] = tail
+            try:
+                g.set_tail_scores(tail is not None)
+            finally:
+                os.environ.pop("CVO_HIP_HANDLE_TAIL", None)
             g.set_pcd(p.fixed.xyz, p.fixed.feat)
             tf = g.match_keyframe(p.moving.xyz, p.moving.feat)
+            if tail == "queue" and seed == 42:      # asked for another transform FIRST: what was queued is dropped, the score kernel answers
+                other = np.array(g.transform, np.float32).copy(); other[0, 3] += 0.01
+                first = g.compute_innerproduct(other)
             got[tail] = g.compute_innerproduct(g.transform)
+            if tail == "queue" and seed == 42:
+                assert first["inn_post"][0] != got[tail]["inn_post"][0]
             if tail:      # not the align's own transform: the score kernel answers, and differently
                 other = np.array(g.transform, np.float32).copy(); other[0, 3] += 0.01
                 sc2 = g.compute_innerproduct(other)
-                assert sc2["inn_post"][0] != got[True]["inn_post"][0]
+                assert sc2["inn_post"][0] != got[tail]["inn_post"][0]
                 again = g.compute_innerproduct(g.transform)
-                assert again["inn_post"] == got[True]["inn_post"] and again["inliers"] == got[True]["inliers"]
+                assert again["inn_post"] == got[tail]["inn_post"] and again["inliers"] == got[tail]["inliers"]
+                # a new MOVING cloud between the alignment and the question: nothing started for the old one may answer
+                q = synth.make_small_pair(900 + seed, n=600)
+                g.match_keyframe(p.moving.xyz, p.moving.feat)
+                tf_old = np.array(g.transform, np.float32).copy()
+                g.set_pcd(q.moving.xyz, q.moving.feat)
+                after = g.compute_innerproduct(tf_old)
+                ref = hiplib.Cvo(); ref.set_workgroups(wgs); ref.set_pcd(p.fixed.xyz, p.fixed.feat); ref.match_keyframe(p.moving.xyz, p.moving.feat); ref.match_keyframe(p.moving.xyz, p.moving.feat)
+                np.testing.assert_array_equal(np.array(ref.transform, np.float32), np.array(g.transform, np.float32))
+                ref.set_pcd(q.moving.xyz, q.moving.feat)
+                want_after = ref.compute_innerproduct(tf_old)
+                assert after["inn_post"] == want_after["inn_post"] and after["inliers"] == want_after["inliers"] and after["inn_pre"] == want_after["inn_pre"]
+                ref.close()
             g.close()
-        _check(got[True], got[False], 1e-6)
-        _check(got[True], want, 1e-5)
+        for tail in ("queue", "kernel"):
+            _check(got[tail], got[None], 1e-6)
+            _check(got[tail], want, 1e-5)
+
+
+def test_a_handle_learns_the_trackers_pattern(hiplib):
+    """cvo_set_tail_scores' default (2): nothing is queued until an alignment has been followed by compute_innerproduct(its transform); from then on every alignment
+    queues the block, until one is not asked.  A tracker's object (asked after every frame) against the same sequence with the mode off: identical numbers; a
+    loop-closure object (compute_innerproduct_lc) never queues."""
+    from cvo_slam_amd import synth
+    p = synth.make_small_pair(2100, n=1500); q = synth.make_small_pair(2101, n=1500)
+    keys = ("inn_pre", "inn_post", "inn_fixed_pcd", "inn_moving_pcd", "inliers", "cos_angle")
+    auto, off = hiplib.Cvo(), hiplib.Cvo(); off.set_tail_scores(0)
+    seen = []
+    for g in (auto, off):
+        g.set_pcd(p.fixed.xyz, p.fixed.feat)
+        out = []
+        for frame in range(5):
+            mv = (p if frame % 2 == 0 else q).moving
+            g.match_odometry(mv.xyz, mv.feat)
+            if frame != 3:                                   # frame 3 is not asked: frame 4 queues nothing, frame 4's question teaches it again
+                sc = g.compute_innerproduct(np.asarray(g.transform, np.float32))
+                out.append([sc[k] for k in keys] + [sc["post_hessian"].tolist()])
+        seen.append(out)
+    assert seen[0] == seen[1]
+    assert off.queued_score_count() == 0
+    assert auto.queued_score_count() == 2                    # frames 1 and 2 (frame 0: nothing learned yet; frame 3 queued but was not asked; frame 4: not queued)
+    auto.close(); off.close()
+    lc = hiplib.Cvo(); lc.set_pcd(p.fixed.xyz, p.fixed.feat)
+    eye = np.eye(3, 4, dtype=np.float32)
+    for frame in range(3):
+        lc.match_keyframe(p.moving.xyz, p.moving.feat); lc.compute_innerproduct_lc(eye, eye, eye, np.asarray(lc.transform, np.float32))
+    assert lc.queued_score_count() == 0
+    lc.close()
