@@ -159,6 +159,31 @@ struct LastGenerated {          // per host thread: the handles of one thread ar
 LastGenerated& last_generated() { static thread_local LastGenerated g; return g; }
 bool share_generated_clouds() { static const bool on = [] { const char* e = std::getenv("CVO_HIP_SHARE_CLOUDS"); return !e || std::atoi(e) != 0; }(); return on; }
 
+// The hand-over's copy into the pinned ring: 12.6 MB per 64-pair step that the host never reads again.  Ordinary stores pull every destination line into the cache first
+// (read-for-ownership) and push the caller's data out of it; non-temporal 16-byte stores write the lines straight through (CVO_HIP_UPLOAD_NT=1; off by default: measured, no difference).
+inline void ring_copy(void* dst, const void* src, size_t bytes, bool nt) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    if (nt && bytes >= 4096) {
+        typedef long long v2di __attribute__((vector_size(16)));
+        unsigned char* d = static_cast<unsigned char*>(dst); const unsigned char* s = static_cast<const unsigned char*>(src);
+        const size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+        if (head) { std::memcpy(d, s, head); d += head; s += head; bytes -= head; }
+        const size_t body = bytes & ~(size_t)63;
+        for (size_t o = 0; o < body; o += 64) {
+            v2di a, b, c, e;
+            std::memcpy(&a, s + o, 16); std::memcpy(&b, s + o + 16, 16); std::memcpy(&c, s + o + 32, 16); std::memcpy(&e, s + o + 48, 16);
+            __builtin_nontemporal_store(a, reinterpret_cast<v2di*>(d + o)); __builtin_nontemporal_store(b, reinterpret_cast<v2di*>(d + o + 16));
+            __builtin_nontemporal_store(c, reinterpret_cast<v2di*>(d + o + 32)); __builtin_nontemporal_store(e, reinterpret_cast<v2di*>(d + o + 48));
+        }
+        if (bytes > body) std::memcpy(d + body, s + body, bytes - body);
+        asm volatile("sfence" ::: "memory");
+        return;
+    }
+#endif
+    (void)nt;
+    std::memcpy(dst, src, bytes);
+}
+
 // Copy threads of the hand-over (Engine::upload_many: a batch's host arrays into the pinned ring, 12.6 MB per 64-pair step).  They live as long as the process:
 // starting three threads per hand-over cost 0.1 ms of the host's 0.5 per step, and a step's launch is resubmitted that much later (profiles/r04_upload_pool.txt).
 class CopyPool {
@@ -381,6 +406,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_RING_MIRROR")) ring_mirror = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_UPLOAD_THREADS")) upload_threads = std::max(1, std::min(16, std::atoi(e)));
         upload_threads = std::max(1, std::min(upload_threads, (int)std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("CVO_HIP_UPLOAD_NT")) upload_nt = std::atoi(e) != 0;
         return CVO_OK;
     }
     void destroy() {
@@ -406,6 +432,7 @@ struct Engine {
     struct UploadItem { Cloud* c; const float* xyz; const float* feat; int n; };
     DevBuf d_raw;
     int upload_threads = 8;
+    bool upload_nt = false;          // measured: no difference in the hand-over loop (profiles/r04_upload_nt_ab.txt) -- the host copy is not what that loop waits for
     bool upload_copy = true;
     bool defer_pack = false;          // batches (cvo_batch_create)
     bool order_pairs = true;          // CVO_HIP_ORDER_PAIRS=0: positions take the pairs in index order
@@ -420,7 +447,14 @@ struct Engine {
     hipEvent_t ev_ring = nullptr;     // recorded behind the last mirror copy
     std::vector<Cloud*> pending;      // clouds with a hand-over not packed yet (Cloud::raw)
     PinBuf h_packdesc, h_rawtab;
-    hipStream_t packdesc_stream = nullptr, ring_reader = nullptr;
+    hipStream_t packdesc_stream = nullptr;
+    std::vector<hipStream_t> ring_readers;   // every stream with work queued that reads the staging ring (pack kernels, launches that pull raw clouds): all of them before the ring is written over
+    void add_ring_reader(hipStream_t s) { if (std::find(ring_readers.begin(), ring_readers.end(), s) == ring_readers.end()) ring_readers.push_back(s); }
+    int sync_ring_readers() {
+        for (hipStream_t r : ring_readers) if (r != stream) HIP_TRY(hipStreamSynchronize(r));
+        ring_readers.clear();
+        return CVO_OK;
+    }
     // pack kernel over every pending cloud, on stream s (zero-copy from the ring)
     int flush_pending(hipStream_t s) {
         if (pending.empty()) return CVO_OK;
@@ -438,7 +472,7 @@ struct Engine {
         if (q == 0) return CVO_OK;
         const hipError_t e = launch_pack_clouds(base, pd, q, n_max, s);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("cloud pack kernel launch: ") + hipGetErrorString(e));
-        packdesc_stream = s; ring_reader = s;
+        packdesc_stream = s; add_ring_reader(s);
         return CVO_OK;
     }
     // before the ring is written over: nothing may still have to read it
@@ -447,9 +481,7 @@ struct Engine {
         if (launched && last_stream && last_stream != stream) HIP_TRY(hipStreamSynchronize(last_stream));
         int rc = flush_pending(stream); if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(stream));
-        if (ring_reader && ring_reader != stream) HIP_TRY(hipStreamSynchronize(ring_reader));
-        ring_reader = nullptr;
-        return CVO_OK;
+        return sync_ring_readers();
     }
     int upload_many(const UploadItem* it, int count) {
         HIP_TRY(hipSetDevice(device));
@@ -499,7 +531,8 @@ struct Engine {
             off += (size_t)n * REC;
         }
         const int nthreads = bytes >= ((size_t)2 << 20) ? std::max(1, std::min(upload_threads, (int)pieces.size())) : 1;
-        auto copy_range = [&pieces](size_t a, size_t b) { for (size_t i = a; i < b; ++i) std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); };
+        const bool nt = upload_nt && defer_pack;                     // (a single object's block is copied on by the DMA engine right away: let it come from the cache)
+        auto copy_range = [&pieces, nt](size_t a, size_t b) { for (size_t i = a; i < b; ++i) ring_copy(pieces[i].dst, pieces[i].src, pieces[i].bytes, nt); };
         if (nthreads == 1) copy_range(0, pieces.size());
         else {                                                        // in 4 x nthreads parts, taken by the pool's threads and the caller as they come free
             const int parts = std::min((int)pieces.size(), 4 * nthreads);
@@ -513,7 +546,7 @@ struct Engine {
         // clouds first (a score block, a cooperative launch) runs the pack kernel on them (flush_pending).
         if (defer_pack) {
             if (ring_mirror && inkernel_pack) {
-                if (d_ring.bytes < h_stage.bytes) { HIP_TRY(hipStreamSynchronize(stream)); if (ring_reader && ring_reader != stream) HIP_TRY(hipStreamSynchronize(ring_reader)); rc = d_ring.ensure(h_stage.bytes); if (rc) return rc; }
+                if (d_ring.bytes < h_stage.bytes) { HIP_TRY(hipStreamSynchronize(stream)); for (hipStream_t r : ring_readers) if (r != stream) HIP_TRY(hipStreamSynchronize(r)); rc = d_ring.ensure(h_stage.bytes); if (rc) return rc; }
                 HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(d_ring.p) + (blk - static_cast<unsigned char*>(h_stage.p)), blk, bytes, hipMemcpyHostToDevice, stream));
                 if (!ev_ring) HIP_TRY(hipEventCreateWithFlags(&ev_ring, hipEventDisableTiming));
                 HIP_TRY(hipEventRecord(ev_ring, stream));
@@ -947,7 +980,7 @@ struct Engine {
         if (rawtab) {                                                 // those clouds are the kernel's now; the ring has to stay as it is until the launch is over
             for (int i = 0; i < n; ++i) { if (pairs[i].fixed) pairs[i].fixed->raw = nullptr; if (pairs[i].moving) pairs[i].moving->raw = nullptr; }
             pending.erase(std::remove_if(pending.begin(), pending.end(), [](Cloud* c) { return c->raw == nullptr; }), pending.end());
-            ring_reader = s;
+            add_ring_reader(s);
         }
         return CVO_OK;
     }

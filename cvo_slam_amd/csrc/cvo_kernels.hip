@@ -2012,7 +2012,9 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
     // own lanes wrote them; the next workgroup barrier is the epilogue's
     block_reduce<4, 4, false>(acc4, sh, tid, nwaves);
 #ifdef CVO_KTRACE
+#ifndef CVO_KTRACE_EPI
     if (tid == 0) { sh->ksub[0] = kt1 - kt0; sh->ksub[1] = CVO_NOW() - kt1; }
+#endif
 #endif
     if (G > 1) {
         if (tid < 64) { if (!group_exchange<4>(sh, c.xch, G, g, sh->launch_tag | (2u * (unsigned)k + 2u), lane)) sh->status = 6; }
@@ -2066,7 +2068,13 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         for (int q = 0; q < 3; ++q) { omega[q] = sh->omega[q]; v[q] = sh->v[q]; }
         ell = sh->ell;
         const float c3 = (float)(4.0 * float(E)), c2 = (float)(3.0 * float(Dd)), c1 = (float)(2.0 * float(C)), c0 = float(B);   // cvo.cpp:318
+#ifdef CVO_KTRACE_EPI
+        const unsigned long long kq0 = CVO_NOW();
+#endif
         step = cubic_step(c3, c2, c1, c0, P.min_step);
+#ifdef CVO_KTRACE_EPI
+        __builtin_amdgcn_sched_barrier(0); sh->ksub[0] = CVO_NOW() - kq0 + (step == 12345.f ? 1 : 0);
+#endif
         stop_a = norm3f(omega) < P.eps && norm3f(v) < P.eps;                            // cvo.cpp:782
         if (!stop_a) {
             float R[9], T[3], RdT[3], Rn[9];
@@ -2079,9 +2087,15 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
             for (int i = 0; i < 9; ++i) sh->R[i] = Rn[i];                                // cvo.cpp:801
         }
         sh->stop = 0;
+#ifdef CVO_KTRACE_EPI
+        __builtin_amdgcn_sched_barrier(0); sh->ksub[1] = CVO_NOW() - kq0 - sh->ksub[0];
+#endif
     }
     __syncthreads();                                                 // R, T are out
     if (threadIdx.x == 0) {
+#ifdef CVO_KTRACE_EPI
+        const unsigned long long kq2 = CVO_NOW();
+#endif
         const DevParams& P = sh->P;
         float dist = -1.f;
         int stop = 0;
@@ -2112,6 +2126,9 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
             tr.step = step; tr.ell = ell; tr.dist = dist; tr.pad_ = 0;
             *c.trace_len = k + 1;
         }
+#ifdef CVO_KTRACE_EPI
+        __builtin_amdgcn_sched_barrier(0); sh->ksub[2] = CVO_NOW() - kq2 + (dist == 12345.f ? 1 : 0);
+#endif
     }
 #ifdef CVO_KTRACE
     const unsigned long long ke1 = CVO_NOW();
@@ -2127,7 +2144,11 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         }
     }
 #ifdef CVO_KTRACE
+#ifdef CVO_KTRACE_EPI
+    if (threadIdx.x == 0) sh->ksub[3] = CVO_NOW() - ke0;
+#else
     if (threadIdx.x == 0) { sh->ksub[2] = ke1 - ke0; sh->ksub[3] = CVO_NOW() - ke1; }
+#endif
 #endif
 }
 
