@@ -962,6 +962,9 @@ struct Engine {
         // get shorter and the pairs cull 2.0-2.3 times instead of 3.3-3.8: +10 % at 3 k points, +6 % at 9 k (profiles/r04_list_margin_sweep.txt; other motion mixes: r04_list_margin_motion.txt)
         if (skin_auto && alpha_auto) { Pl.skin = y_mode == 1 ? 0.05f : 0.15f; Pl.skin_alpha = y_mode == 1 ? 0.0125f : 0.01f; if (!gamma_set) Pl.alpha_gamma = y_mode == 1 ? 1.0f : 0.f; }
         else if (skin_auto) Pl.skin = y_mode == 1 ? 0.35f : 0.30f;   // CVO_HIP_SKIN_ALPHA given alone: the constant part as round 3 had it
+        // (Wider FIRST lists for pairs on four or more cooperating workgroups -- few rows per workgroup, a cull costs what it always did -- were measured: 1.75 x the margin takes 2.2 %
+        // off the bench's pairs (0.1-0.2 m between the frames), which then cull once instead of twice, and ADDS 5 % to a tracker frame's alignments (consecutive frames: one cull
+        // either way, the wider lists only cost): not taken, profiles/r04_single_pair_phases.txt.  CVO_HIP_FIRST_SCALE sets it for every launch.)
         Pl.adopt_on = ac ? 1 : 0;
         if (qc) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
             std::lock_guard<std::mutex> lk(adopt_submit_mutex());
