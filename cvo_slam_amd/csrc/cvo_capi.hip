@@ -386,7 +386,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_SKIN_ALPHA")) { P.skin_alpha = std::max(0.f, std::min(0.2f, (float)std::atof(e))); alpha_auto = false; }
         if (const char* e = std::getenv("CVO_HIP_ALPHA_GAMMA")) { P.alpha_gamma = std::max(0.f, std::min(4.f, (float)std::atof(e))); gamma_set = true; }
         if (const char* e = std::getenv("CVO_HIP_FUSE_REFINE")) P.fuse_refine = std::atoi(e) != 0;
-        if (const char* e = std::getenv("CVO_HIP_FIRST_SCALE")) P.first_scale = std::max(0.f, std::min(16.f, (float)std::atof(e)));
+        if (const char* e = std::getenv("CVO_HIP_FIRST_SCALE")) { P.first_scale = std::max(0.f, std::min(16.f, (float)std::atof(e))); first_scale_set = true; }
         if (const char* e = std::getenv("CVO_HIP_PREDICT")) P.predict = std::max(0.f, std::min(0.99f, (float)std::atof(e)));
         if (const char* e = std::getenv("CVO_HIP_PREDICT_STEPS")) P.predict_steps = std::max(0.f, (float)std::atof(e));
         if (const char* e = std::getenv("CVO_HIP_OVERLAP_STOP")) P.overlap_stop_test = std::atoi(e) != 0;
@@ -431,6 +431,7 @@ struct Engine {
     // is only waited for when it wraps.  Large hand-overs (a batch of 64 pairs = 12.6 MB) are copied into the ring by a few threads.
     struct UploadItem { Cloud* c; const float* xyz; const float* feat; int n; };
     DevBuf d_raw;
+    bool first_scale_set = false; float coop_first_scale = 0.f;   // (cvo_batch_create sets the latter)
     int upload_threads = 8;
     bool upload_nt = false;          // measured: no difference in the hand-over loop (profiles/r04_upload_nt_ab.txt) -- the host copy is not what that loop waits for
     bool upload_copy = true;
@@ -962,9 +963,11 @@ struct Engine {
         // get shorter and the pairs cull 2.0-2.3 times instead of 3.3-3.8: +10 % at 3 k points, +6 % at 9 k (profiles/r04_list_margin_sweep.txt; other motion mixes: r04_list_margin_motion.txt)
         if (skin_auto && alpha_auto) { Pl.skin = y_mode == 1 ? 0.05f : 0.15f; Pl.skin_alpha = y_mode == 1 ? 0.0125f : 0.01f; if (!gamma_set) Pl.alpha_gamma = y_mode == 1 ? 1.0f : 0.f; }
         else if (skin_auto) Pl.skin = y_mode == 1 ? 0.35f : 0.30f;   // CVO_HIP_SKIN_ALPHA given alone: the constant part as round 3 had it
-        // (Wider FIRST lists for pairs on four or more cooperating workgroups -- few rows per workgroup, a cull costs what it always did -- were measured: 1.75 x the margin takes 2.2 %
-        // off the bench's pairs (0.1-0.2 m between the frames), which then cull once instead of twice, and ADDS 5 % to a tracker frame's alignments (consecutive frames: one cull
-        // either way, the wider lists only cost): not taken, profiles/r04_single_pair_phases.txt.  CVO_HIP_FIRST_SCALE sets it for every launch.)
+        // Wider FIRST lists for the pairs of a BATCH on four or more cooperating workgroups each (a handful of loop-closure candidates, keyframe_graph.cpp:693-717: few rows per
+        // workgroup, a cull costs what it always did, and the frames are far apart): 1.75 x the margin, most pairs then cull once instead of twice -- 10 candidates 2.53 -> 2.35 ms, one
+        // of the bench's pairs alone -2.2 %.  Not for single handles: a tracker's consecutive frames cull once either way and the wider lists ADD 5 % to their alignments
+        // (profiles/r04_single_pair_phases.txt).  CVO_HIP_FIRST_SCALE sets it for every launch.
+        if (coop_first_scale > 0.f && !first_scale_set && G >= 4 && y_mode == 1) Pl.first_scale = coop_first_scale;
         Pl.adopt_on = ac ? 1 : 0;
         if (qc) {                                                     // count the workgroups as submitted, then submit them: in that order, under one lock per process
             std::lock_guard<std::mutex> lk(adopt_submit_mutex());
@@ -1833,6 +1836,7 @@ int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* 
     b->max_pairs = max_pairs;
     b->eng.defer_pack = true;                                       // hand-overs are packed by the next align launch (Engine::upload_many)
     b->eng.rec_hint = max_pairs + 1;                                // room for the padding record of an uneven shard (cvo_shard_range)
+    b->eng.coop_first_scale = 1.75f;                                // few pairs on many workgroups each = loop-closure candidates: wider first lists (launch_impl)
     b->fixed.resize(max_pairs); b->moving.resize(max_pairs);
     b->init_states.resize(max_pairs);
     for (auto& s : b->init_states) fresh_state(s, b->prm.ell);
