@@ -55,18 +55,25 @@ def test_full_size_tracker_sequence_from_images_vs_oracle(hiplib, oracle):
     cam = synth.camera_tuple(synth.TUM1)
 
     odo, kf = hiplib.Cvo(), hiplib.Cvo()
-    got = []
+    got, scores = [], []
     odo.set_pcd_images(*frames[0], cam); kf.set_pcd_images(*frames[0], cam)          # :228, :231
     t = odo.match_odometry_images(*frames[1], cam); got.append((t, odo.get_iteration_number()))   # :233
+    scores.append(odo.compute_innerproduct(np.asarray(t, np.float32)))               # :251
     odo.update_fixed_pcd()                                                           # :277
     kf.first_frame = False; kf.reset_transform(np.asarray(t, np.float32))            # :330-333
     for f in frames[2:]:
         t = odo.match_odometry_images(*f, cam); got.append((t, odo.get_iteration_number()))       # :356
+        scores.append(odo.compute_innerproduct(np.asarray(t, np.float32)))           # :375
         odo.update_fixed_pcd()                                                       # :403
         kf.reset_initial(np.asarray(t, np.float32))                                  # :407
         tk = kf.match_keyframe_images(*f, cam); got.append((tk, kf.get_iteration_number()))       # :415
+        scores.append(kf.compute_innerproduct(np.asarray(tk, np.float32)))           # :431
         kf.update_previous_pcd()                                                     # :506
     n_pts = odo.get_fixed_and_moving_number()
+    # the economies of the tracker's pattern were taken: the keyframe object generated none of its clouds (frames 0, 2, 3, 4 came from the odometry object's generation) and both
+    # objects' score blocks were started by their alignments from the second one on
+    assert kf.shared_cloud_count() == 4 and odo.shared_cloud_count() == 0
+    assert odo.queued_score_count() == 3 and kf.queued_score_count() == 2
     odo.close(); kf.close()
 
     clouds = [oracle.pcd_generate(b, d, cam) for (b, d) in frames]
@@ -74,15 +81,24 @@ def test_full_size_tracker_sequence_from_images_vs_oracle(hiplib, oracle):
     oo, ok = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8), oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8)
     want = []
     c = clouds[0]; oo.set_pcd(c["xyz"], c["feat"]); ok.set_pcd(c["xyz"], c["feat"])
+    want_scores = []
     c = clouds[1]; rc, t = oo.match(c["xyz"], c["feat"]); assert rc == 0; want.append((t, oo.get_state()["iter"]))
+    rc, sc = oo.compute_innerproduct(oo.get_state()["transform"]); assert rc == 0; want_scores.append(sc)
     oo.update_fixed_pcd(); ok.reset_transform(t.astype(np.float32))
     for c in clouds[2:]:
         rc, t = oo.match(c["xyz"], c["feat"]); assert rc == 0; want.append((t, oo.get_state()["iter"]))
+        rc, sc = oo.compute_innerproduct(oo.get_state()["transform"]); assert rc == 0; want_scores.append(sc)
         oo.update_fixed_pcd()
         ok.reset_initial(t.astype(np.float32))
         rc, tk = ok.match(c["xyz"], c["feat"]); assert rc == 0; want.append((tk, ok.get_state()["iter"]))
+        rc, sc = ok.compute_innerproduct(ok.get_state()["transform"]); assert rc == 0; want_scores.append(sc)
         ok.update_previous_pcd()
-    assert len(got) == len(want) == 7
+    assert len(got) == len(want) == 7 and len(scores) == len(want_scores) == 7
+    for k, (g, w) in enumerate(zip(scores, want_scores)):
+        for key in ("inn_pre", "inn_post", "inn_fixed_pcd", "inn_moving_pcd"):
+            assert g[key][1] == w[key][1], (k, key)
+            assert g[key][0] == pytest.approx(w[key][0], rel=1e-5), (k, key)
+        assert g["inliers"] == w["inliers"], k
     for k, ((tg, ig), (tw, iw)) in enumerate(zip(got, want)):
         re, te = rot_trans_err(tg, tw)
         assert re <= 1e-4 and te <= 1e-4, (k, re, te)
