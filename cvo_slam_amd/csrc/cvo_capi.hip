@@ -624,15 +624,17 @@ struct Engine {
             pattern_len = (int)n;
         }
         unsigned char* st = static_cast<unsigned char*>(img_stage->buf.p);
-        std::memcpy(st, bgr8, 3 * n); std::memcpy(st + 3 * n, depth16, 2 * n);
+        // the colour image first: its copy and the gradient / threshold kernels (which need nothing else) run while the host stages the depth image
+        std::memcpy(st, bgr8, 3 * n);
         HIP_TRY(hipMemcpyAsync(d_bgr.p, st, 3 * n, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(d_depth.p, st + 3 * n, 2 * n, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemsetAsync(d_ths.p, 0, sizeof(float) * nths, stream));
         HIP_TRY(hipMemsetAsync(d_thsS.p, 0, sizeof(float) * nths, stream));
         float* I0 = (float*)d_I0.p; float* dx0 = (float*)d_dx0.p; float* dy0 = (float*)d_dy0.p; float* abs0 = (float*)d_abs0.p;
         hipError_t e = pcd_launch_pyramid((const uint8_t*)d_bgr.p, w, h, I0, (float*)d_I1.p, (float*)d_I2.p, dx0, dy0, abs0, (float*)d_abs1.p, (float*)d_abs2.p, stream);
         if (e == hipSuccess) e = pcd_launch_thresholds(abs0, w, h, (float*)d_ths.p, (float*)d_thsS.p, stream);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd kernels: ") + hipGetErrorString(e));
+        std::memcpy(st + 3 * n, depth16, 2 * n);
+        HIP_TRY(hipMemcpyAsync(d_depth.p, st + 3 * n, 2 * n, hipMemcpyHostToDevice, stream));
         // PixelSelector::makeMaps (PixelSelector2.cpp:136-282), a fresh selector per frame: potential 3, one re-selection allowed
         int pot = 3, recursions_left = 1, ideal = 3;
         float num_have = 0, quotia = 0;
