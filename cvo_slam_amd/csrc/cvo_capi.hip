@@ -316,6 +316,7 @@ struct Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevParams P;
     bool wide_waves = true;          // CVO_HIP_WIDE=0: plane-layout launches run the two-waves-per-SIMD build as well
+    bool wide_all = false;           // CVO_HIP_WIDE=2: the float4 layout runs the three-waves-per-SIMD build too (measured again in round 4: profiles/r04_three_waves_tum.txt)
     bool gamma_set = false;          // CVO_HIP_ALPHA_GAMMA given: else the depth-proportional margin falls with ell (gamma 1) in the float4 layout: +1 % (profiles/r04_list_margin_gamma.txt)
     bool alpha_auto = true;          // ... and its depth-proportional part (CVO_HIP_SKIN_ALPHA fixes it; CVO_HIP_SKIN alone = one margin for all rows, alpha 0)
     bool skin_auto = true;           // the list radius margin follows the layout: 0.35 with the cloud resident as 16-byte points (3 k-point shape), 0.30 otherwise -- measured with
@@ -393,7 +394,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_NT_MIN")) P.nt_min = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("CVO_HIP_RESORT")) P.resort = std::max(0, std::min(2, std::atoi(e)));
         if (const char* e = std::getenv("CVO_HIP_COLOCATE")) P.colocate = std::atoi(e) != 0;
-        if (const char* e = std::getenv("CVO_HIP_WIDE")) wide_waves = std::atoi(e) != 0;
+        if (const char* e = std::getenv("CVO_HIP_WIDE")) { wide_waves = std::atoi(e) != 0; wide_all = std::atoi(e) >= 2; }
         if (const char* e = std::getenv("CVO_HIP_ADOPT_KMAX")) P.adopt_kmax = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("CVO_HIP_ADOPT_INJECT")) P.adopt_inject = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_ADOPT")) adopt = std::atoi(e) != 0;
@@ -783,9 +784,9 @@ struct Engine {
         const KSet* K = &KS2;
         Plan pl = plan(KS2);
         if (pl.err) return fail(CVO_ERR_INVALID, "CVO_HIP_Y_MODE: the requested LDS layout does not fit");
-        if (pl.y_mode == 2 && wide_waves && per_cu == 1) {
+        if ((pl.y_mode == 2 || (wide_all && pl.y_mode == 1)) && wide_waves && per_cu == 1) {
             const Plan p3 = plan(KS3);
-            if (!p3.err && p3.y_mode == 2) { pl = p3; K = &KS3; }
+            if (!p3.err && p3.y_mode == pl.y_mode) { pl = p3; K = &KS3; }
         }
         const int y_mode = pl.y_mode, tile = pl.tile, tab_cols = pl.tab_cols, block = pl.block, rows_per = rows_per_w;
 
