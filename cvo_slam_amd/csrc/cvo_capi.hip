@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -597,6 +598,9 @@ struct Engine {
     }
     int generate_pcd(Cloud& c, const unsigned char* bgr8, const unsigned short* depth16, int w, int h, const cvo_camera& cam, int num_want) {
         HIP_TRY(hipSetDevice(device));
+        static const bool timing = std::getenv("CVO_HIP_PCD_TIMING") != nullptr;   // development aid: where a generation's host time goes (stderr)
+        const auto tq0 = std::chrono::steady_clock::now(); auto tq = tq0; double tms[6] = {0, 0, 0, 0, 0, 0}; int tqi = 0;
+        auto lap = [&]() { if (timing && tqi < 6) { const auto now = std::chrono::steady_clock::now(); tms[tqi++] = std::chrono::duration<double, std::micro>(now - tq).count(); tq = now; } };
         if (!bgr8 || !depth16) return fail(CVO_ERR_INVALID, "null image pointer");
         if (w < 64 || h < 64 || (size_t)w * h > (size_t)1 << 26) return fail(CVO_ERR_INVALID, "image size out of range");
         if (num_want <= 0) return fail(CVO_ERR_INVALID, "num_want must be positive");
@@ -634,8 +638,10 @@ struct Engine {
         hipError_t e = pcd_launch_pyramid((const uint8_t*)d_bgr.p, w, h, I0, (float*)d_I1.p, (float*)d_I2.p, dx0, dy0, abs0, (float*)d_abs1.p, (float*)d_abs2.p, stream);
         if (e == hipSuccess) e = pcd_launch_thresholds(abs0, w, h, (float*)d_ths.p, (float*)d_thsS.p, stream);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd kernels: ") + hipGetErrorString(e));
+        lap();                                                          // [0] buffers, colour staging + copy + kernels queued
         std::memcpy(st + 3 * n, depth16, 2 * n);
         HIP_TRY(hipMemcpyAsync(d_depth.p, st + 3 * n, 2 * n, hipMemcpyHostToDevice, stream));
+        lap();                                                          // [1] depth staging + copy queued
         // PixelSelector::makeMaps (PixelSelector2.cpp:136-282), a fresh selector per frame: potential 3, one re-selection allowed
         int pot = 3, recursions_left = 1, ideal = 3;
         float num_have = 0, quotia = 0;
@@ -648,6 +654,7 @@ struct Engine {
             if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd select: ") + hipGetErrorString(e));
             HIP_TRY(hipMemcpyAsync(hc, d_counts.p, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            lap();                                                      // [2] (and [3] after a re-selection) everything up to the selection's counts
             num_have = (float)(hc[0] + hc[1] + hc[2]);                  // :191
             quotia = num_want_f / num_have;                             // :192
             const float K = num_have * (pot + 1) * (pot + 1);           // :195
@@ -674,6 +681,7 @@ struct Engine {
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd sub-sampling: ") + hipGetErrorString(e));
         HIP_TRY(hipMemcpyAsync(hc, d_tiles.p, sizeof(int) * 3 * (size_t)nt, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        lap();                                                          // sub-sampling + tile counts
         int npts = 0;
         for (int t = 0; t < nt; ++t) npts += hc[nt + t];                 // kept pixels with a valid depth = points (pcd_generator.cpp:471)
         if (npts > 65535) return fail(CVO_ERR_INVALID, "more than 65535 points per cloud is not supported (16-bit column indices)");
@@ -685,6 +693,9 @@ struct Engine {
                              (uint16_t*)c.px.p, stream);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd cloud: ") + hipGetErrorString(e));
         HIP_TRY(hipStreamSynchronize(stream));
+        lap();                                                          // the cloud itself
+        if (timing) std::fprintf(stderr, "[cvo_hip] generate_pcd laps (us): %.0f %.0f %.0f %.0f %.0f %.0f, total %.0f\n", tms[0], tms[1], tms[2], tms[3], tms[4], tms[5],
+                                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count());
         return CVO_OK;
     }
 
