@@ -88,7 +88,7 @@ ABI_SYMBOLS = [
     "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds", "cvo_batch_compute_innerproduct_lc",
     "cvo_set_pcd_images", "cvo_shared_cloud_count", "cvo_queued_score_count", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
-    "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3",
+    "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3", "cvo_selftest_libm", "cvo_selftest_pair_values",
     "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups", "cvo_batch_set_adoption", "cvo_batch_last_adoptions", "cvo_batch_last_adoption_retractions",
     "cvo_adaptive_default_params", "cvo_adaptive_align",
     "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_comm_info", "cvo_batch_gather_results",
@@ -182,8 +182,9 @@ def load_library():
     L.cvo_batch_enqueue_innerproduct.argtypes = [vp, C.c_int]
     L.cvo_batch_innerproduct_results.argtypes = [vp, C.c_int, C.POINTER(TrackScores)]
     L.cvo_batch_compute_innerproduct.argtypes = [vp, C.c_int, C.POINTER(TrackScores)]
-    for name in ("cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3"):
+    for name in ("cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3", "cvo_selftest_libm"):
         getattr(L, name).argtypes = [C.c_int, C.c_int, fp, fp]
+    L.cvo_selftest_pair_values.argtypes = [C.c_int, C.POINTER(Params), C.c_float, C.c_int, fp, fp, fp]
     L.cvo_function_inner_product_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, C.POINTER(InnP)]
     L.cvo_se3_hessian_clouds.argtypes = [vp, fp, fp, C.c_int, fp, fp, C.c_int, dp, ip]
     L.cvo_batch_set_max_workgroups.argtypes = [vp, C.c_int]
@@ -269,6 +270,24 @@ def selftest_dist_se3(dR_dT, device: int = 0):
     fp = C.POINTER(C.c_float)
     _check(load_library().cvo_selftest_dist_se3(device, a.shape[0], a.ctypes.data_as(fp), out.ctypes.data_as(fp)))
     return out
+
+
+def selftest_libm(x, device: int = 0):
+    """The device's float routines element by element: (n, 5) = OCML sinf, cosf, logf, then the correctly rounded sine and cosine of exp_sek3."""
+    a = np.ascontiguousarray(x, np.float32).reshape(-1); out = np.zeros((a.shape[0], 5), np.float32)
+    fp = C.POINTER(C.c_float)
+    _check(load_library().cvo_selftest_libm(device, a.shape[0], a.ctypes.data_as(fp), out.ctypes.data_as(fp)))
+    return out
+
+
+def selftest_pair_values(y_g, ell: float, params: "Params | None" = None, device: int = 0):
+    """The pair arithmetic of se_kernel (cvo.cpp:166-175) on the device by the align kernel's four routes, for n x {y[3], g[5]} against a fixed
+    point at the origin with zero features: (a (n, 4), d2 (n,), d2c (n,))."""
+    a = np.ascontiguousarray(y_g, np.float32).reshape(-1, 8); out = np.zeros((a.shape[0], 4), np.float32); aux = np.zeros((a.shape[0], 2), np.float32)
+    fp = C.POINTER(C.c_float)
+    _check(load_library().cvo_selftest_pair_values(device, C.byref(params) if params is not None else None, float(ell), a.shape[0], a.ctypes.data_as(fp),
+                                                   out.ctypes.data_as(fp), aux.ctypes.data_as(fp)))
+    return out, aux[:, 0], aux[:, 1]
 
 
 def _check(rc: int):

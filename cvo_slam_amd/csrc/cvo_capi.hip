@@ -70,6 +70,7 @@ hipError_t launch_cloud_boxes(const float* rec, int n, float* gbox, hipStream_t 
 hipError_t launch_adaptive(const AdaptiveArgs& A, int iterations, hipStream_t stream);
 int adaptive_partial_records(int nf, int nm);
 hipError_t launch_selftest(int kind, const float* in, float* out, int n, hipStream_t s);
+hipError_t launch_selftest_pairs(const float* in, float* out, float* aux, int n, float ell, const DevParams& P, hipStream_t s);
 hipError_t launch_score(const ScoreBatch& B, const ScoreDesc* more, int nreq, int row_blocks, int chunks, const DevParams& P, double* partials,
                         double* out_pinned, hipStream_t stream, unsigned* wgs_started, bool* sweep_submitted);
 }  // namespace cvohip
@@ -1840,6 +1841,25 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
 int cvo_selftest_cubic_step(int device, int n, const float* coef_minstep, float* step_out) { return selftest(device, 0, n, coef_minstep, 5, step_out, 1); }
 int cvo_selftest_exp_sek3(int device, int n, const float* omega_v_dt, float* dR_dT_out) { return selftest(device, 1, n, omega_v_dt, 7, dR_dT_out, 12); }
 int cvo_selftest_dist_se3(int device, int n, const float* dR_dT, float* dist_out) { return selftest(device, 2, n, dR_dT, 12, dist_out, 1); }
+int cvo_selftest_libm(int device, int n, const float* x, float* out5) { return selftest(device, 3, n, x, 1, out5, 5); }
+int cvo_selftest_pair_values(int device, const cvo_params* params, float ell, int n, const float* y_g, float* a_out, float* d2_d2c_out) {
+    int rc = check_device(device, nullptr); if (rc) return rc;
+    if (n <= 0 || !y_g || !a_out || !(ell > 0.f)) return fail(CVO_ERR_INVALID, "bad self-test arguments");
+    cvo_params p; if (params) p = *params; else cvo_default_params(&p);
+    HIP_TRY(hipSetDevice(device));
+    DevBuf din, dout, daux;
+    if ((rc = din.ensure(sizeof(float) * (size_t)n * 8)) || (rc = dout.ensure(sizeof(float) * (size_t)n * 4)) || (rc = daux.ensure(sizeof(float) * (size_t)n * 2))) {
+        din.release(); dout.release(); daux.release(); return rc;
+    }
+    hipError_t e = hipMemcpy(din.p, y_g, sizeof(float) * (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_selftest_pairs(static_cast<const float*>(din.p), static_cast<float*>(dout.p), static_cast<float*>(daux.p), n, ell, to_dev(p), nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(a_out, dout.p, sizeof(float) * (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && d2_d2c_out) e = hipMemcpy(d2_d2c_out, daux.p, sizeof(float) * (size_t)n * 2, hipMemcpyDeviceToHost);
+    din.release(); dout.release(); daux.release();
+    if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("self-test: ") + hipGetErrorString(e));
+    return CVO_OK;
+}
 
 int cvo_batch_create(const cvo_params* p, int device, int max_pairs, cvo_batch* out) {
     if (!out || max_pairs <= 0) return fail(CVO_ERR_INVALID, "bad argument");

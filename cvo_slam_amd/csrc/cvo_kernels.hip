@@ -521,6 +521,79 @@ __device__ __forceinline__ void se_kernel_values_flat(const float* xi, const flo
         a_out[u] = (pass[u] & (a > G.sp)) ? a : 0.f;
     }
 }
+// The steady walk's k = (float)(s2 * exp(x)), x in [-0.25, 0] (Gates::poly_ok), from a SHORTER polynomial -- with a guard that makes the f32 result the one the
+// long polynomial gives.  The double is rounded to f32 right away (cvo.cpp:172), so all the f32 result needs of it is which side of a rounding boundary it
+// lies on: a degree-7 interpolant of exp on [-1/4, 0] (Chebyshev nodes, scripts/derive/exp7_coefficients.py: 1.3e-14 relative, measured on 2e6 points) times s2
+// (folded into the coefficients once per phase: 1.1e-16 each) decides that for every value farther than its own error from a boundary.  The 29 mantissa bits
+// the conversion drops say how far: within 256 double ulps (>= 2.8e-14 relative, twice the error budget) of the half-way pattern the entry is re-evaluated with
+// the 12-term chain -- 512 of 2^29 patterns, one entry in a million.  Seven half-rate Horner steps instead of twelve and no product with s2: 6 of an entry's 16
+// double-precision instructions, for 3 integer ones.
+struct Exp7 { double c[7]; double c7; double inv_den; };   // c[0..6], inv_den wave-uniform (scalar operands of the Horner steps); c7 in a vector register pair (the chain's start)
+// a wave-uniform double in a scalar register pair.  (Not __builtin_amdgcn_readfirstlane: the compiler folds that away for a value it can prove uniform and
+// then hands the "s" operands of the Horner steps a VECTOR register pair -- three 64-bit vector operands per v_fma_f64, measurably slower than two.)
+__device__ __forceinline__ double uni_d(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    unsigned lo, hi;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"((unsigned)b));
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"((unsigned)(b >> 32)));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ Exp7 make_exp7(const Gates& G) {
+    const double c[8] = {0x1.fffffffffffa3p-1, 0x1.fffffffff45b5p-1, 0x1.fffffff859bf4p-2, 0x1.5555536ab4a73p-3, 0x1.5554dc6d808f1p-5, 0x1.1100d93fb8b12p-7,
+                         0x1.69aae1f1adc28p-10, 0x1.6f5e2611a1689p-13};
+    Exp7 E;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) E.c[k] = uni_d((double)G.s2 * c[k]);    // wave-uniform: the Horner steps take them as scalar operands
+    E.c7 = (double)G.s2 * c[7];
+    E.inv_den = uni_d(G.inv_den_l);
+    return E;
+}
+template <int PFN>
+__device__ __forceinline__ void se_kernel_values_flat7(const float* xi, const float4 (&yj)[PFN], const float (&ck)[PFN], const bool (&active)[PFN], const Gates& G, const Exp7& E7,
+                                                       float (&a_out)[PFN], float (&e_out)[PFN][3], float* d2_out = nullptr) {
+    double x[PFN], p[PFN]; bool pass[PFN]; float kk[PFN], d2s[PFN];
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+        const float e0 = xi[0] - yj[u].x, e1 = xi[1] - yj[u].y, e2 = xi[2] - yj[u].z;
+        float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;              // nanoflann.hpp:403-406
+        if (d2_out) d2_out[u] = d2;
+        d2s[u] = d2;
+        pass[u] = active[u] & (d2 < G.d2_thres);
+        asm("v_mul_f64 %0, %1, %2" : "=v"(x[u]) : "v"((double)(-d2)), "s"(E7.inv_den));
+        e_out[u][0] = e0; e_out[u][1] = e1; e_out[u][2] = e2;
+    }
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) p[u] = horner_step(E7.c7, x[u], E7.c[6]);
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+#pragma unroll
+        for (int u = 0; u < PFN; ++u) p[u] = horner_step(p[u], x[u], E7.c[k]);
+    }
+    bool amb = false, ambu[PFN];
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+        const unsigned lo = (unsigned)(unsigned long long)__double_as_longlong(p[u]);
+        ambu[u] = pass[u] & (((lo + (256u - (1u << 28))) & 0x1FFFFFFFu) < 512u);
+        amb |= ambu[u];
+        kk[u] = (float)p[u];
+    }
+    if (__builtin_expect(__ballot(amb) != 0ull, 0)) {                           // one entry in a million: the long chain, as se_kernel_values_flat evaluates it
+#pragma unroll
+        for (int u = 0; u < PFN; ++u) {
+            if (ambu[u]) {
+                const double xe[1] = {(double)(-d2s[u]) * G.inv_den_l};
+                double pe[1];
+                exp_poly13_n<1, 12>(xe, pe);
+                kk[u] = (float)((double)G.s2 * pe[0]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+        const float a = ck[u] * kk[u];
+        a_out[u] = (pass[u] & (a > G.sp)) ? a : 0.f;
+    }
+}
 __device__ __forceinline__ float se_kernel_value_flat(const float* xi, const float4 yj, float ck, bool active, const Gates& G) {
     const float e0 = xi[0] - yj.x, e1 = xi[1] - yj.y, e2 = xi[2] - yj.z;
     float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;                  // nanoflann.hpp:403-406
@@ -529,6 +602,25 @@ __device__ __forceinline__ float se_kernel_value_flat(const float* xi, const flo
     const float k = (float)((double)G.s2 * exp_poly13(x));
     const float a = ck * k;
     return (pass & (a > G.sp)) ? a : 0.f;
+}
+
+// The colour factor of PFN listed pairs (cvo.cpp:171, 173): ck = (float)(c_sigma^2 exp(-d2c / (2.0 c_ell^2))), or NaN for a pair that fails the colour gate
+// (a NaN factor never passes a > sp_thres).  exp_neg with its PFN range reductions and polynomials side by side; evaluated once per entry when a list is made.
+template <int PFN>
+__device__ __forceinline__ void colour_factors(const float (&d2c)[PFN], const Gates& gates, float (&ckv)[PFN]) {
+    double kc[PFN], rc[PFN], pc[PFN];
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+        const double xc = (double)(-d2c[u]) * gates.inv_den_c;
+        kc[u] = __builtin_rint(xc * 1.44269504088896338700e+00);
+        rc[u] = __builtin_fma(kc[u], -1.90821492927058770002e-10, __builtin_fma(kc[u], -6.93147180369123816490e-01, xc));
+    }
+    exp_poly13_n<PFN>(rc, pc);
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+        const float ckx = (float)((double)gates.csig2 * __builtin_ldexp(pc[u], (int)kc[u]));
+        ckv[u] = (d2c[u] < gates.d2c_thres) ? ckx : __builtin_nanf("");
+    }
 }
 
 __device__ __forceinline__ Gates make_gates(float l, const DevParams& P) {
@@ -604,11 +696,30 @@ __device__ __forceinline__ void ls_pair(const float (&df)[3] /* x_i - y_j, cvo.c
     const float gamma_ij = L.s_gamma * (t0.w + sum3f(t1.x * df[0], t1.y * df[1], t1.z * df[2]));  // cvo.cpp:290-291
     const float delta_ij = L.s_delta * (t1.w + sum3f(t2.x * df[0], t2.y * df[1], t2.z * df[2]));  // cvo.cpp:293-294
     const float epsil_ij = L.s_gamma * (t2.w + sum3f(t3.x * df[0], t3.y * df[1], t3.z * df[2]));  // cvo.cpp:296-297
+#ifdef CVO_LS_FULL      // the brackets operation by operation as cvo.cpp:301-305 writes them (experiment builds; the default is the condensed form below)
     Bi += double(A_ij * beta_ij);                                                                                              // cvo.cpp:301
     Ci += double(A_ij * (gamma_ij + beta_ij * beta_ij / 2.0));                                                                 // cvo.cpp:302
     Di += double(A_ij * (delta_ij + beta_ij * gamma_ij + div6((double)(beta_ij * beta_ij * beta_ij))));                        // cvo.cpp:303
     Ei += double(A_ij * (epsil_ij + beta_ij * delta_ij + 1 / 2.0 * beta_ij * beta_ij * gamma_ij                                // cvo.cpp:304-305
                          + 1 / 2.0 * gamma_ij * gamma_ij + 1 / 24.0 * beta_ij * beta_ij * beta_ij * beta_ij));
+#else
+    // The same four terms with the double-precision part of the brackets condensed (cvo.cpp:301-305).  Everything the reference rounds to FLOAT stays as
+    // it is (A*beta, beta*beta, delta + beta*gamma, beta*beta*beta, epsil + beta*delta: each a float product or sum converted afterwards); what it evaluates
+    // in DOUBLE -- because of the 2.0, 6.0, 24.0 literals -- is a polynomial in beta, gamma whose value these lines give to within 2-3 ulps of a double:
+    //   q = beta^2 (exact in double: two 24-bit factors);  gamma + bb/2 = fma(0.5, bb, gamma) (0.5 bb is exact: the same bits as the reference's sum);
+    //   bbb/6.0 as a product with RN(1/6);  1/2 q gamma + 1/2 gamma^2 + q^2/24 = 1/2 gamma (q + gamma) + q^2 RN(1/24);  term and sum fused.
+    // B..E are sums of ~1e4 such terms in an order the reference leaves to its threads (cvo.cpp:309-314), rounded to float before the cubic (cvo.cpp:318): an
+    // ulp of a double in a term is to the result what the order of the sum is (the oracle's shuffled-order variants: no pose bit moves).  12 double-precision
+    // instructions per nonzero instead of 27; tests/test_gpu_config3.py holds the poses of all 64 pairs at 0.0 / 0.0.
+    const double Ad = (double)A_ij, bd = (double)beta_ij, gd = (double)gamma_ij;
+    const double q = bd * bd;
+    Bi += double(A_ij * beta_ij);                                                                                              // cvo.cpp:301
+    Ci = __builtin_fma(Ad, __builtin_fma(0.5, (double)(beta_ij * beta_ij), gd), Ci);                                           // cvo.cpp:302
+    Di = __builtin_fma(Ad, __builtin_fma((double)(beta_ij * beta_ij * beta_ij), 1.0 / 6.0, (double)(delta_ij + beta_ij * gamma_ij)), Di);   // cvo.cpp:303
+    double e = __builtin_fma(0.5, gd * (q + gd), (double)(epsil_ij + beta_ij * delta_ij));                                     // cvo.cpp:304-305
+    e = __builtin_fma(q * q, 1.0 / 24.0, e);
+    Ei = __builtin_fma(Ad, e, Ei);
+#endif
 }
 // one nonzero of A: adds its B, C, D, E terms (cvo.cpp:282-306)
 __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float A_ij, const LsConsts& L, double& Bi, double& Ci, double& Di, double& Ei) {
@@ -1284,9 +1395,24 @@ __device__ __forceinline__ void fold_entry(const float* xi, const float4 y4, flo
     wcount += __popcll(mask);
 }
 
+// The wave's segment of nonzero records as a buffer resource: the record stores of the walks go through it with the lane's byte offset, and a lane
+// that has no record to write gives an offset beyond the segment -- the range check of the buffer instruction drops it.  A store under `if (a > 0)` is a
+// divergent branch (s_and_saveexec, s_cbranch_execz around the store), and behind four of those the compiler no longer knows how many stores are in flight
+// when the walk claims its prefetched list entries at the end of the step: it waited for vmcnt(0) there -- every step of the walk ended by draining its own
+// record stores, a round trip to L2 with nothing to overlap it.  Unconditional stores are counted exactly: the wait becomes vmcnt(4) and the stores of a step
+// complete under the arithmetic of the next.
+constexpr unsigned REC_DROP = 0x7FFFFFF0u;   // a byte offset beyond any segment (segments are far below 2 GB)
+// a whole work buffer of the pair (lists, raw lists) as a buffer resource: offsets below REC_DROP are in range
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_region(const void* base /* wave-uniform */) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(REC_DROP - 16u), 0x00020000);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t record_segment(gv2u* sp /* wave-uniform */, unsigned records) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)sp, 0, (int)(records * 8u), 0x00020000);
+}
 // the same with e = x_i - y_j already at hand (the flat evaluation computed it for d2): y_j - x_i = -e exactly, so
 // sv - a*e has the bits of sv + a*(y_j - x_i)
-__device__ __forceinline__ void fold_entry_e(const float* xi, const float4 y4, const float (&e)[3], float a, unsigned tag, RowSums& rs, gv2u* sp, int& wcount, int lane) {
+__device__ __forceinline__ void fold_entry_e(const float* xi, const float4 y4, const float (&e)[3], float a, unsigned tag, RowSums& rs, gv2u* sp, __amdgpu_buffer_rsrc_t seg,
+                                             int& wcount, int lane) {
     {
         const float yv[3] = {y4.x, y4.y, y4.z};
         float cr[3]; cross3(xi, yv, cr);                            // cvo.cpp:216
@@ -1294,11 +1420,20 @@ __device__ __forceinline__ void fold_entry_e(const float* xi, const float4 y4, c
         rs.sv[0] -= a * e[0]; rs.sv[1] -= a * e[1]; rs.sv[2] -= a * e[2];     // cvo.cpp:217
     }
     const unsigned long long mask = __ballot(a > 0.f);
+#ifndef CVO_BRANCHY_REC
+    {
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        v2u rec; rec.x = __float_as_uint(a); rec.y = tag;
+        const unsigned off = (a > 0.f) ? ((unsigned)wcount + below) * 8u : REC_DROP;
+        __builtin_amdgcn_raw_buffer_store_b64(rec, seg, (int)off, 0, 0);
+    }
+#else
     if (a > 0.f) {
         const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         v2u rec; rec.x = __float_as_uint(a); rec.y = tag;
         st_rec(at_off(sp, (unsigned)wcount + below), rec);
     }
+#endif
     wcount += __popcll(mask);
 }
 
@@ -1310,10 +1445,14 @@ template <int YM, bool FLAT, bool NT = true, bool REFINE = false>
 __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                             double (&acc8)[8], float Rn = 0.f, float alpha_n = 0.f, bool do_shift = false, const float* shift_rt = nullptr) {
     gv2u* sp = uni_ptr(c.surv + c.fbase + sh->wbase[wave]);
+    const __amdgpu_buffer_rsrc_t seg = record_segment(sp, (unsigned)uni(sh->wtot[wave]));   // (a wave has no more nonzeros than listed candidates)
     const bool x_lds = sh->x_lds != 0;
     int wcount = 0;
     const int nb = sh->wnb[wave];
     int kept_w = 0, nb_left = 0;
+#ifdef CVO_EXP7
+    const Exp7 e7 = make_exp7(gates);
+#endif
     const float inv_1ma_n = 1.0f / (1.0f - alpha_n);
     const unsigned rp = (unsigned)c.rows_pad, estep = (PF / 2) * rp;      // in 16-byte words
     // the first entries of a block are fetched while the block before it is walked: in the late iterations a row holds only a
@@ -1350,6 +1489,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
             wp = uni_ptr(c.ent + 2 * (slot - lane));                // the kept entries go to the front of the row (never ahead of the reads): scalar base of the block + 32-bit offsets
             woff = 2u * (unsigned)lane;                             // entry n of the lane's slot at 2 ((n >> 1) rows_pad + slot) + (n & 1)
         }
+        const __amdgpu_buffer_rsrc_t wseg = whole_region((const void*)(REFINE ? wp : sp));
         v4u eq4[PF / 2];
 #pragma unroll
         for (int u = 0; u < PF / 2; ++u) eq4[u] = ehead[u];
@@ -1376,15 +1516,27 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
             }
             if (FLAT) {
                 float ev[PF][3], d2v[PF];
+#ifdef CVO_EXP7
+                se_kernel_values_flat7<PF>(xi, yv4, ckv, actv, gates, e7, av, ev, REFINE ? d2v : nullptr);   // PF exp chains side by side
+#else
                 se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av, ev, REFINE ? d2v : nullptr);   // PF exp chains side by side
+#endif
 #pragma unroll
-                for (int u = 0; u < PF; ++u) fold_entry_e(xi, yv4[u], ev[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, wcount, lane);
+                for (int u = 0; u < PF; ++u) fold_entry_e(xi, yv4[u], ev[u], av[u], stag | (eq[u].y & 0xFFFFu), rs, sp, seg, wcount, lane);
                 if (REFINE) {
 #pragma unroll
                     for (int u = 0; u < PF; ++u) {
                         float dn = d2v[u];
                         if (do_shift) { const float q0 = xs[0] - yv4[u].x, q1 = xs[1] - yv4[u].y, q2 = xs[2] - yv4[u].z; dn = __builtin_fmaf(q2, q2, __builtin_fmaf(q1, q1, q0 * q0)); }
+#ifndef CVO_BRANCHY_REC
+                        {   // (unconditional store, dropped by the range check for an entry that is not kept: see record_segment)
+                            const bool keep = actv[u] && dn < thr_n;
+                            __builtin_amdgcn_raw_buffer_store_b64(eq[u], wseg, (int)(keep ? woff * 8u : REC_DROP), 0, 0);
+                            woff += keep ? ((cnt & 1) ? 2u * rp - 1u : 1u) : 0u; cnt += keep ? 1 : 0;
+                        }
+#else
                         if (actv[u] && dn < thr_n) { st_rf(at_off(wp, woff), eq[u]); woff += (cnt & 1) ? 2u * rp - 1u : 1u; ++cnt; }
+#endif
                     }
                 }
             } else {
@@ -1426,8 +1578,13 @@ template <int YM, bool FLAT, bool GL = false>
 __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* sh, const Gates& gates, int lane, int wave, int nwaves, float inv_c, float inv_d,
                                            double (&acc8)[8]) {
     gv2u* sp = uni_ptr(c.surv + c.fbase + sh->wbase[wave]);
+    const __amdgpu_buffer_rsrc_t seg = record_segment(sp, (unsigned)uni(sh->wtot[wave]));
+    const __amdgpu_buffer_rsrc_t jseg = whole_region((const void*)uni_ptr(c.jT4)), eseg = whole_region((const void*)uni_ptr(c.ent));
     int wcount = 0;
     const int nb = sh->wnb[wave];
+#ifdef CVO_EXP7
+    const Exp7 e7 = make_exp7(gates);
+#endif
     for (int bi = 0; bi < nb; ++bi) {
         const int blk = wave_block(bi, wave, nwaves);
         const int slot = blk * 64 + lane;
@@ -1446,12 +1603,21 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         auto cols = [&](int n0, int (&jo)[PF]) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) jo[u] = 0;
+#ifndef CVO_BRANCHY_REC
+            {   // (unconditional load: a lane whose row has ended reads beyond the range and gets zeros -- no branch, so the loads in flight stay countable)
+                const v2u w = __builtin_amdgcn_raw_buffer_load_b64(jseg, (int)(n0 < len ? ((unsigned)(n0 >> 2) * (unsigned)c.rows_pad + (unsigned)li) * 8u : REC_DROP), 0, 0);
+                const int q[PF] = {(int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16)};
+#pragma unroll
+                for (int u = 0; u < PF; ++u) jo[u] = (n0 + u < len) ? q[u] : 0;
+            }
+#else
             if (n0 < len) {
                 const v2u w = ld_jt(&jp[(size_t)(n0 >> 2) * c.rows_pad]);
                 const int q[PF] = {(int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16)};
 #pragma unroll
                 for (int u = 0; u < PF; ++u) jo[u] = (n0 + u < len) ? q[u] : 0;
             }
+#endif
         };
         auto feats = [&](const int (&ji)[PF], float4 (&go)[PF]) {
 #pragma unroll
@@ -1464,7 +1630,6 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
             cols(n0 + 2 * PF, j2);
             feats(j1, g1);
             float av[PF], ckv[PF], d2c[PF]; float4 yv4[PF]; bool actv[PF];
-            double kc[PF], rc[PF], pc[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 actv[u] = n0 + u < len;
@@ -1473,18 +1638,15 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
                 const float f0 = (YM == 2) ? ld4(c.moving + lo_off(j)).w : yv4[u].w;   // the first channel rides with y, except in the 12-byte LDS layout
                 const float fb[5] = {f0, g0[u].x, g0[u].y, g0[u].z, g0[u].w};
                 d2c[u] = feat_d2(fi, fb);
-                // exp_neg, its PF range reductions and polynomials side by side
-                const double xc = (double)(-d2c[u]) * gates.inv_den_c;
-                kc[u] = __builtin_rint(xc * 1.44269504088896338700e+00);
-                rc[u] = __builtin_fma(kc[u], -1.90821492927058770002e-10, __builtin_fma(kc[u], -6.93147180369123816490e-01, xc));
             }
-            exp_poly13_n<PF>(rc, pc);
+            colour_factors<PF>(d2c, gates, ckv);
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const float ckx = (float)((double)gates.csig2 * __builtin_ldexp(pc[u], (int)kc[u]));
-                ckv[u] = (d2c[u] < gates.d2c_thres) ? ckx : __builtin_nanf("");
+#ifndef CVO_BRANCHY_REC
+            for (int u = 0; u < PF; u += 2) {                         // two entries per 16-byte store (the second may lie beyond the row's end: stale there anyway)
+                v4u e; e.x = __float_as_uint(ckv[u]); e.y = (unsigned)j0[u]; e.z = __float_as_uint(ckv[u + 1]); e.w = (unsigned)j0[u + 1];
+                __builtin_amdgcn_raw_buffer_store_b128(e, eseg, (int)(actv[u] ? (2u * (unsigned)slot + (unsigned)ent_ix(n0 + u, (size_t)c.rows_pad)) * 8u : REC_DROP), 0, 2 /* nt */);
             }
-#pragma unroll
+#else
             for (int u = 0; u < PF; u += 2)                           // two entries per 16-byte store (the second may lie beyond the row's end: stale there anyway)
                 if (actv[u]) {
                     v4u e; e.x = __float_as_uint(ckv[u]); e.y = (unsigned)j0[u]; e.z = __float_as_uint(ckv[u + 1]); e.w = (unsigned)j0[u + 1];
@@ -1494,11 +1656,16 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
                     *reinterpret_cast<gv4u*>(&ep[ent_ix(n0 + u, (size_t)c.rows_pad)]) = e;
 #endif
                 }
+#endif
             if (FLAT) {
                 float ev[PF][3];
+#ifdef CVO_EXP7
+                se_kernel_values_flat7<PF>(xi, yv4, ckv, actv, gates, e7, av, ev);
+#else
                 se_kernel_values_flat<PF>(xi, yv4, ckv, actv, gates, av, ev);
+#endif
 #pragma unroll
-                for (int u = 0; u < PF; ++u) fold_entry_e(xi, yv4[u], ev[u], av[u], stag | (unsigned)j0[u], rs, sp, wcount, lane);
+                for (int u = 0; u < PF; ++u) fold_entry_e(xi, yv4[u], ev[u], av[u], stag | (unsigned)j0[u], rs, sp, seg, wcount, lane);
             } else {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) av[u] = actv[u] ? se_kernel_value_ck(xi, yv4[u], ckv[u], gates) : 0.f;
@@ -2988,6 +3155,49 @@ hipError_t launch_adaptive(const AdaptiveArgs& A, int iterations, hipStream_t st
     return hipGetLastError();
 }
 int adaptive_partial_records(int nf, int nm) { return (nf + ADP_ROWS - 1) / ADP_ROWS + (nm + ADP_ROWS - 1) / ADP_ROWS; }
+
+// ---------------------------------------------------------------- device known-answer test of the pair arithmetic (cvo_selftest_pair_values)
+// One lane per case: the fixed point at the origin with zero features, the moving point y and its features g as given, so that d2 = y0^2 + y1^2 + y2^2 and
+// d2c = sum g^2 with the kernels' own association.  out[4 i ..] = a by the four routes the align kernel has for it:
+//   [0] se_kernel_value (dense fallback, adaptive variant: branches, exp_small)   [1] colour_factors + se_kernel_value_ck (lists outside Gates::poly_ok)
+//   [2] colour_factors + se_kernel_values_flat (the 12-term chain)                [3] colour_factors + se_kernel_values_flat7 (degree 7 + guard)
+// and out_aux[2 i ..] = {d2, d2c} as the device formed them.  Routes 2, 3 need Gates::poly_ok (the default parameters have it): 0 otherwise.
+__global__ void selftest_pairs_kernel(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ aux, int n, float ell, DevParams P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const Gates G = make_gates(ell, P);
+    const float xi[3] = {0.f, 0.f, 0.f}, fi[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int ii = min(i, n - 1);
+    const float4 yj = make_float4(in[ii * 8 + 0], in[ii * 8 + 1], in[ii * 8 + 2], in[ii * 8 + 3]);
+    const float4 gj = make_float4(in[ii * 8 + 4], in[ii * 8 + 5], in[ii * 8 + 6], in[ii * 8 + 7]);
+    const float r0 = se_kernel_value(xi, fi, yj, gj, G);
+    const float fb[5] = {yj.w, gj.x, gj.y, gj.z, gj.w};
+    const float d2c1[1] = {feat_d2(fi, fb)};
+    float ck1[1];
+    colour_factors<1>(d2c1, G, ck1);
+    const float r1 = se_kernel_value_ck(xi, yj, ck1[0], G);
+    float r2 = 0.f, r3 = 0.f, d2s[1] = {0.f};
+    if (G.poly_ok) {
+        const float4 yv[1] = {yj}; const bool act[1] = {true};
+        float a1[1], e1[1][3];
+        se_kernel_values_flat<1>(xi, yv, ck1, act, G, a1, e1, d2s);
+        r2 = a1[0];
+        const Exp7 E7 = make_exp7(G);
+        se_kernel_values_flat7<1>(xi, yv, ck1, act, G, E7, a1, e1);
+        r3 = a1[0];
+    } else {
+        const float e0 = -yj.x, e1 = -yj.y, e2 = -yj.z;
+        float d2 = e0 * e0; d2 = d2 + e1 * e1; d2 = d2 + e2 * e2;
+        d2s[0] = d2;
+    }
+    if (i < n) {
+        out[i * 4 + 0] = r0; out[i * 4 + 1] = r1; out[i * 4 + 2] = r2; out[i * 4 + 3] = r3;
+        aux[i * 2 + 0] = d2s[0]; aux[i * 2 + 1] = d2c1[0];
+    }
+}
+hipError_t launch_selftest_pairs(const float* in, float* out, float* aux, int n, float ell, const DevParams& P, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(selftest_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, aux, n, ell, P);
+    return hipGetLastError();
+}
 
 int align_blocks_per_cu() { return BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD / 2; }
 int align_block_max() { return BLOCK_MAX; }

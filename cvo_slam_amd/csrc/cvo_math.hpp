@@ -140,6 +140,39 @@ CVO_HD float cubic_step(float c3, float c2, float c1, float c0, float min_step) 
     return step;
 }
 
+// sin(float), cos(float) as the correctly rounded float: the reference calls its libm's float routines (LieGroup.cpp:174-175), whose last bit differs
+// between libms (glibc 2.35's sinf is not the correctly rounded value for 1 % of the arguments above 0.03, OCML's for another 1.4 %:
+// tests/test_gpu_pair_values.py); oracle and device both take the value of the double routine rounded once.  Below 0.5 -- every argument a converging
+// alignment produces (step <= 0.8 times |omega| of a few hundredths) -- the series to x^17 (truncation < 1e-20) stands in for the double routine.
+CVO_HD float sin_f32_cr(float x) {
+    const double t = (double)x;
+    if (!(fabs(t) < 0.5)) return (float)sin(t);
+    const double z = t * t;
+    double p = -1.0 / 355687428096000.0;                            // -1/17!
+    p = fma(p, z, 1.0 / 1307674368000.0);                           //  1/15!
+    p = fma(p, z, -1.0 / 6227020800.0);
+    p = fma(p, z, 1.0 / 39916800.0);
+    p = fma(p, z, -1.0 / 362880.0);
+    p = fma(p, z, 1.0 / 5040.0);
+    p = fma(p, z, -1.0 / 120.0);
+    p = fma(p, z, 1.0 / 6.0);
+    return (float)fma(-t * z, p, t);                                // t - t^3 (1/6 - ...)
+}
+CVO_HD float cos_f32_cr(float x) {
+    const double t = (double)x;
+    if (!(fabs(t) < 0.5)) return (float)cos(t);
+    const double z = t * t;
+    double p = 1.0 / 20922789888000.0;                              // 1/16!
+    p = fma(p, z, -1.0 / 87178291200.0);                            // -1/14!
+    p = fma(p, z, 1.0 / 479001600.0);
+    p = fma(p, z, -1.0 / 3628800.0);
+    p = fma(p, z, 1.0 / 40320.0);
+    p = fma(p, z, -1.0 / 720.0);
+    p = fma(p, z, 1.0 / 24.0);
+    p = fma(p, z, -0.5);
+    return (float)fma(z, p, 1.0);
+}
+
 // Exp_SEK3 (K=1), LieGroup.cpp:159-186, including the theta<1e-6 branch R=I, Jl=I (Q3)
 CVO_HD void exp_sek3(const float* omega, const float* v, float dt, float* dR, float* dT) {
     const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -150,8 +183,8 @@ CVO_HD void exp_sek3(const float* omega, const float* v, float dt, float* dR, fl
     } else {
         float A[9]; skew3(omega, A);
         const float theta2 = theta * theta;
-        const float stheta = sinf(dt * theta);
-        const float ctheta = cosf(dt * theta);
+        const float stheta = sin_f32_cr(dt * theta);
+        const float ctheta = cos_f32_cr(dt * theta);
         const float oneMinusCosTheta2 = (1 - ctheta) / (theta2);
         float A2[9]; mat3_mul(A, A, A2);
         const float s1 = stheta / theta;

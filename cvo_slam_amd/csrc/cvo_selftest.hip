@@ -30,10 +30,20 @@ __global__ void selftest_dist_kernel(const float* __restrict__ in, float* __rest
     out[i] = dist_se3(dR, dT);
 }
 
+// the device's float routines where the epilogue and the gates call them (OCML: sinf, cosf in exp_sek3 -- LieGroup.cpp:174-175 --, logf in the gates,
+// cvo.cpp:125-126), element by element: out[5 i ..] = {sinf(x), cosf(x), logf(x), sin_f32_cr(x), cos_f32_cr(x)} -- the last two are what exp_sek3 calls
+__global__ void selftest_libm_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    out[i * 5 + 0] = sinf(x); out[i * 5 + 1] = cosf(x); out[i * 5 + 2] = logf(x); out[i * 5 + 3] = sin_f32_cr(x); out[i * 5 + 4] = cos_f32_cr(x);
+}
+
 hipError_t launch_selftest(int kind, const float* in, float* out, int n, hipStream_t s) {
     const dim3 grid((n + 63) / 64), block(64);
     if (kind == 0) hipLaunchKernelGGL(selftest_cubic_kernel, grid, block, 0, s, in, out, n);
     else if (kind == 1) hipLaunchKernelGGL(selftest_exp_kernel, grid, block, 0, s, in, out, n);
+    else if (kind == 3) hipLaunchKernelGGL(selftest_libm_kernel, grid, block, 0, s, in, out, n);
     else hipLaunchKernelGGL(selftest_dist_kernel, grid, block, 0, s, in, out, n);
     return hipGetLastError();
 }

@@ -496,6 +496,31 @@ static int cubic_real_roots(double a, double b, double c, double* roots) {
     return 3;
 }
 
+void orc_pair_values(const orc_params* p, float ell, int n, const float* d2v, const float* d2cv, float* a_out, float* k_out, float* ck_out) {
+    const orc_params& P = *p;
+    const float l = ell, s2 = P.sigma * P.sigma;                                        // se_kernel(ell, sigma*sigma), cvo.cpp:189
+    const float d2_thres = (float)(-2.0 * l * l * (double)std::log(P.sp_thres / s2));   // cvo.cpp:125
+    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)std::log(P.sp_thres / P.c_sigma / P.c_sigma));   // cvo.cpp:126
+    for (int i = 0; i < n; ++i) {
+        const float d2 = d2v[i], d2_color = d2cv[i];
+        const float k = (float)(s2 * std::exp(-d2 / (2.0 * l * l)));                    // cvo.cpp:172
+        const float ck = (float)(P.c_sigma * P.c_sigma * std::exp(-d2_color / (2.0 * P.c_ell * P.c_ell)));   // cvo.cpp:173
+        float a = 0.f;
+        if (d2 < d2_thres && d2_color < d2_c_thres) {                                   // cvo.cpp:166, 171
+            const float ak = ck * k;                                                    // cvo.cpp:174
+            if (ak > P.sp_thres) a = ak;                                                // cvo.cpp:175
+        }
+        a_out[i] = a;
+        if (k_out) k_out[i] = k;
+        if (ck_out) ck_out[i] = ck;
+    }
+}
+void orc_libm_f32(int kind, int n, const float* in, float* out) {
+    for (int i = 0; i < n; ++i)
+        out[i] = kind == 0 ? std::sin(in[i]) : kind == 1 ? std::cos(in[i]) : kind == 2 ? std::log(in[i])                    // the float overloads
+               : kind == 3 ? (float)std::sin((double)in[i]) : (float)std::cos((double)in[i]);                                // the correctly rounded floats (Exp_SEK3 here)
+}
+
 extern "C" float orc_cubic_step(float c3, float c2, float c1, float c0, float min_step) {
     const float p1f = c2 / c3, p2f = c1 / c3, p3f = c0 / c3;                      // (coef/coef(0)).segment(1,3), cvo.cpp:86
     float best = std::numeric_limits<float>::max();
@@ -591,6 +616,8 @@ void compute_step_size(orc_cvo* o) {
 
 }  // namespace
 
+static inline float sin_cr(float x) { return (float)std::sin((double)x); }
+static inline float cos_cr(float x) { return (float)std::cos((double)x); }
 // Exp_SEK3 for K=1, LieGroup.cpp:159-186 (incl. the theta<1e-6 branch: R=I, Jl=I)
 extern "C" void orc_exp_sek3(const float omega[3], const float v[3], float dt, float dR[9], float dT[3]) {
     const float TOLERANCE = 1e-6f;                                                // LieGroup.cpp:18
@@ -602,8 +629,12 @@ extern "C" void orc_exp_sek3(const float omega[3], const float v[3], float dt, f
     } else {
         float A[9]; skew3(omega, A);
         const float theta2 = theta * theta;
-        const float stheta = std::sin(dt * theta);
-        const float ctheta = std::cos(dt * theta);
+        // sin(float), cos(float) are the libm's float routines in the reference (LieGroup.cpp:174-175) -- Intel's under icpc, glibc's under gcc -- and
+        // differ between libms in the last bit: glibc 2.35's sinf is not the correctly rounded value for 1 % of the arguments above 0.03 (none below
+        // 1e-3; tests/test_gpu_pair_values.py measures it), the device's OCML sinf for another 1.4 %.  Oracle and device both take the correctly
+        // rounded float: the double routine's value rounded once (sin_cr / cos_cr here, sin_f32_cr / cos_f32_cr in cvo_math.hpp).
+        const float stheta = sin_cr(dt * theta);
+        const float ctheta = cos_cr(dt * theta);
         const float oneMinusCosTheta2 = (1 - ctheta) / (theta2);
         float A2[9]; mat3_mul(A, A, A2);
         const float s1 = stheta / theta;

@@ -165,6 +165,15 @@ int  orc_flow_once(orc_cvo* o, float omega[3], float v[3], int* nnz, double BCDE
                    int* csr_rowptr /* nf+1 or NULL */, int* csr_col /* cap or NULL */,
                    float* csr_val /* cap or NULL */, int csr_cap);
 
+/* ---- the pair arithmetic alone (known-answer checks of the device's pair functions, tests/test_gpu_pair_values.py).
+ * orc_pair_values: cvo.cpp:166-175 on caller-supplied squared distances -- out[i] = a if (d2, d2c) is a member of A at `ell`, else 0;
+ *                  k_out / ck_out (may be NULL): the two kernel factors as floats, whatever the gates say.
+ * orc_libm_f32:    glibc's sinf (kind 0), cosf (1), logf (2: what the gates call, cvo.cpp:125-126), and the correctly rounded float sine (3) and cosine (4) the
+ *                  oracle's Exp_SEK3 uses (LieGroup.cpp:174-175: `sin(float)` of the reference's libm, which differs between libms in the last bit),
+ *                  element by element, to compare the device's routines with on the arguments the kernel produces. */
+void orc_pair_values(const orc_params* p, float ell, int n, const float* d2, const float* d2c, float* a_out, float* k_out, float* ck_out);
+void orc_libm_f32(int kind, int n, const float* in, float* out);
+
 /* closed-form pieces */
 float orc_cubic_step(float c3, float c2, float c1, float c0, float min_step);   /* cvo.cpp:76-92,317-333 */
 void  orc_exp_sek3(const float omega[3], const float v[3], float dt, float dR[9], float dT[3]); /* LieGroup.cpp:159-186 */

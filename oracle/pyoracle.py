@@ -120,6 +120,8 @@ def lib(flavor: str = "parity"):
         L.orc_dist_se3.argtypes = [fp, fp]; L.orc_dist_se3.restype = C.c_float
         L.orc_hessian_regularize.argtypes = [fp, C.c_int, dp]
         L.orc_radius_search.argtypes = [fp, C.c_int, fp, C.c_float, ip, fp, C.c_int, C.c_int]
+        L.orc_pair_values.argtypes = [C.POINTER(Params), C.c_float, C.c_int, fp, fp, fp, fp, fp]
+        L.orc_libm_f32.argtypes = [C.c_int, C.c_int, fp, fp]
         L.orc_set_variant.argtypes = [C.c_void_p, C.c_int, C.c_ulonglong]
         L.orc_cubic_step_f32eig.argtypes = [C.c_float] * 5; L.orc_cubic_step_f32eig.restype = C.c_float
         L.orc_dist_se3_f32logm.argtypes = [fp, fp]; L.orc_dist_se3_f32logm.restype = C.c_float
@@ -293,6 +295,24 @@ def adaptive_align(fixed_xyz, fixed_feat, moving_xyz, moving_feat, params: Adapt
     tr = [dict(omega=np.array(r.omega[:], np.float32), v=np.array(r.v[:], np.float32), dl=r.dl, ell=r.ell, step=r.step,
                nnz_xy=r.nnz_xy, nnz_xx=r.nnz_xx, nnz_yy=r.nnz_yy) for r in rows[: n.value]]
     return rc, dict(transform=tf.reshape(3, 4), R=Rb.reshape(3, 3), T=Tb, ell=ell.value, iter=it.value, trace=tr)
+
+
+def pair_values(d2, d2c, ell, params: Params | None = None):
+    """cvo.cpp:166-175 on given squared distances: (a, k, ck) float32 arrays (a = 0 for a non-member)."""
+    d, dp_ = _f(d2); c, cp = _f(d2c)
+    assert d.shape == c.shape and d.ndim == 1
+    a = np.zeros_like(d); k = np.zeros_like(d); ck = np.zeros_like(d)
+    fp = C.POINTER(C.c_float)
+    p = params or default_params()
+    lib().orc_pair_values(C.byref(p), float(ell), d.shape[0], dp_, cp, a.ctypes.data_as(fp), k.ctypes.data_as(fp), ck.ctypes.data_as(fp))
+    return a, k, ck
+
+
+def libm_f32(kind: str, x):
+    """glibc sinf / cosf / logf element by element (kind 'sin', 'cos', 'log'); 'sin_cr', 'cos_cr': the correctly rounded floats of the oracle's Exp_SEK3."""
+    a, ap = _f(x); out = np.zeros_like(a)
+    lib().orc_libm_f32({"sin": 0, "cos": 1, "log": 2, "sin_cr": 3, "cos_cr": 4}[kind], a.size, ap, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
 
 
 def cubic_step(c3, c2, c1, c0, min_step=0.2):
