@@ -1596,9 +1596,11 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
         const float xi[3] = {lo.x, lo.y, lo.z};
         const float fi[5] = {lo.w, hi.x, hi.y, hi.z, hi.w};
         RowSums rs = {{0, 0, 0}, {0, 0, 0}};
-        const gv2u* jp = c.jT4 + li;                                // entries 4q .. 4q+3 of this row: jp[q * rows_pad]
         static_assert(PF == 4, "the cull packs four columns per word");
+#ifdef CVO_BRANCHY_REC
+        const gv2u* jp = c.jT4 + li;                                // entries 4q .. 4q+3 of this row: jp[q * rows_pad]
         gv2u* ep = c.ent + 2 * slot;
+#endif
         const unsigned stag = (unsigned)slot << 16;
         auto cols = [&](int n0, int (&jo)[PF]) {
 #pragma unroll
