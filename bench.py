@@ -213,6 +213,25 @@ def latency_probe(ca, pairs, device):
             (trf if full else tr).append(time.perf_counter() - t0)
             shared = kf.shared_cloud_count()                          # 2: the keyframe object took both frames' clouds over from the odometry object's generation (same images)
             odo.close(); kf.close()
+    # the same frame with the caller one image ahead (cvo_stage_next_frame): frame t's cloud was staged while frame t - 1 was tracked, frame t + 1's is staged
+    # between this frame's odometry block and its keyframe block -- what a pipelined image reader does with the reference's loop (run_SLAM.cpp:70-87)
+    (fc, dc), _, _ = synth.make_frames(1)
+    trs = []
+    for _ in range(5):
+        odo, kf = ca.Cvo(device=device), ca.Cvo(device=device)
+        odo.set_tail_scores(True); kf.set_tail_scores(True)
+        odo.set_pcd_images(fa, da, camt); kf.set_pcd_images(fa, da, camt)
+        odo.stage_next_frame(fb, db, camt)
+        time.sleep(0.003)                                             # (the previous frame's tracking: the staged generation runs beside it)
+        t0 = time.perf_counter()
+        tfo = odo.match_odometry_images(fb, db, camt)
+        odo.stage_next_frame(fc, dc, camt)
+        tfk = kf.match_keyframe_images(fb, db, camt)
+        kf.compute_innerproduct(tfk.astype(np.float32))
+        trs.append(time.perf_counter() - t0)
+        staged = odo.staged_frame_count()
+        odo.set_pcd_images(fc, dc, camt)                              # (takes the frame staged above: nothing is left running when the objects close)
+        odo.close(); kf.close()
     pc = []
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -227,6 +246,7 @@ def latency_probe(ca, pairs, device):
     return {"single_pair_align_ms": med(al), "single_pair_score_block_ms": med(sc), "lc_candidates": n,
             "set_pcd_images_ms": med(pg[2:]), "set_pcd_images_same_frame_ms": med(pg_same), "set_pcd_images_points": int(n_pts), "set_pcd_images_input_MB": img_bytes / 1e6,
             "set_pcd_images_cpu_port_ms": med(pc), "tracker_frame_from_images_ms": med(tr), "tracker_frame_with_both_score_blocks_ms": med(trf), "tracker_frame_clouds_taken_over": shared,
+            "tracker_frame_next_frame_staged_ms": med(trs), "tracker_frame_staged_clouds_taken": staged,
             "lc_batch_align_ms": med(la), "lc_batch_score_block_ms": med(ls), "note": "host wall time per call, median of 5, automatic workgroup count"}
 
 
@@ -234,40 +254,109 @@ def launch_ranks(n: int, argv, collect_stdout: bool = False) -> int:
     """`bench.py --gpus N` invoked bare (no RANK in the environment): start the N ranks as CHILD processes of this one -- which has not
     touched the GPU and never will --, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
     torch.distributed.run sets them.  Rank 0 writes the JSON line to this process's stdout; the other ranks' stdout goes to stderr.
-    Returns the largest exit status; when a rank fails the others get ten seconds, then they are ended (by PID)."""
+    Returns the largest exit status; when a rank fails the others get ten seconds, then SIGTERM, then ten more and SIGKILL (by PID)."""
     import socket
     import subprocess
-    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "GROUP_RANK": "0", "NNODES": "1",
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "CVO_BENCH_LAUNCHED_BY": "bench.py"})
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        out = subprocess.PIPE if collect_stdout else (None if r == 0 else sys.stderr)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out, text=collect_stdout or None))
-    print(f"[bench] started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
-    rcs = [None] * n
-    t_fail = None
-    while any(rc is None for rc in rcs):
-        for i, pr in enumerate(procs):
-            if rcs[i] is None:
-                rc = pr.poll()
-                if rc is not None:
-                    rcs[i] = rc
-                    if rc != 0 and t_fail is None:
-                        t_fail = time.time()
-                        print(f"[bench] rank {i} exited with status {rc}", file=sys.stderr, flush=True)
-        if t_fail is not None and time.time() - t_fail > 10.0:
+    import tempfile
+
+    def start(port):
+        ps, outs = [], []
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "GROUP_RANK": "0", "NNODES": "1",
+                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "CVO_BENCH_LAUNCHED_BY": "bench.py"})
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # collected output goes to a temporary file, not a pipe: a rank that prints more than a pipe holds would block with nobody reading
+            f = tempfile.TemporaryFile(mode="w+") if collect_stdout else None
+            outs.append(f)
+            ps.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=f if collect_stdout else (None if r == 0 else sys.stderr)))
+        return ps, outs
+
+    def free_port():
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); p = sock.getsockname()[1]; sock.close()
+        return p
+
+    rcs = [1] * n
+    for attempt in range(3):                       # the port is only known to be free when it was asked for: another process may take it before rank 0 binds it
+        port = free_port()
+        procs, outs = start(port)
+        print(f"[bench] started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
+        rcs = [None] * n
+        t_fail = t_term = None
+        t_start = time.time()
+        while any(rc is None for rc in rcs):
             for i, pr in enumerate(procs):
                 if rcs[i] is None:
-                    pr.kill(); rcs[i] = pr.wait() or 1
-        time.sleep(0.05)
-    if collect_stdout:
-        for pr in procs:
-            sys.stdout.write(pr.stdout.read())
-        sys.stdout.flush()
+                    rc = pr.poll()
+                    if rc is not None:
+                        rcs[i] = rc
+                        if rc != 0 and t_fail is None:
+                            t_fail = time.time()
+                            print(f"[bench] rank {i} exited with status {rc}", file=sys.stderr, flush=True)
+            if t_fail is not None and t_term is None and time.time() - t_fail > 10.0:      # the others get ten seconds, then SIGTERM, then another ten, then SIGKILL
+                t_term = time.time()
+                for i, pr in enumerate(procs):
+                    if rcs[i] is None:
+                        pr.terminate()
+            if t_term is not None and time.time() - t_term > 10.0:
+                for i, pr in enumerate(procs):
+                    if rcs[i] is None:
+                        pr.kill(); rcs[i] = pr.wait() or 1
+            time.sleep(0.05)
+        if collect_stdout:
+            for f in outs:
+                f.seek(0); sys.stdout.write(f.read()); f.close()
+            sys.stdout.flush()
+        # a rendezvous that failed within seconds because the port was taken: once more on another port (anything else is the ranks' own failure)
+        if all(rc == 0 for rc in rcs) or time.time() - t_start > 20.0 or os.environ.get("CVO_BENCH_NO_PORT_RETRY"):
+            break
+        print(f"[bench] the ranks failed within {time.time() - t_start:.0f} s (statuses {rcs}): trying another rendezvous port", file=sys.stderr, flush=True)
     return max(abs(rc) for rc in rcs)
+
+
+def parity_check(pairs, results, its, threads):
+    """Every pair of the timed batch through the oracle's un-fused parity build, one alignment per host thread: max pose error, iteration counts."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    po.build()
+
+    def one(p):
+        _, fx, ff, mx, mf = p
+        o = po.OracleCvo(search=po.SEARCH_KDTREE, threads=1, flavor="parity")
+        o.set_pcd(fx, ff); o.set_pcd(mx, mf); o.align()
+        st = o.get_state()
+        return st["transform"].copy(), st["iter"] + 1
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        cpu = list(ex.map(one, pairs))
+    errs = [rot_trans_err(results[i]["transform"], cpu[i][0]) for i in range(len(cpu))]
+    return {"pairs_checked": len(errs), "against": "oracle, un-fused parity build (every pair of the timed batch)", "max_rot_err_rad": max(e[0] for e in errs),
+            "max_trans_err_m": max(e[1] for e in errs), "iterations_equal": bool(all(a == b[1] for a, b in zip(its, cpu))), "tolerance": "1e-4 rad / 1e-4 m",
+            "oracle_seconds": time.perf_counter() - t0, "host_threads": threads}
+
+
+def config5_child():
+    """BASELINE config 5 (the largest single-GPU configuration: 736x456 ETH3D shape, ~9.3 k points per cloud) as a short run of this very script in a child process,
+    after the main measurement has left the device: value, roofline and the parity of the 64 pairs it timed, for the driver's line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--shape", "eth3d", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--parity-only", "--no-latency-probe"]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited {r.returncode}", "stderr_tail": r.stderr[-400:]}
+        d = json.loads(line[-1])
+    except Exception as e:                                           # the main line must not depend on this object
+        return {"error": repr(e)}
+    rf, hb = d.get("roofline", {}), d.get("hbm", {})
+    return {"metric": "CVO frame-pair alignments/sec (736x456, ~9.3k pts/cloud: BASELINE config 5)", "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+            "ms_per_step": d["ms_per_step"], "workload": d["config"]["workload"], "points_fixed_mean": d["config"]["points_fixed_mean"], "iterations_mean": d["config"]["iterations_mean"],
+            "workgroups_per_pair": d["config"]["workgroups_per_pair"], "steps_in_flight": d["config"]["steps_in_flight"],
+            "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "valu_wave_instructions_per_launch", "counters")},
+            "traffic_over_algorithmic_bytes": (hb.get("traffic") / hb["algorithmic_bytes_per_launch"]) if hb.get("traffic") and hb.get("algorithmic_bytes_per_launch") else None,
+            "parity": d.get("parity"), "child_seconds": time.perf_counter() - t0, "command": " ".join(cmd[1:])}
 
 
 def main():
@@ -287,6 +376,8 @@ def main():
     ap.add_argument("--reuse", choices=("any", "oldest"), default="any", help="which batch object in flight the next step reuses: whichever has completed first (cvo_batch_done), or strictly the oldest")
     ap.add_argument("--total-pairs", type=int, default=0, help="pairs per step over ALL ranks, dealt in contiguous blocks (cvo_shard_range: blocks may differ by one, the gather pads); 0 = --pairs per rank")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the single-pair / loop-closure / point-cloud latency measurements (counter passes)")
+    ap.add_argument("--parity-only", action="store_true", help="with --no-cpu-baseline: still check every timed pair against the oracle (parity build, all host threads), without the timed CPU legs")
+    ap.add_argument("--no-config5", action="store_true", help="do not append the `config5` object (a short run of BASELINE config 5, --shape eth3d, in a child process) to the default line")
     ap.add_argument("--dry-launch", action="store_true", help="every rank prints its block of the step's pairs (cvo_shard_range) as one JSON line and exits: no GPU needed")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:      # the bare invocation: this process becomes the launcher of the N ranks (before anything imports torch or touches the GPU)
@@ -318,8 +409,18 @@ def main():
         from cvo_slam_amd import api
         blk = list(api.shard_range(total_pairs, rank, world))            # cvo_shard_range / cvo_shard_block: arithmetic of the C ABI, no device needed
         assert blk == list(range(first_pair, first_pair + n_mine)) and api.shard_block(total_pairs, world) == n_block
+        try:
+            rccl = api.comm_library_path()                               # dlopen + dladdr only: no device needed
+        except Exception as e:
+            rccl = f"not loadable ({e})"
+        want_abi = os.environ.get("CVO_BENCH_BACKEND", "nccl") == "nccl" and os.environ.get("CVO_BENCH_GATHER", "abi") == "abi"
         print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world": world, "first_pair": first_pair, "pairs": n_mine,
-                          "block_records": n_block, "total_pairs": total_pairs, "launched_by": os.environ.get("CVO_BENCH_LAUNCHED_BY", "external launcher")}), flush=True)
+                          "block_records": n_block, "total_pairs": total_pairs, "launched_by": os.environ.get("CVO_BENCH_LAUNCHED_BY", "external launcher"),
+                          # what the N > 1 line will say about the collective (the timed run fills the same keys from the live communicator)
+                          "ranks_in_communicator": world if world > 1 else 1, "gather": ("rccl" if want_abi else "torch") if world > 1 else "none",
+                          "gather_streams": (("one (the communicator's own: CVO_BENCH_GATHER_STREAM)" if os.environ.get("CVO_BENCH_GATHER_STREAM") else
+                                              "the align launches' own (one per step in flight)") if (world > 1 and want_abi) else None),
+                          "rccl_library": rccl if world > 1 else None}), flush=True)
         return
     first_pair += int(os.environ.get("CVO_BENCH_PAIR_OFFSET", "0"))      # experiments: another set of synthetic pairs (the metric's set starts at 0)
     # host-side input generation first (forks; no GPU state yet)
@@ -404,6 +505,8 @@ def main():
                 dist.all_reduce(ok2, op=dist.ReduceOp.MIN)             # every rank has its communicator, or nobody uses one
                 if int(ok2.item()) == 1:
                     gather_mode = "abi"
+                    if os.environ.get("CVO_BENCH_GATHER_STREAM"):     # fallback mode: all gathers on the communicator's own stream (include/cvo_hip.h, "ORDER INVARIANT")
+                        comm.set_gather_stream(True)
                     comm_ranks, comm_rank = comm.info()                # ncclCommCount / ncclCommUserRank: what the RCCL communicator itself reports
                     assert (comm_ranks, comm_rank) == (world, rank), (comm_ranks, comm_rank, world, rank)
                 else:
@@ -415,6 +518,12 @@ def main():
             elif rank == 0:
                 print("[bench] gathering with torch.distributed instead", file=sys.stderr, flush=True)
 
+    rccl_path = None
+    if world > 1 and rank == 0:
+        try:
+            rccl_path = api.comm_library_path()    # dladdr of the ncclAllGather the C ABI bound
+        except Exception as e:
+            rccl_path = f"not loaded ({e})"
     kernel_ms = []                                 # HIP-event duration of every launch, on the stream it ran on
 
     launch_status = [0] * depth                    # what cvo_batch_align_async returned for the step a batch object holds
@@ -715,6 +824,8 @@ def main():
             "dtype": "f32", "data": "synthetic", "timed_region_s": elapsed,
             "ranks_in_communicator": comm_ranks if world > 1 else 1,
             "gather": ("rccl" if gather_mode == "abi" else ("torch" if backend == "nccl" else backend)) if world > 1 else "none",
+            "gather_streams": ("one (the communicator's own: CVO_BENCH_GATHER_STREAM)" if os.environ.get("CVO_BENCH_GATHER_STREAM") else "the align launches' own (one per step in flight)") if (world > 1 and gather_mode == "abi") else None,
+            "rccl_library": rccl_path if world > 1 else None,
             "config": {"workload": f"{n} independent synthetic {'640x480 TUM' if args.shape == 'tum' else '736x456 ETH3D'}-shape RGB-D pairs per GPU per step "
                                    f"(BASELINE config {'3' if args.shape == 'tum' else '5'}; {total_pairs} pairs per step at {world} GPU(s); config 4 = 512 pairs at 8 GPUs), "
                                    f"full align() from R=I,T=0,ell=0.15 to convergence",
@@ -791,6 +902,10 @@ def main():
                              "iterations_equal": bool(all(a == b for a, b in zip(its, cpu_its))), "tolerance": "1e-4 rad / 1e-4 m",
                              "reference_noise_envelope": env}
             out["speedup_vs_cpu_baseline"] = value / cpu_rate
+        elif args.parity_only and world == 1:
+            out["parity"] = parity_check(pairs, results, its, host_threads())
+        if args.shape == "tum" and world == 1 and not args.no_config5 and not args.no_latency_probe and not under_profiler():
+            out["config5"] = config5_child()
         print(json.dumps(out), flush=True)
 
     if world > 1:

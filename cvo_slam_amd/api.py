@@ -86,12 +86,12 @@ ABI_SYMBOLS = [
     "cvo_batch_create", "cvo_batch_destroy", "cvo_batch_set_pair", "cvo_batch_set_state", "cvo_batch_set_workgroups",
     "cvo_batch_reset_states", "cvo_batch_align_async", "cvo_batch_wait", "cvo_batch_last_launch",
     "cvo_batch_results_to_device", "cvo_batch_last_phase_seconds", "cvo_batch_compute_innerproduct_lc",
-    "cvo_set_pcd_images", "cvo_shared_cloud_count", "cvo_queued_score_count", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
+    "cvo_set_pcd_images", "cvo_shared_cloud_count", "cvo_stage_next_frame", "cvo_staged_frame_count", "cvo_queued_score_count", "cvo_set_num_want", "cvo_match_odometry_images", "cvo_match_keyframe_images", "cvo_get_cloud", "cvo_get_selected_points",
     "cvo_batch_enqueue_innerproduct", "cvo_batch_innerproduct_results", "cvo_batch_compute_innerproduct",
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3", "cvo_selftest_libm", "cvo_selftest_pair_values",
     "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups", "cvo_batch_set_adoption", "cvo_batch_last_adoptions", "cvo_batch_last_adoption_retractions",
     "cvo_adaptive_default_params", "cvo_adaptive_align",
-    "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_comm_info", "cvo_batch_gather_results",
+    "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_comm_info", "cvo_comm_set_gather_stream", "cvo_comm_library_path", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
     "cvo_batch_set_pairs", "cvo_batch_result_records", "cvo_shard_block", "cvo_batch_gather_results_padded", "cvo_batch_padded_records",
     "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds", "cvo_batch_last_pair_spans", "cvo_batch_last_tail_seconds", "cvo_set_tail_scores", "cvo_batch_last_cull_masks", "cvo_batch_last_nonzeros",
@@ -174,6 +174,8 @@ def load_library():
     L.cvo_set_pcd_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera)]
     L.cvo_set_num_want.argtypes = [vp, C.c_int]
     L.cvo_shared_cloud_count.argtypes = [vp, C.POINTER(C.c_int)]
+    L.cvo_stage_next_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera)]
+    L.cvo_staged_frame_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.cvo_queued_score_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.cvo_match_odometry_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera), dp]
     L.cvo_match_keyframe_images.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(Camera), dp]
@@ -199,6 +201,8 @@ def load_library():
     L.cvo_comm_create_all.argtypes = [ip, C.c_int, C.POINTER(vp)]
     L.cvo_comm_destroy.argtypes = [vp]
     L.cvo_comm_info.argtypes = [vp, ip, ip]
+    L.cvo_comm_set_gather_stream.argtypes = [vp, C.c_int]
+    L.cvo_comm_library_path.argtypes = [C.c_char_p, C.c_int]
     L.cvo_batch_gather_results.argtypes = [vp, vp, C.c_int, vp]
     L.cvo_gather_results.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]
     L.cvo_multi_create.argtypes = [C.POINTER(Params), ip, C.c_int, C.c_int, C.POINTER(vp)]
@@ -358,6 +362,17 @@ class Cvo:
         """camera = (scaling_factor, fx, fy, cx, cy)."""
         bgr, dep, w, h = self._images(bgr8, depth16); cam = Camera(*[float(v) for v in camera])
         _check(self.L.cvo_set_pcd_images(self.h, bgr.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p), w, h, C.byref(cam)))
+
+    def stage_next_frame(self, bgr8, depth16, camera):
+        """cvo_stage_next_frame: start generating this frame's cloud now; a later set_pcd_images / match_*_images with the same images takes it.
+        The arrays are kept alive (and must not be written) until then."""
+        bgr, dep, w, h = self._images(bgr8, depth16); cam = Camera(*[float(v) for v in camera])
+        self._staged = (bgr, dep)                                    # the library reads them from its worker thread
+        _check(self.L.cvo_stage_next_frame(self.h, bgr.ctypes.data_as(C.c_void_p), dep.ctypes.data_as(C.c_void_p), w, h, C.byref(cam)))
+
+    def staged_frame_count(self) -> int:
+        """cvo_staged_frame_count: clouds this object took from a generation started ahead of time"""
+        n = C.c_int(0); _check(self.L.cvo_staged_frame_count(self.h, C.byref(n))); return n.value
 
     def set_num_want(self, num_want: int):
         _check(self.L.cvo_set_num_want(self.h, int(num_want)))
@@ -556,6 +571,13 @@ def compact_records(gathered, n_pairs: int, world: int):
     return out, err.value
 
 
+def comm_library_path() -> str:
+    """cvo_comm_library_path: the file the RCCL bound by the C ABI was loaded from."""
+    buf = C.create_string_buffer(1024)
+    _check(load_library().cvo_comm_library_path(buf, 1024))
+    return buf.value.decode()
+
+
 def comm_unique_id() -> bytes:
     buf = C.create_string_buffer(COMM_ID_BYTES)
     _check(load_library().cvo_comm_unique_id(buf))
@@ -569,6 +591,10 @@ class CvoComm:
         self.L = load_library(); self.h = C.c_void_p(); self.n_ranks = n_ranks; self.rank = rank
         assert len(unique_id) == COMM_ID_BYTES
         _check(self.L.cvo_comm_create(unique_id, n_ranks, rank, device, C.byref(self.h)))
+
+    def set_gather_stream(self, on: bool):
+        """cvo_comm_set_gather_stream: every gather of this communicator on one stream of its own (fallback mode, include/cvo_hip.h)."""
+        _check(self.L.cvo_comm_set_gather_stream(self.h, 1 if on else 0))
 
     def info(self):
         """(ranks, rank) as the RCCL communicator reports them (ncclCommCount / ncclCommUserRank)."""

@@ -151,6 +151,7 @@ struct Cloud {
 // is raised before the owner overwrites the buffer: a compare that saw the same stamp before and after has read one image.
 struct ImageStage {
     PinBuf buf; std::atomic<unsigned long long> stamp{0};
+    std::mutex mu;              // held while the owner rewrites `buf` and while anybody compares against it (the stamp alone would leave memcpy racing memcmp formally)
     ~ImageStage() { buf.release(); }
 };
 struct LastGenerated {          // per host thread: the handles of one thread are used one after the other, so whoever shares never races with the generator
@@ -159,6 +160,8 @@ struct LastGenerated {          // per host thread: the handles of one thread ar
     std::shared_ptr<Cloud> cloud;
 };
 LastGenerated& last_generated() { static thread_local LastGenerated g; return g; }
+struct FrameStager;
+FrameStager*& frame_stager_slot() { static thread_local FrameStager* s = nullptr; return s; }
 bool share_generated_clouds() { static const bool on = [] { const char* e = std::getenv("CVO_HIP_SHARE_CLOUDS"); return !e || std::atoi(e) != 0; }(); return on; }
 
 // The hand-over's copy into the pinned ring: 12.6 MB per 64-pair step that the host never reads again.  Ordinary stores pull every destination line into the cache first
@@ -294,7 +297,8 @@ SlotBook& slot_book() { static SlotBook b; return b; }
 // EVERY align launch of the process counts (with or without adoption, cooperative, queue mode), and so does every score launch: those are
 // the kernels whose workgroups wait for a compute unit while persistent align workgroups hold them.  The two counters only ever move
 // together: a launch adds its grid to `submitted` before it is submitted (and takes it back when the submission fails), and every one of
-// its workgroups adds itself to `started` first thing -- there is nothing to re-synchronise and no host read of the device counter.
+// its workgroups adds itself to `started` first thing -- no host read of the device counter on any healthy path; a launch call that reports an error re-synchronises
+// them once the device has drained (resync_adopt_counters).
 struct AdoptCounters { int device = -1; unsigned* submitted_host = nullptr; unsigned* submitted_dev = nullptr; unsigned* started_dev = nullptr; };
 AdoptCounters* adopt_counters(int device) {                          // null when they cannot be made: launches then run without adoption
     static std::mutex mu; static std::vector<AdoptCounters*> all;
@@ -310,6 +314,18 @@ AdoptCounters* adopt_counters(int device) {                          // null whe
     return a->submitted_host ? a : nullptr;
 }
 std::mutex& adopt_submit_mutex() { static std::mutex m; return m; }
+// A launch call has reported an error.  It may still have been enqueued (hipGetLastError can hand out an earlier, sticky error), so "take the grid back from
+// `submitted`" could leave the two counters apart for the life of the process -- and the helpers silent (submitted != started reads "work is queued").  Errors are
+// rare: let the device drain and set `submitted` to what has really started.  Called with the submit lock held (nothing counted is submitted meanwhile).
+void resync_adopt_counters(AdoptCounters* a) {
+    (void)hipDeviceSynchronize();
+    unsigned st = 0;
+    if (hipMemcpy(&st, a->started_dev, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {
+        if (*a->submitted_host != st) std::fprintf(stderr, "cvo_hip: launch error on device %d: adoption counters re-synchronised (submitted %u, started %u)\n", a->device, *a->submitted_host, st);
+        *a->submitted_host = st;
+    }
+    (void)hipGetLastError();
+}
 
 // Launch machinery shared by single-object handles and batches.
 struct Engine {
@@ -630,6 +646,9 @@ struct Engine {
             pattern_len = (int)n;
         }
         unsigned char* st = static_cast<unsigned char*>(img_stage->buf.p);
+        // every return from here on leaves nothing of this call in flight: the next generation overwrites the pinned stage the copies read from
+        struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{stream};
+        std::unique_lock<std::mutex> stage_lock(img_stage->mu);
         // the colour image first: its copy and the gradient / threshold kernels (which need nothing else) run while the host stages the depth image
         std::memcpy(st, bgr8, 3 * n);
         HIP_TRY(hipMemcpyAsync(d_bgr.p, st, 3 * n, hipMemcpyHostToDevice, stream));
@@ -641,6 +660,7 @@ struct Engine {
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("pcd kernels: ") + hipGetErrorString(e));
         lap();                                                          // [0] buffers, colour staging + copy + kernels queued
         std::memcpy(st + 3 * n, depth16, 2 * n);
+        stage_lock.unlock();
         HIP_TRY(hipMemcpyAsync(d_depth.p, st + 3 * n, 2 * n, hipMemcpyHostToDevice, stream));
         lap();                                                          // [1] depth staging + copy queued
         // PixelSelector::makeMaps (PixelSelector2.cpp:136-282), a fresh selector per frame: potential 3, one re-selection allowed
@@ -989,7 +1009,7 @@ struct Engine {
             *qc->submitted_host += (unsigned)grid;
             e = K->launch(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl,
                              qc->submitted_dev, qc->started_dev, rawtab);
-            if (e != hipSuccess) *qc->submitted_host -= (unsigned)grid;
+            if (e != hipSuccess) resync_adopt_counters(qc);
         } else {
             e = K->launch(grid, block, tile, rows_cap, y_mode, nm_pad, tab_cols, s, static_cast<const PairDesc*>(d_descs.p), n, G, launch_seq << 16, static_cast<unsigned long long*>(d_queue.p), Pl, nullptr, nullptr, rawtab);
         }
@@ -1135,7 +1155,8 @@ struct Engine {
             *qc->submitted_host += wgs;
             bool sweep_submitted = false;
             e = launch_score(B, more, n, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), s, qc->started_dev, &sweep_submitted);
-            if (!sweep_submitted) *qc->submitted_host -= wgs;       // nothing of it will start
+            if (!sweep_submitted) *qc->submitted_host -= wgs;       // nothing of it will start (the sweep was never handed to the runtime)
+            else if (e != hipSuccess) resync_adopt_counters(qc);
         } else e = launch_score(B, more, n, row_blocks, chunks, P, static_cast<double*>(d_partials.p), static_cast<double*>(h_partials.p), s, nullptr, nullptr);
         if (e != hipSuccess) return fail(CVO_ERR_HIP, std::string("score kernel launch: ") + hipGetErrorString(e));
         score_stream = s; score_pending = n;
@@ -1291,6 +1312,7 @@ struct cvo_handle_s {
     const Cloud* queued_fixed = nullptr; const Cloud* queued_moving = nullptr; float queued_ell = 0.f, queued_tran[12];
     int queued_hits = 0;                                             // score blocks answered by what an alignment had queued
     int shared_hits = 0;                                             // clouds this handle took from last_generated() instead of generating them
+    int staged_hits = 0;                                             // clouds this handle took from a generation started ahead of time (cvo_stage_next_frame)
     bool tail_valid = false;
     double tail_r[5][24];
     const Cloud* tail_fixed = nullptr; const Cloud* tail_moving = nullptr;
@@ -1351,9 +1373,14 @@ int do_align(cvo_handle_s* h, cvo_trace_row* trace, int trace_cap, int* trace_le
         queued = h->eng.score_enqueue(rq, 5, h->eng.last_stream) == CVO_OK;
     }
     rc = queued ? h->eng.wait_align_only() : h->eng.wait(); if (rc) { h->eng.score_pending = 0; return rc; }
-    if (queued) { h->queued_valid = true; h->queued_fixed = h->fixed.get(); h->queued_moving = h->moving.get(); }   // (ell and transform: below, from the result)
     const PairState& r = h->eng.results()[0];
-    if (r.status != CVO_OK) return fail(r.status, "align kernel reported an error (6 = inter-workgroup wait timed out)");
+    if (r.status != CVO_OK) {
+        // the block queued behind a FAILED alignment was computed from that alignment's device state: it answers nobody's question.  Let it leave the
+        // device (the next score launch reuses its buffers) and drop it; the handle keeps the transform and ell of the alignment before.
+        if (queued) { (void)hipStreamSynchronize(h->eng.last_stream); h->eng.score_pending = 0; }
+        return fail(r.status, "align kernel reported an error (6 = inter-workgroup wait timed out)");
+    }
+    if (queued) { h->queued_valid = true; h->queued_fixed = h->fixed.get(); h->queued_moving = h->moving.get(); }   // (ell and transform: below, from the result)
     std::memcpy(h->R, r.R, sizeof(h->R)); std::memcpy(h->T, r.T, sizeof(h->T));
     h->ell = r.ell; h->iter = r.iter; h->A_nonzero = r.A_nonzero;
     Aff prev; std::memcpy(prev.m, r.prev_transform, sizeof(prev.m));
@@ -1446,16 +1473,17 @@ namespace {
 // The frame this thread's last cloud was generated from, byte for byte?  Then `c` becomes a device copy of that cloud (positions + features, selected pixels:
 // 100 KB at 3 k points, queued on the handle's stream) and nothing is generated: 0.22 ms -> the compare of 1.5 MB the staging copy would have read anyway.
 // A different frame differs within the first bytes and costs nothing.
-int take_generated(cvo_handle_s* h, Cloud& c, const unsigned char* bgr8, const unsigned short* depth16, int w, int hh, const cvo_camera& cam, bool* taken) {
+int take_from(const LastGenerated& g, cvo_handle_s* h, Cloud& c, const unsigned char* bgr8, const unsigned short* depth16, int w, int hh, const cvo_camera& cam, bool* taken) {
     *taken = false;
-    LastGenerated& g = last_generated();
-    if (!share_generated_clouds() || !g.cloud || !g.stage || g.device != h->eng.device || g.w != w || g.h != hh || g.num_want != h->num_want ||
+    if (!g.cloud || !g.stage || g.device != h->eng.device || g.w != w || g.h != hh || g.num_want != h->num_want ||
         std::memcmp(&g.cam, &cam, sizeof(cam)) != 0 || !bgr8 || !depth16) return CVO_OK;
     const size_t n = (size_t)w * hh;
-    if (g.stage->stamp.load(std::memory_order_acquire) != g.stamp || g.stage->buf.bytes < 5 * n) return CVO_OK;
-    const unsigned char* st = static_cast<const unsigned char*>(g.stage->buf.p);
-    if (std::memcmp(st, bgr8, 3 * n) != 0 || std::memcmp(st + 3 * n, depth16, 2 * n) != 0) return CVO_OK;
-    if (g.stage->stamp.load(std::memory_order_acquire) != g.stamp) return CVO_OK;
+    {
+        std::lock_guard<std::mutex> lk(g.stage->mu);
+        if (g.stage->stamp.load(std::memory_order_acquire) != g.stamp || g.stage->buf.bytes < 5 * n) return CVO_OK;
+        const unsigned char* st = static_cast<const unsigned char*>(g.stage->buf.p);
+        if (std::memcmp(st, bgr8, 3 * n) != 0 || std::memcmp(st + 3 * n, depth16, 2 * n) != 0) return CVO_OK;
+    }
     const Cloud& src = *g.cloud;
     HIP_TRY(hipSetDevice(h->eng.device));
     c.n = src.n; c.n_px = src.n_px; c.cost_hint = src.cost_hint; c.boxes_valid = false; c.raw = nullptr;
@@ -1468,9 +1496,78 @@ int take_generated(cvo_handle_s* h, Cloud& c, const unsigned char* bgr8, const u
         HIP_TRY(hipMemcpyAsync(c.px.p, src.px.p, (size_t)src.n_px * 2 * sizeof(uint16_t), hipMemcpyDeviceToDevice, h->eng.stream));
     }
     HIP_TRY(hipStreamSynchronize(h->eng.stream));                    // complete when the call returns, as a generated cloud is (any stream may read it next)
-    ++h->shared_hits;
     *taken = true;
     return CVO_OK;
+}
+int take_generated(cvo_handle_s* h, Cloud& c, const unsigned char* bgr8, const unsigned short* depth16, int w, int hh, const cvo_camera& cam, bool* taken) {
+    *taken = false;
+    if (!share_generated_clouds()) return CVO_OK;
+    const int rc = take_from(last_generated(), h, c, bgr8, depth16, w, hh, cam, taken);
+    if (rc == CVO_OK && *taken) ++h->shared_hits;
+    return rc;
+}
+
+// ---- the NEXT frame's cloud, generated ahead of its set_pcd (cvo_stage_next_frame).  The reference's tracker handles a frame strictly in sequence
+// (local_tracker.cpp:356 set_pcd + align, :375 scores, :415 set_pcd + align, :431 scores) and its generator is the first thing each frame waits for; frame t + 1's
+// images do not depend on frame t's alignment, so a caller that has them early hands them over here and goes on with frame t: a worker thread with an engine of
+// its own (own stream, own scratch) runs the generator beside the alignment -- eight workgroups of 256 CUs --, and cvo_set_pcd_images finds the finished cloud by
+// comparing the images byte for byte, as it does for the second object of a frame.  One staged frame per host thread; the images must stay as they are until the
+// cvo_set_pcd_images that takes them (or the next cvo_stage_next_frame) has returned.
+struct FrameStager {
+    Engine eng; bool ready = false;
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    bool quit = false, busy = false, have = false;
+    const unsigned char* bgr = nullptr; const unsigned short* depth = nullptr; int w = 0, h = 0, num_want = 0; cvo_camera cam{};
+    LastGenerated out;              // valid when `have`: the staged frame and its cloud
+    int rc = CVO_OK; std::string err;
+    int start(int device, const cvo_params& prm) {
+        const int r = eng.init(device, prm); if (r) return r;
+        ready = true;
+        th = std::thread([this] { run(); });
+        return CVO_OK;
+    }
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return quit || busy; });
+            if (quit) return;
+            lk.unlock();
+            auto cloud = std::make_shared<Cloud>();
+            const int r = eng.generate_pcd(*cloud, bgr, depth, w, h, cam, num_want);
+            std::string e = r ? g_err : std::string();
+            lk.lock();
+            rc = r; err = e; have = (r == CVO_OK);
+            if (have) {
+                out.stage = eng.img_stage; out.stamp = out.stage->stamp.load(std::memory_order_acquire);
+                out.device = eng.device; out.w = w; out.h = h; out.num_want = num_want; out.cam = cam; out.cloud = cloud;
+            } else out.cloud.reset();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void wait_idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !busy; }); }
+    ~FrameStager() {
+        if (ready) {
+            { std::lock_guard<std::mutex> lk(mu); quit = true; }
+            cv.notify_all();
+            if (th.joinable()) th.join();
+            out.cloud.reset();
+            eng.destroy();
+        }
+    }
+};
+struct StagerOwner { FrameStager* p = nullptr; ~StagerOwner() { delete p; } };
+FrameStager* frame_stager(int device, const cvo_params& prm, int* rc_out) {
+    static thread_local StagerOwner own;
+    *rc_out = CVO_OK;
+    if (own.p && own.p->eng.device != device) { delete own.p; own.p = nullptr; }
+    if (!own.p) {
+        own.p = new FrameStager();
+        const int rc = own.p->start(device, prm);
+        if (rc) { delete own.p; own.p = nullptr; *rc_out = rc; }
+    }
+    frame_stager_slot() = own.p;
+    return own.p;
 }
 }  // namespace
 
@@ -1480,6 +1577,19 @@ int cvo_set_pcd_images(cvo_handle h, const unsigned char* bgr8, const unsigned s
     std::shared_ptr<Cloud>& c = slot_to_fill(h);
     bool taken = false;
     int rc = take_generated(h, *c, bgr8, depth16, width, height, *cam, &taken); if (rc) return rc;
+    if (!taken) {
+        if (FrameStager* fs = frame_stager_slot()) {                  // a frame staged ahead (cvo_stage_next_frame)?  wait for its generation, then compare
+            fs->wait_idle();
+            if (fs->have) {
+                rc = take_from(fs->out, h, *c, bgr8, depth16, width, height, *cam, &taken); if (rc) return rc;
+                if (taken) {
+                    ++h->staged_hits;
+                    if (share_generated_clouds()) last_generated() = fs->out;   // the frame's second object finds it where it looks (take_generated)
+                    fs->have = false; fs->out.cloud.reset();
+                }
+            }
+        }
+    }
     if (!taken) {
         LastGenerated& g = last_generated();
         g.cloud.reset();                                             // (frees the previous frame's cloud unless a handle still holds it)
@@ -1494,6 +1604,23 @@ int cvo_set_pcd_images(cvo_handle h, const unsigned char* bgr8, const unsigned s
     h->A_nonzero = 0;                                                // cvo.cpp:385
     return CVO_OK;
 }
+int cvo_stage_next_frame(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera* cam) {
+    if (!h || !cam || !bgr8 || !depth16) return fail(CVO_ERR_INVALID, "null argument");
+    if (width < 64 || height < 64 || (size_t)width * height > (size_t)1 << 26) return fail(CVO_ERR_INVALID, "image size out of range");
+    int rc = CVO_OK;
+    FrameStager* fs = frame_stager(h->eng.device, h->prm, &rc);
+    if (!fs) return rc;
+    fs->wait_idle();                                                  // (a frame staged before and never asked for: dropped)
+    {
+        std::lock_guard<std::mutex> lk(fs->mu);
+        fs->have = false; fs->out.cloud.reset();
+        fs->bgr = bgr8; fs->depth = depth16; fs->w = width; fs->h = height; fs->num_want = h->num_want; fs->cam = *cam;
+        fs->busy = true;
+    }
+    fs->cv.notify_all();
+    return CVO_OK;
+}
+int cvo_staged_frame_count(cvo_handle h, int* count) { if (!h || !count) return fail(CVO_ERR_INVALID, "null argument"); *count = h->staged_hits; return CVO_OK; }
 int cvo_queued_score_count(cvo_handle h, int* count) { if (!h || !count) return fail(CVO_ERR_INVALID, "null argument"); *count = h->queued_hits; return CVO_OK; }
 int cvo_shared_cloud_count(cvo_handle h, int* count) { if (!h || !count) return fail(CVO_ERR_INVALID, "null argument"); *count = h->shared_hits; return CVO_OK; }
 
@@ -2204,7 +2331,11 @@ constexpr int RCCL_FLOAT = 7;     // ncclFloat32 (rccl.h)
 
 // `send`: a block of records that all carry CVO_ERR_RANK_FAILED, made when the communicator is: what this rank contributes to a gather whose own block
 // could not be prepared (bad arguments, a buffer that would not grow, a fill kernel that would not launch) -- so that the rank still enters the collective.
-struct cvo_comm_s { void* comm = nullptr; int n_ranks = 1, rank = 0, device = 0; DevBuf send; int fallback_records = 0; };
+// own_stream (cvo_comm_set_gather_stream; CVO_HIP_GATHER_STREAM=1 when the communicator is made): every gather of this communicator runs on ONE stream of the
+// communicator's own, behind an event of the align launch it follows, and the launch's stream continues behind the gather's event -- the fallback for a RCCL that
+// does not take collectives of one communicator from several streams at once.
+struct cvo_comm_s { void* comm = nullptr; int n_ranks = 1, rank = 0, device = 0; DevBuf send; int fallback_records = 0;
+                    bool own_stream = false; hipStream_t gstream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr; };
 
 struct cvo_multi_s {
     int n_devices = 0, max_pairs = 0, last_n = 0;
@@ -2253,6 +2384,7 @@ int cvo_comm_create(const char id[CVO_COMM_ID_BYTES], int n_ranks, int rank, int
     void* comm = nullptr;
     RCCL_TRY(g_rccl.CommInitRank(&comm, n_ranks, uid, rank));
     cvo_comm_s* c = new cvo_comm_s(); c->comm = comm; c->n_ranks = n_ranks; c->rank = rank; c->device = device;
+    if (const char* e = std::getenv("CVO_HIP_GATHER_STREAM")) c->own_stream = std::atoi(e) != 0;
     (void)comm_fallback_block(c, COMM_FALLBACK_RECORDS);
     *out = c;
     return CVO_OK;
@@ -2265,6 +2397,7 @@ int cvo_comm_create_all(const int* devices, int n_devices, cvo_comm* out) {
     RCCL_TRY(g_rccl.CommInitAll(comms.data(), n_devices, devices));
     for (int i = 0; i < n_devices; ++i) {
         cvo_comm_s* c = new cvo_comm_s(); c->comm = comms[i]; c->n_ranks = n_devices; c->rank = i; c->device = devices[i];
+        if (const char* e = std::getenv("CVO_HIP_GATHER_STREAM")) c->own_stream = std::atoi(e) != 0;
         if (hipSetDevice(devices[i]) == hipSuccess) (void)comm_fallback_block(c, COMM_FALLBACK_RECORDS);
         out[i] = c;
     }
@@ -2279,9 +2412,23 @@ int cvo_comm_info(cvo_comm c, int* n_ranks, int* rank) {
     if (rank) *rank = r;
     return CVO_OK;
 }
+int cvo_comm_set_gather_stream(cvo_comm c, int on) {
+    if (!c) return fail(CVO_ERR_INVALID, "null communicator");
+    c->own_stream = on != 0; return CVO_OK;
+}
+// where the RCCL this process bound lives on disk (dladdr of ncclAllGather): a torch process resolves librccl.so.1 to torch's bundled copy, a plain C++ caller to /opt/rocm's
+int cvo_comm_library_path(char* out, int cap) {
+    if (!out || cap <= 0) return fail(CVO_ERR_INVALID, "bad argument");
+    out[0] = 0;
+    int rc = rccl_load(); if (rc) return rc;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(g_rccl.AllGather), &info) && info.dli_fname) { std::strncpy(out, info.dli_fname, (size_t)cap - 1); out[cap - 1] = 0; }
+    return CVO_OK;
+}
 int cvo_comm_destroy(cvo_comm c) {
     if (!c) return fail(CVO_ERR_INVALID, "null communicator");
     (void)hipSetDevice(c->device);
+    if (c->gstream) { (void)hipStreamSynchronize(c->gstream); (void)hipStreamDestroy(c->gstream); (void)hipEventDestroy(c->ev_in); (void)hipEventDestroy(c->ev_out); }
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     c->send.release();
     delete c;
@@ -2308,6 +2455,17 @@ bool gather_fallback_plan(cvo_batch b, cvo_comm c, int n_block, void* recv_devic
     return true;
 }
 int gather_post(cvo_comm c, int n_block, void* recv_device, const GatherPlan& plan) {
+    if (c->own_stream) {
+        // launch stream -> event -> the communicator's stream: all-gather -> event -> the launch stream waits for it: whoever waits for the launch's stream
+        // (cvo_batch_wait) still finds every rank's records in place, and the collectives of this communicator are posted to one stream, in call order
+        if (!c->gstream) { HIP_TRY(hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming)); }
+        HIP_TRY(hipEventRecord(c->ev_in, plan.s));
+        HIP_TRY(hipStreamWaitEvent(c->gstream, c->ev_in, 0));
+        RCCL_TRY(g_rccl.AllGather(plan.send, recv_device, (size_t)n_block * CVO_RESULT_FLOATS, RCCL_FLOAT, c->comm, c->gstream));
+        HIP_TRY(hipEventRecord(c->ev_out, c->gstream));
+        HIP_TRY(hipStreamWaitEvent(plan.s, c->ev_out, 0));
+        return CVO_OK;
+    }
     RCCL_TRY(g_rccl.AllGather(plan.send, recv_device, (size_t)n_block * CVO_RESULT_FLOATS, RCCL_FLOAT, c->comm, plan.s));
     return CVO_OK;
 }

@@ -67,6 +67,10 @@ public:
         if (cvo_set_pcd_images(h_, bgr8, depth16, width, height, &cam) != CVO_OK) throw std::runtime_error(std::string("set_pcd: ") + cvo_last_error());
         sync();
     }
+    // not in the reference: the NEXT frame's images, handed over early (cvo_stage_next_frame in include/cvo_hip.h)
+    void stage_next_frame(const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera& cam) {
+        if (cvo_stage_next_frame(h_, bgr8, depth16, width, height, &cam) != CVO_OK) throw std::runtime_error(std::string("stage_next_frame: ") + cvo_last_error());
+    }
     void match_keyframe(const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera& cam, Affine3d& transformd) {
         const int rc = cvo_match_keyframe_images(h_, bgr8, depth16, width, height, &cam, transformd.m);
         if (rc == CVO_ERR_NOT_INITIALIZED) { std::printf("cvo not initialized !\n"); return; }

@@ -791,7 +791,7 @@ template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
 // the depth-proportional list margin at the present ell: skin_alpha at the first ell (0.15, cvo.cpp:35), falling with ell to the power alpha_gamma -- the cloud moves less
 // from iteration to iteration as the alignment converges, and at ell = 0.03 a margin of 0.0125 |x| is as large as the radius itself (DevParams::alpha_gamma)
 __device__ __forceinline__ float list_alpha(const DevParams& P, float ell) {
-    return P.alpha_gamma > 0.f ? P.skin_alpha * __powf(fminf(ell * (1.0f / 0.15f), 1.0f), P.alpha_gamma) : P.skin_alpha;
+    return fminf(P.alpha_gamma > 0.f ? P.skin_alpha * __powf(fminf(ell * (1.0f / 0.15f), 1.0f), P.alpha_gamma) : P.skin_alpha, 0.5f);
 }
 constexpr int PF = 4;                 // list entries a lane evaluates side by side
 constexpr int NCLS = 128;             // list-length classes (ceil(len / PF), the last one open-ended) the rows are sorted by
@@ -1032,7 +1032,8 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     const float mscale = sh->twist_ok ? 1.0f : sh->P.first_scale;
     const float Rb = r_c * (1.0f + sh->P.skin * mscale);
     // row i is listed with radius (Rb + alpha |x_i|) / (1 - alpha) (DevParams::skin_alpha; phase_transform's staleness test is its counterpart)
-    const float alpha = list_alpha(sh->P, sh->ell) * mscale, inv_1ma = 1.0f / (1.0f - alpha);
+    // (alpha well below 1: the row radius (Rb + alpha |x|) / (1 - alpha) and the staleness proof need 1 - alpha > 0; only experiment knobs could push it there)
+    const float alpha = fminf(list_alpha(sh->P, sh->ell) * mscale, 0.5f), inv_1ma = 1.0f / (1.0f - alpha);
     float xmax_l = 0.f;
     // The lists are built around where the cloud is HEADING, not where it is: a list stays valid while every point is within its allowance
     // (skin r + alpha |b_j|) of the position b_j it was listed at, so with b_j a stretch ahead on the path the same radius covers up to twice the

@@ -138,6 +138,17 @@ public:
         ptr_moving_fr.reset(new frame());
         generate_and_upload(RGB_img, dep_img, ptr_moving_fr.get(), CVO_SLOT_MOVING);
     }
+    // NOT a member of the reference's class (optional, off the tracker's call sequence): the NEXT frame's images, handed over while this frame is still
+    // being tracked -- its cloud is then generated beside this frame's keyframe alignment and the next frame's set_pcd finds it (cvo_stage_next_frame in
+    // include/cvo_hip.h; INTEGRATION.md shows the one line in run_SLAM's loop).  The two cv::Mat must stay alive and unchanged until that set_pcd.
+#ifndef CVO_ADAPTOR_CPU_PCD
+    void stage_next_frame(const cv::Mat& RGB_img, const cv::Mat& dep_img) {
+        if (!RGB_img.isContinuous() || !dep_img.isContinuous()) return;                       // (set_pcd would clone them: nothing to recognise later)
+        const cvo_camera cam = {cam_info.scaling_factor, cam_info.fx, cam_info.fy, cam_info.cx, cam_info.cy};
+        if (cvo_stage_next_frame(h_, RGB_img.data, reinterpret_cast<const unsigned short*>(dep_img.data), RGB_img.cols, RGB_img.rows, &cam) != CVO_OK)
+            std::cerr << "cvo stage_next_frame: " << cvo_last_error() << "\n";
+    }
+#endif
     void align() { if (cvo_align(h_) != CVO_OK) std::cerr << "cvo align: " << cvo_last_error() << "\n"; sync(); }   // cvo.cpp:763-821
 
     void match_odometry(const cv::Mat& RGB_img, const cv::Mat& dep_img, Eigen::Affine3d& transformd) {   // cvo.cpp:461-473

@@ -117,6 +117,17 @@ typedef struct cvo_camera { float scaling_factor, fx, fy, cx, cy; } cvo_camera;
 int cvo_set_pcd_images(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height,
                        const cvo_camera* cam);
 int cvo_shared_cloud_count(cvo_handle h, int* count);
+/* Start the generation of a frame's cloud AHEAD of the cvo_set_pcd_images that will ask for it.  The reference handles a frame strictly in sequence
+ * (local_tracker.cpp:356 -> 375 -> 407 -> 415 -> 431) and every frame starts by waiting for its generator (cvo.cpp:348-366); frame t + 1's images do not depend on
+ * frame t's alignments, so a caller that has them (run_SLAM.cpp:70-87 loads the next image right after this one) hands them over here, e.g. between the odometry
+ * block and the keyframe block of frame t, and goes on: a worker thread with a stream and scratch of its own runs the generator beside frame t's keyframe
+ * alignment (eight workgroups of 256 compute units), and frame t + 1's cvo_set_pcd_images -- on this host thread and device, given byte for byte these images,
+ * this camera and the handle's num_want -- takes the finished cloud (waiting for it if need be; then the frame's second object takes its copy as it always did).
+ * Returns at once.  The two images must stay valid and unchanged until that cvo_set_pcd_images (or the next cvo_stage_next_frame) has returned; one frame is
+ * staged per host thread, a frame never asked for is dropped.  Nothing changes in what any call computes: same cloud bits (tests/test_gpu_pcd.py).
+ * cvo_staged_frame_count: how many of this handle's clouds were taken from a staged generation. */
+int cvo_stage_next_frame(cvo_handle h, const unsigned char* bgr8, const unsigned short* depth16, int width, int height, const cvo_camera* cam);
+int cvo_staged_frame_count(cvo_handle h, int* count);
 /* The tracker calls compute_innerproduct(tran = the transform match_* has just returned) behind every alignment (local_tracker.cpp:356-375, 415-431;
  * cvo.cpp:475-503).  An alignment of this handle can start that score block itself -- the score kernel is queued behind the align kernel with the transform
  * and ell taken from the pair's device-resident state, cvo_align returns as soon as the alignment is in, and cvo_compute_innerproduct only collects when it is
@@ -359,6 +370,16 @@ int cvo_comm_create(const char id[CVO_COMM_ID_BYTES], int n_ranks, int rank, int
 int cvo_comm_create_all(const int* devices, int n_devices, cvo_comm* out /* n_devices handles */);
 int cvo_comm_info(cvo_comm c, int* n_ranks, int* rank);                                    /* ncclCommCount / ncclCommUserRank of the communicator */
 int cvo_comm_destroy(cvo_comm c);
+/* ORDER INVARIANT of the gathers: a communicator carries ONE gather per step, and every rank posts its gathers in the same (step) order.  Several may be
+ * outstanding at once, on different streams (each behind the align launch it belongs to: bench.py keeps eight steps in flight), and a rank may post step k's
+ * gather from whichever of its batch objects holds step k -- what has to agree across the ranks is the ORDER of the calls on the communicator, not the batch
+ * object or the stream.  A rank that skips a step, or posts two steps in the other order, pairs its collective with the wrong one of its peers'.
+ * cvo_comm_set_gather_stream(c, 1) (or CVO_HIP_GATHER_STREAM=1 when the communicator is made) posts every gather of the communicator to ONE stream of the
+ * communicator's own instead -- behind an event of the align launch, with the launch's stream continuing behind the gather -- for a RCCL build that does not
+ * take collectives of one communicator from several streams at once; cvo_batch_wait still returns with every rank's records in place.
+ * cvo_comm_library_path: the file the bound RCCL was loaded from (a torch process resolves librccl.so.1 to torch's bundled copy, a C++ caller to /opt/rocm's). */
+int cvo_comm_set_gather_stream(cvo_comm c, int on);
+int cvo_comm_library_path(char* out, int cap);
 int cvo_batch_gather_results(cvo_batch b, cvo_comm c, int n, void* recv_device);
 int cvo_batch_gather_results_padded(cvo_batch b, cvo_comm c, int n_valid, int n_block, int launch_status, void* recv_device);
 /* the block a rank would send (padding / status records in place), for launchers that run their own collective: DEVICE address,

@@ -28,7 +28,20 @@ def test_bare_invocation_starts_its_ranks(hiplib, gpus, total, blocks):
         assert l["world"] == gpus and l["launched_by"] == "bench.py" and l["local_rank"] == l["rank"]
         assert (l["first_pair"], l["pairs"]) == blocks[l["rank"]]
         assert l["block_records"] == max(b[1] for b in blocks)
+        # what the N > 1 line says about the collective: the communicator's size, who gathers, on which streams, and which RCCL file the C ABI bound
+        assert l["ranks_in_communicator"] == gpus and l["gather"] == "rccl" and "one per step in flight" in l["gather_streams"]
+        assert "librccl" in l["rccl_library"], l["rccl_library"]
     assert sum(l["pairs"] for l in lines) == (total or 64 * gpus)
+
+
+def test_the_gather_stream_fallback_is_named_in_the_line(hiplib):
+    out = _run(["--gpus", "2", "--dry-launch"], {"CVO_BENCH_GATHER_STREAM": "1"})
+    assert out.returncode == 0, out.stderr
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all("the communicator's own" in l["gather_streams"] for l in lines)
+    out = _run(["--gpus", "2", "--dry-launch"], {"CVO_BENCH_GATHER": "torch"})
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert all(l["gather"] == "torch" and l["gather_streams"] is None for l in lines)
 
 
 def test_under_an_external_launcher_it_is_one_rank(hiplib):

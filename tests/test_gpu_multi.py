@@ -88,6 +88,33 @@ def _rank_main(rank, world, port, n_pairs, out_dir):
     b.close()
 
 
+def test_gathers_on_the_communicators_own_stream(hiplib):
+    """The fallback mode of include/cvo_hip.h ("ORDER INVARIANT"): every gather of a communicator on one stream of its own, behind an event of the align launch,
+    the launch's stream continuing behind the gather -- two batch objects in flight on their own streams, the records in place when each wait returns."""
+    import torch
+    ca = hiplib
+    from cvo_slam_amd import api
+    assert "librccl" in api.comm_library_path()
+    pairs = _pairs(4, 720)
+    comm = ca.CvoComm(api.comm_unique_id(), 1, 0, device=0)
+    comm.set_gather_stream(True)
+    bs = [ca.CvoBatch(len(pairs)) for _ in range(2)]
+    for b in bs:
+        for i, p in enumerate(pairs):
+            b.set_pair(i, p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat)
+    recvs = [torch.full((len(pairs), api.RESULT_FLOATS), -1.0, dtype=torch.float32, device="cuda") for _ in bs]
+    for rnd in range(3):
+        for b, r in zip(bs, recvs):
+            r.fill_(-1.0); torch.cuda.synchronize()
+            b.reset_states(); b.align_async(len(pairs)); b.gather_results(comm, len(pairs), r.data_ptr())
+        for b, r in zip(bs, recvs):
+            res = b.wait(len(pairs))
+            np.testing.assert_array_equal(r.cpu().numpy(), _records(res))
+    for b in bs:
+        b.close()
+    comm.close()
+
+
 def test_world2_ranks_run_the_hip_path_and_gather(hiplib, tmp_path):
     import torch.multiprocessing as mp
     n_pairs, world = 7, 2

@@ -129,3 +129,50 @@ def test_two_handles_given_one_frame_generate_its_cloud_once(hiplib, oracle):
     b2 = eighth.get_cloud(0); np.testing.assert_array_equal(b[0], b2[0])
     for g in (odo, kf, third, fourth, fifth, sixth, eighth):
         g.close()
+
+
+def test_a_frame_staged_ahead_is_taken_by_the_set_pcd_that_asks_for_it(hiplib, oracle):
+    """cvo_stage_next_frame: frame t + 1's cloud generated on a worker thread while frame t is aligned.  The set_pcd / match_* that is later given those very images takes
+    the staged cloud (identical to the oracle's and to a cloud generated on the spot), the frame's second object takes its copy as always; a frame that differs in a
+    byte, or was never staged, is generated; a staged frame nobody asks for is dropped; nothing about the alignments changes."""
+    from cvo_slam_amd import synth
+    (fa, da), (fb, db), camt, _ = frames(3, synth.TUM1)
+    (fc, dc), _, _, _ = frames(6, synth.TUM1)
+    want_a, want_b, want_c = oracle.pcd_generate(fa, da, camt), oracle.pcd_generate(fb, db, camt), oracle.pcd_generate(fc, dc, camt)
+    # reference run without staging
+    ref_o, ref_k = hiplib.Cvo(), hiplib.Cvo()
+    ref_o.set_pcd_images(fa, da, camt); ref_k.set_pcd_images(fa, da, camt)
+    tf_ref_o = ref_o.match_odometry_images(fb, db, camt); tf_ref_k = ref_k.match_keyframe_images(fb, db, camt)
+    ref_o.update_fixed_pcd(); tf_ref_o2 = ref_o.match_odometry_images(fc, dc, camt)
+    # the same sequence with every next frame staged while the current one is tracked
+    odo, kf = hiplib.Cvo(), hiplib.Cvo()
+    odo.set_pcd_images(fa, da, camt); kf.set_pcd_images(fa, da, camt)
+    odo.stage_next_frame(fb, db, camt)                                                     # frame 1, ahead of its set_pcd
+    tf_o = odo.match_odometry_images(fb, db, camt)
+    assert odo.staged_frame_count() == 1 and odo.shared_cloud_count() == 0
+    odo.stage_next_frame(fc, dc, camt)                                                     # frame 2, staged while frame 1's keyframe alignment runs
+    tf_k = kf.match_keyframe_images(fb, db, camt)                                          # (frame 1's second object: the copy of the thread's last taken frame)
+    assert kf.shared_cloud_count() == 2 and kf.staged_frame_count() == 0
+    check_cloud(hiplib, odo, 1, want_b); check_cloud(hiplib, kf, 1, want_b)
+    np.testing.assert_array_equal(tf_o, tf_ref_o); np.testing.assert_array_equal(tf_k, tf_ref_k)
+    odo.update_fixed_pcd()
+    tf_o2 = odo.match_odometry_images(fc, dc, camt)
+    assert odo.staged_frame_count() == 2
+    check_cloud(hiplib, odo, 1, want_c); np.testing.assert_array_equal(tf_o2, tf_ref_o2)
+    # staged, then asked for with one byte changed: generated, not taken
+    other = hiplib.Cvo()
+    other.stage_next_frame(fa, da, camt)
+    fa2 = fa.copy(); fa2[0, 0, 0] ^= 1
+    other.set_pcd_images(fa2, da, camt)
+    assert other.staged_frame_count() == 0
+    check_cloud(hiplib, other, 0, oracle.pcd_generate(fa2, da, camt))
+    # the staged frame is still there for whoever asks for it; a second staging replaces one nobody asked for
+    again = hiplib.Cvo(); again.set_pcd_images(fa, da, camt)
+    assert again.staged_frame_count() == 1
+    check_cloud(hiplib, again, 0, want_a)
+    again.stage_next_frame(fb, db, camt); again.stage_next_frame(fc, dc, camt)
+    again.set_pcd_images(fb, db, camt)                                                     # fb was dropped: generated here
+    assert again.staged_frame_count() == 1
+    check_cloud(hiplib, again, 1, want_b)
+    for g in (ref_o, ref_k, odo, kf, other, again):
+        g.close()
