@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "cvo_selftest_cubic_step", "cvo_selftest_exp_sek3", "cvo_selftest_dist_se3", "cvo_selftest_libm", "cvo_selftest_pair_values",
     "cvo_function_inner_product_clouds", "cvo_se3_hessian_clouds", "cvo_batch_set_max_workgroups", "cvo_batch_set_adoption", "cvo_batch_last_adoptions", "cvo_batch_last_adoption_retractions",
     "cvo_adaptive_default_params", "cvo_adaptive_align",
-    "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_comm_destroy", "cvo_comm_info", "cvo_comm_set_gather_stream", "cvo_comm_library_path", "cvo_batch_gather_results",
+    "cvo_shard_range", "cvo_comm_unique_id", "cvo_comm_create", "cvo_comm_create_all", "cvo_host_register", "cvo_host_unregister", "cvo_comm_destroy", "cvo_comm_info", "cvo_comm_set_gather_stream", "cvo_comm_library_path", "cvo_batch_gather_results",
     "cvo_gather_results", "cvo_multi_create", "cvo_multi_destroy", "cvo_multi_batch", "cvo_multi_align_async", "cvo_multi_wait",
     "cvo_batch_set_pairs", "cvo_batch_result_records", "cvo_shard_block", "cvo_batch_gather_results_padded", "cvo_batch_padded_records",
     "cvo_compact_records", "cvo_gather_results_padded", "cvo_multi_align_async_v", "cvo_batch_done", "cvo_batch_set_tail_scores", "cvo_batch_last_tail_answers", "cvo_batch_last_pair_seconds", "cvo_batch_last_pair_spans", "cvo_batch_last_tail_seconds", "cvo_set_tail_scores", "cvo_batch_last_cull_masks", "cvo_batch_last_nonzeros",
@@ -201,6 +201,8 @@ def load_library():
     L.cvo_comm_create_all.argtypes = [ip, C.c_int, C.POINTER(vp)]
     L.cvo_comm_destroy.argtypes = [vp]
     L.cvo_comm_info.argtypes = [vp, ip, ip]
+    L.cvo_host_register.argtypes = [vp, C.c_size_t]
+    L.cvo_host_unregister.argtypes = [vp]
     L.cvo_comm_set_gather_stream.argtypes = [vp, C.c_int]
     L.cvo_comm_library_path.argtypes = [C.c_char_p, C.c_int]
     L.cvo_batch_gather_results.argtypes = [vp, vp, C.c_int, vp]
@@ -569,6 +571,17 @@ def compact_records(gathered, n_pairs: int, world: int):
     out = np.zeros((n_pairs, RESULT_FLOATS), np.float32); err = C.c_int(0); fp = C.POINTER(C.c_float)
     _check(load_library().cvo_compact_records(g.ctypes.data_as(fp), n_pairs, world, out.ctypes.data_as(fp), C.byref(err)))
     return out, err.value
+
+
+def host_register(array):
+    """cvo_host_register: pin + map a numpy array's memory; clouds handed over from inside it are read in place (no staging copy)."""
+    a = np.asarray(array)
+    assert a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"]
+    _check(load_library().cvo_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+
+
+def host_unregister(array):
+    _check(load_library().cvo_host_unregister(C.c_void_p(np.asarray(array).ctypes.data)))
 
 
 def comm_library_path() -> str:

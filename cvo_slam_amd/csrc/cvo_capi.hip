@@ -140,6 +140,7 @@ struct Cloud {
     // a hand-over the device has not packed yet: the cloud's arrays as they came (n x 3 positions, then 5 channel-major feature arrays) in
     // the engine's pinned staging ring; the next align launch packs them itself, any other consumer runs the pack kernel first
     mutable const float* raw = nullptr;
+    mutable const float* raw_feat = nullptr;   // with `raw`: the feature arrays when they do not lie right behind the positions (clouds handed over in caller-registered memory)
     float cost_hint = 0.f;          // mean 1/z^2 of a sample of the points (0 = unknown): what a pair costs per iteration follows the density of its clouds
     float* rec() const { return static_cast<float*>(buf.p); }
     ~Cloud() { buf.release(); px.release(); boxes.release(); }
@@ -163,6 +164,20 @@ LastGenerated& last_generated() { static thread_local LastGenerated g; return g;
 struct FrameStager;
 FrameStager*& frame_stager_slot() { static thread_local FrameStager* s = nullptr; return s; }
 bool share_generated_clouds() { static const bool on = [] { const char* e = std::getenv("CVO_HIP_SHARE_CLOUDS"); return !e || std::atoi(e) != 0; }(); return on; }
+
+// Caller-registered host memory (cvo_host_register): clouds handed over from inside such a range are not copied into the staging ring at all -- the align launch that
+// builds their device layout reads them where they are (registered memory is pinned and mapped into the device's address space, like the ring).
+struct HostRange { const unsigned char* lo; const unsigned char* hi; };
+struct HostRegistry { std::mutex mu; std::vector<HostRange> ranges; };
+HostRegistry& host_registry() { static HostRegistry r; return r; }
+bool in_registered_memory(const void* p, size_t bytes) {
+    HostRegistry& r = host_registry();
+    if (r.ranges.empty()) return false;
+    std::lock_guard<std::mutex> lk(r.mu);
+    const unsigned char* q = static_cast<const unsigned char*>(p);
+    for (const HostRange& g : r.ranges) if (q >= g.lo && q + bytes <= g.hi) return true;
+    return false;
+}
 
 // The hand-over's copy into the pinned ring: 12.6 MB per 64-pair step that the host never reads again.  Ordinary stores pull every destination line into the cache first
 // (read-for-ownership) and push the caller's data out of it; non-temporal 16-byte stores write the lines straight through (CVO_HIP_UPLOAD_NT=1; off by default: measured, no difference).
@@ -485,8 +500,9 @@ struct Engine {
         int n_max = 0, q = 0;
         for (Cloud* c : pending) {
             if (!c->raw || c->n <= 0) { c->raw = nullptr; continue; }
-            pd[q].raw_off = (unsigned long long)(c->raw - base); pd[q].dst = c->rec(); pd[q].n = c->n; pd[q].pad_ = 0; ++q;
-            n_max = std::max(n_max, c->n); c->raw = nullptr;
+            pd[q].raw_off = (unsigned long long)(c->raw - base); pd[q].dst = c->rec(); pd[q].n = c->n; pd[q].pad_ = 0;   // (a cloud in registered memory: the difference wraps, base + it is the cloud again)
+            pd[q].feat_off = c->raw_feat ? (unsigned long long)(c->raw_feat - base) : 0ull; ++q;
+            n_max = std::max(n_max, c->n); c->raw = nullptr; c->raw_feat = nullptr;
         }
         pending.clear();
         if (q == 0) return CVO_OK;
@@ -543,14 +559,18 @@ struct Engine {
         struct Piece { const float* src; float* dst; size_t bytes; };
         std::vector<Piece> pieces; pieces.reserve(2 * (size_t)live);
         size_t off = 0; int q = 0;
+        std::vector<char> in_place(count, 0);                          // clouds of a batch that lie in caller-registered memory: read where they are
         for (int k = 0; k < count; ++k) {
             const int n = it[k].n; if (n <= 0) continue;
-            pd[q].raw_off = off; pd[q].dst = it[k].c->rec(); pd[q].n = n; pd[q].pad_ = 0; ++q;
-            pieces.push_back(Piece{it[k].xyz, raw + off, sizeof(float) * 3 * (size_t)n});
-            pieces.push_back(Piece{it[k].feat, raw + off + 3 * (size_t)n, sizeof(float) * 5 * (size_t)n});
+            in_place[k] = defer_pack && inkernel_pack && !ring_mirror && in_registered_memory(it[k].xyz, sizeof(float) * 3 * (size_t)n) && in_registered_memory(it[k].feat, sizeof(float) * 5 * (size_t)n);
+            pd[q].raw_off = off; pd[q].dst = it[k].c->rec(); pd[q].n = n; pd[q].pad_ = 0; pd[q].feat_off = 0; ++q;
+            if (!in_place[k]) {
+                pieces.push_back(Piece{it[k].xyz, raw + off, sizeof(float) * 3 * (size_t)n});
+                pieces.push_back(Piece{it[k].feat, raw + off + 3 * (size_t)n, sizeof(float) * 5 * (size_t)n});
+            }
             off += (size_t)n * REC;
         }
-        const int nthreads = bytes >= ((size_t)2 << 20) ? std::max(1, std::min(upload_threads, (int)pieces.size())) : 1;
+        const int nthreads = (bytes >= ((size_t)2 << 20) && !pieces.empty()) ? std::max(1, std::min(upload_threads, (int)pieces.size())) : 1;
         const bool nt = upload_nt && defer_pack;                     // (a single object's block is copied on by the DMA engine right away: let it come from the cache)
         auto copy_range = [&pieces, nt](size_t a, size_t b) { for (size_t i = a; i < b; ++i) ring_copy(pieces[i].dst, pieces[i].src, pieces[i].bytes, nt); };
         if (nthreads == 1) copy_range(0, pieces.size());
@@ -575,7 +595,9 @@ struct Engine {
             for (int k = 0; k < count; ++k) {
                 const int n = it[k].n; if (n <= 0) continue;
                 if (!it[k].c->raw) pending.push_back(it[k].c);
-                it[k].c->raw = raw + o2; o2 += (size_t)n * REC;
+                if (in_place[k]) { it[k].c->raw = it[k].xyz; it[k].c->raw_feat = it[k].feat; }
+                else { it[k].c->raw = raw + o2; it[k].c->raw_feat = nullptr; }
+                o2 += (size_t)n * REC;
             }
             return CVO_OK;
         }
@@ -867,13 +889,17 @@ struct Engine {
         if (!pending.empty()) {
             if (inkernel_pack && G == 1 && !tails) {
                 if (launched && last_stream) HIP_TRY(hipStreamSynchronize(last_stream));   // an earlier launch of this engine may still read the table
-                if ((rc = h_rawtab.ensure(sizeof(const float*) * 2 * (size_t)n))) return rc;
+                if ((rc = h_rawtab.ensure(sizeof(const float*) * 4 * (size_t)n))) return rc;
                 rawtab = static_cast<const float**>(h_rawtab.p);
                 // (the clouds' raw pointers are host addresses in the ring; with the mirror the kernel gets the same offsets in the device copy)
                 const bool mir = ring_mirror && d_ring.p && d_ring.bytes >= h_stage.bytes && ev_ring;
                 const ptrdiff_t shift = mir ? (static_cast<const unsigned char*>(d_ring.p) - static_cast<const unsigned char*>(h_stage.p)) : 0;
                 auto dev = [&](const float* r) -> const float* { return r ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(r) + shift) : nullptr; };
-                for (int i = 0; i < n; ++i) { rawtab[2 * i] = dev(pairs[i].fixed ? pairs[i].fixed->raw : nullptr); rawtab[2 * i + 1] = dev(pairs[i].moving ? pairs[i].moving->raw : nullptr); }
+                for (int i = 0; i < n; ++i) {                        // {positions, features (null: right behind the positions)} x {fixed, moving}
+                    const Cloud* cf = pairs[i].fixed; const Cloud* cm = pairs[i].moving;
+                    rawtab[4 * i] = dev(cf ? cf->raw : nullptr); rawtab[4 * i + 1] = (cf && cf->raw) ? cf->raw_feat : nullptr;
+                    rawtab[4 * i + 2] = dev(cm ? cm->raw : nullptr); rawtab[4 * i + 3] = (cm && cm->raw) ? cm->raw_feat : nullptr;
+                }
                 if (mir && s != stream) HIP_TRY(hipStreamWaitEvent(s, ev_ring, 0));
             } else if ((rc = flush_pending(s))) return rc;
         }
@@ -1019,7 +1045,7 @@ struct Engine {
         last_stream = s;
         last_tail = tails;
         if (rawtab) {                                                 // those clouds are the kernel's now; the ring has to stay as it is until the launch is over
-            for (int i = 0; i < n; ++i) { if (pairs[i].fixed) pairs[i].fixed->raw = nullptr; if (pairs[i].moving) pairs[i].moving->raw = nullptr; }
+            for (int i = 0; i < n; ++i) { if (pairs[i].fixed) { pairs[i].fixed->raw = nullptr; pairs[i].fixed->raw_feat = nullptr; } if (pairs[i].moving) { pairs[i].moving->raw = nullptr; pairs[i].moving->raw_feat = nullptr; } }
             pending.erase(std::remove_if(pending.begin(), pending.end(), [](Cloud* c) { return c->raw == nullptr; }), pending.end());
             add_ring_reader(s);
         }
@@ -1519,6 +1545,7 @@ struct FrameStager {
     bool quit = false, busy = false, have = false;
     const unsigned char* bgr = nullptr; const unsigned short* depth = nullptr; int w = 0, h = 0, num_want = 0; cvo_camera cam{};
     LastGenerated out;              // valid when `have`: the staged frame and its cloud
+    std::shared_ptr<ImageStage> stages[2]; int flip = 0;
     int rc = CVO_OK; std::string err;
     int start(int device, const cvo_params& prm) {
         const int r = eng.init(device, prm); if (r) return r;
@@ -1533,6 +1560,9 @@ struct FrameStager {
             if (quit) return;
             lk.unlock();
             auto cloud = std::make_shared<Cloud>();
+            // two stages in turn: the frame staged before this one has just been taken (or is about to be), and its second object still compares against ITS images
+            if (!stages[flip]) stages[flip] = std::make_shared<ImageStage>();
+            eng.img_stage = stages[flip]; flip ^= 1;
             const int r = eng.generate_pcd(*cloud, bgr, depth, w, h, cam, num_want);
             std::string e = r ? g_err : std::string();
             lk.lock();
@@ -2039,6 +2069,33 @@ int cvo_batch_set_pairs(cvo_batch b, int first, int count, const float* const* f
     int rc = b->eng.upload_many(items.data(), (int)items.size()); if (rc) return rc;
     for (int k = 0; k < count; ++k) fresh_state(b->init_states[first + k], b->prm.ell);
     b->states_dirty = true;
+    return CVO_OK;
+}
+int cvo_host_register(void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(CVO_ERR_INVALID, "bad argument");
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(CVO_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, ptr, 0) != hipSuccess || d != ptr) {   // the kernels take the caller's own addresses: they must be the device's too
+        (void)hipGetLastError(); (void)hipHostUnregister(ptr);
+        return fail(CVO_ERR_HIP, "registered memory is not addressable by the device at the caller's address");
+    }
+    HostRegistry& r = host_registry();
+    std::lock_guard<std::mutex> lk(r.mu);
+    r.ranges.push_back(HostRange{static_cast<const unsigned char*>(ptr), static_cast<const unsigned char*>(ptr) + bytes});
+    return CVO_OK;
+}
+int cvo_host_unregister(void* ptr) {
+    if (!ptr) return fail(CVO_ERR_INVALID, "null pointer");
+    HostRegistry& r = host_registry();
+    {
+        std::lock_guard<std::mutex> lk(r.mu);
+        auto it = std::find_if(r.ranges.begin(), r.ranges.end(), [&](const HostRange& g) { return g.lo == static_cast<const unsigned char*>(ptr); });
+        if (it == r.ranges.end()) return fail(CVO_ERR_INVALID, "not a range cvo_host_register was given");
+        r.ranges.erase(it);
+    }
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(CVO_ERR_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
     return CVO_OK;
 }
 int cvo_batch_set_state(cvo_batch b, int p, const float R[9], const float T[3], float ell) {

@@ -174,6 +174,8 @@ struct PackDesc {
     unsigned long long raw_off;   // floats from the start of the raw staging buffer: n x 3 positions (AoS, data_type.h:30), then 5 channel-major arrays of n (data_type.h:75)
     float* dst;                   // two planes of n float4
     int n, pad_;
+    unsigned long long feat_off;  // floats from the same start to the 5 channel-major feature arrays; 0 = right behind the positions (raw_off + 3 n).  Not 0 for clouds
+                                  // handed over in caller-registered memory (cvo_host_register), whose two arrays lie where the caller has them
 };
 
 // a score block: up to 8 inner-product / Hessian requests evaluated by one launch

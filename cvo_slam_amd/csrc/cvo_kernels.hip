@@ -2589,12 +2589,15 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
         // The pair's clouds as the caller handed them over (cvo_batch_set_pair(s): n x 3 positions AoS, data_type.h:30, then 5 channel-major
         // feature arrays, data_type.h:75), still in the host's pinned staging ring: this workgroup builds the two float4 planes itself --
         // the points cross PCIe here, once.  (A helper that joins later sees the planes behind the owner's release, like the pair's state.)
-        const float* const raws[2] = {raw_table[2 * p], raw_table[2 * p + 1]};
+        const float* const raws[2] = {raw_table[4 * p], raw_table[4 * p + 2]};          // {positions, features (null: right behind the positions)} of the fixed, then of the moving cloud
+        const float* const rawf[2] = {raw_table[4 * p + 1], raw_table[4 * p + 3]};
         float* const dsts[2] = {const_cast<float*>(Dp->fixed), const_cast<float*>(Dp->moving)};
         const int ns[2] = {nf, nm};
+        // (Staging the positions through LDS -- one coalesced stream over PCIe instead of three strided 4-byte loads per point -- was measured and is 1 % slower:
+        //  profiles/r05_upload_ab.txt.)
         for (int q = 0; q < 2; ++q) {
             const float* xyz = raws[q]; if (!xyz) continue;
-            const int n = ns[q]; const float* feat = xyz + 3 * (size_t)n;
+            const int n = ns[q]; const float* feat = rawf[q] ? rawf[q] : xyz + 3 * (size_t)n;
             for (int i = tid; i < n; i += blockDim.x) {
                 float4 lo, hi;
                 lo.x = xyz[3 * (size_t)i]; lo.y = xyz[3 * (size_t)i + 1]; lo.z = xyz[3 * (size_t)i + 2]; lo.w = feat[i];

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void cvo_pack_clouds_kernel(const float* __res
     const PackDesc D = descs[blockIdx.y];
     const int i0 = blockIdx.x * 256, tid = threadIdx.x;
     if (i0 >= D.n) return;
-    const float* xyz = raw + D.raw_off; const float* feat = xyz + 3 * (size_t)D.n;
+    const float* xyz = raw + D.raw_off; const float* feat = D.feat_off ? raw + D.feat_off : xyz + 3 * (size_t)D.n;
     const int cnt = min(256, D.n - i0);
     for (int k = tid; k < 3 * cnt; k += 256) pos[k] = xyz[3 * (size_t)i0 + k];
     __syncthreads();

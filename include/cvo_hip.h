@@ -276,6 +276,13 @@ int cvo_batch_set_pair(cvo_batch b, int p, const float* fixed_xyz, const float* 
 /* the same for pairs first .. first+count-1 in one hand-over (arrays of `count` pointers / sizes): the clouds' arrays are copied as
  * they are into one pinned staging block, ONE host-to-device copy brings them over and ONE kernel builds the device layout -- the
  * way to hand a whole batch over per step (64 pairs of ~3 k points = 12.6 MB).  The host arrays may be reused when the call returns. */
+/* Caller-registered host memory.  cvo_host_register pins a range of the caller's memory and maps it into the devices' address space (hipHostRegister); clouds that
+ * cvo_batch_set_pair(s) is handed from INSIDE a registered range (both arrays of the cloud) are not copied at all: the align launch that builds their device layout
+ * reads them over PCIe where they lie.  For them -- and only for them -- the arrays must stay valid and unchanged until that launch has been waited for (cvo_batch_wait);
+ * everything else about the calls is unchanged, and clouds outside registered ranges are staged as before (cvo.cpp:345-386 copies its inputs too).  Register once, e.g.
+ * the pool a frame grabber or dataset reader fills; cvo_host_unregister before the memory is freed. */
+int cvo_host_register(void* ptr, size_t bytes);
+int cvo_host_unregister(void* ptr);
 int cvo_batch_set_pairs(cvo_batch b, int first, int count, const float* const* fixed_xyz, const float* const* fixed_feat, const int* n_fixed,
                         const float* const* moving_xyz, const float* const* moving_feat, const int* n_moving);
 /* warm start / carried ell for pair p (reset_initial + Q1) */

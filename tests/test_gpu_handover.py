@@ -158,3 +158,54 @@ def test_done_polls_without_blocking_and_the_record_table_is_on_the_device(hipli
         np.testing.assert_array_equal(rec[i, :12].reshape(3, 4), r["transform"])
         assert (int(rec[i, 12]), int(rec[i, 13]), int(rec[i, 14]), int(rec[i, 15])) == (r["iter"], r["A_nonzero"], r["iterations_run"], r["status"])
     b.close()
+
+
+def test_clouds_in_registered_memory_are_read_in_place(hiplib):
+    """cvo_host_register: clouds handed over from inside a registered range are not staged -- the align launch reads them where they lie (one workgroup per
+    pair), or the pack kernel does (cooperative launches, score blocks).  Same results as the staged hand-over; a batch may mix both kinds; the caller may
+    rewrite the arrays between steps (waited-for launches have read them)."""
+    from cvo_slam_amd import synth, api
+    pairs = [synth.make_small_pair(60 + i, n=[900, 333, 1500, 64, 2048][i]) for i in range(5)]
+    clouds = [(p.fixed.xyz, p.fixed.feat, p.moving.xyz, p.moving.feat) for p in pairs]
+    ref = hiplib.CvoBatch(len(clouds)); ref.set_pairs(clouds)
+    want = ref.align(len(clouds))
+    # one arena for all arrays of pairs 0 .. 3 (pair 4 stays in ordinary memory: a mixed hand-over)
+    total = sum(a.size for c in clouds[:4] for a in c)
+    arena = np.zeros(total + 64, np.float32)
+    views, off = [], 0
+    for c in clouds[:4]:
+        vs = []
+        for a in c:
+            v = arena[off: off + a.size].reshape(a.shape); v[...] = a; off += a.size; vs.append(v)
+        views.append(tuple(vs))
+    api.host_register(arena)
+    try:
+        mixed = views + [clouds[4]]
+        for wgs in (1, 4):                                             # in-kernel packing (G = 1) and the pack kernel (cooperative launch)
+            b = hiplib.CvoBatch(len(clouds)); b.set_workgroups(wgs)
+            b.set_pairs(mixed)
+            got = b.align(len(clouds))
+            for x, y in zip(want, got):
+                assert x["status"] == y["status"] == 0 and x["iter"] == y["iter"] and x["A_nonzero"] == y["A_nonzero"]
+                np.testing.assert_array_equal(x["transform"], y["transform"])
+            b.close()
+        # rewrite: pair k's slot now holds a cloud of the same shape scaled away from the camera a little; results follow the new content
+        b = hiplib.CvoBatch(1)
+        b.set_pairs([views[0]]); r0 = b.align(1)[0]
+        views[0][2][...] = clouds[0][2] + np.float32(0.004)            # moving cloud shifted by 4 mm
+        b.set_pairs([views[0]]); r1 = b.align(1)[0]
+        plain = hiplib.CvoBatch(1); plain.set_pairs([(clouds[0][0], clouds[0][1], clouds[0][2] + np.float32(0.004), clouds[0][3])]); r2 = plain.align(1)[0]
+        np.testing.assert_array_equal(r0["transform"], want[0]["transform"])
+        np.testing.assert_array_equal(r1["transform"], r2["transform"])
+        assert not np.array_equal(r0["transform"], r1["transform"])
+        b.close(); plain.close()
+    finally:
+        api.host_unregister(arena)
+    # unregistered again: staged like any memory
+    c = hiplib.CvoBatch(4); c.set_pairs(views)
+    views[1][2][...] = 0                                               # (staged: the caller may scribble right away)
+    got = c.align(4)
+    np.testing.assert_array_equal(got[1]["transform"], want[1]["transform"])
+    with pytest.raises(hiplib.CvoError):
+        api.host_unregister(arena)
+    ref.close(); c.close()
