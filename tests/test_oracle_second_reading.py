@@ -133,3 +133,38 @@ def test_second_reading_gates_match_the_survey_figures():
     # d2_thres(ell) = 0.446287 ell^2; d2_c_thres = 386 265
     s2, d2, d2c = sr.gates(f32(0.15))
     assert abs(float(d2) / 0.15 ** 2 - 0.446287) < 1e-4 and abs(float(d2c) - 386265) < 2
+
+
+def test_second_reading_on_a_full_size_pair(oracle):
+    """The same stages on the benchmark's shape (tests/golden/tum_pair_0.npz: 3 072 x 3 072 points, ~1e5 members of A at ell = 0.15): the first iterations and one at
+    every later length-scale, each from the oracle's own pose at that iteration, with the oracle's association of 3-term sums."""
+    g = np.load(os.path.join(GOLDEN, "tum_pair_0.npz"))
+    x, fx, p, fp = g["fixed_xyz"], g["fixed_feat"], g["moving_xyz"], g["moving_feat"]
+    o = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=4)
+    o.set_pcd(x, fx); o.set_pcd(p, fp)
+    rc, tr = o.align(trace_cap=400)
+    assert rc == 0
+    np.testing.assert_array_equal([r["nnz"] for r in tr], g["trace_nnz"])       # (the oracle is the one that wrote the fixture)
+    old = sr.ASSOC3
+    sr.ASSOC3 = "unrolled"
+    try:
+        for k in (0, 1, 5, 12, len(tr) - 2):
+            pr = oracle.default_params(); pr.max_iter = k
+            ok = oracle.OracleCvo(params=pr, search=oracle.SEARCH_KDTREE, threads=4)
+            ok.set_pcd(x, fx); ok.set_pcd(p, fp)
+            assert ok.align()[0] == 0
+            s = ok.get_state()
+            row = tr[k]; ell = f32(row["ell"])
+            y, _, _ = sr.transform_cloud(s["R"].astype(f32), s["T"].astype(f32), p)
+            A, keep = sr.se_kernel(x, fx, y, fp, ell)
+            omega, v, nnz, fmags = sr.compute_flow(x, y, A)
+            assert nnz == row["nnz"], f"iteration {k}: nnz(A) {nnz} vs the oracle's {row['nnz']}"
+            got = np.concatenate([omega, v]).astype(np.float64); want = np.concatenate([row["omega"], row["v"]]).astype(np.float64)
+            assert np.all(np.abs(got - want) <= 3e-7 * fmags + 1e-30), (k, got, want)
+            BCDE, mags = sr.step_terms(x, y, A, keep, row["omega"].astype(f32), row["v"].astype(f32), ell)
+            for q, nm in enumerate("BCDE"):
+                # (up to 1e5 terms that cancel to a thousandth of their magnitudes, added in float64 in two different orders)
+                assert abs(BCDE[q] - row["BCDE"][q]) <= 1e-9 * abs(row["BCDE"][q]) + 1e-10 * mags[q], f"iteration {k}: {nm} {BCDE[q]} vs {row['BCDE'][q]}"
+            _close(sr.choose_step(row["BCDE"]), row["step"], 1e-6, "step", k)
+    finally:
+        sr.ASSOC3 = old
