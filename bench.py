@@ -826,7 +826,7 @@ def main():
         prof_ms = prof_file = None                       # rocprofv3 --kernel-trace --stats of this command, committed: its average must agree with kernel_ms
         try:
             import csv
-            prof_file = "profiles/r04_kernel_stats.csv" if args.shape == "tum" else "profiles/r04_eth3d_kernel_stats.csv"
+            prof_file = "profiles/r05_kernel_stats.csv" if args.shape == "tum" else "profiles/r05_eth3d_kernel_stats.csv"
             with open(os.path.join(ROOT, prof_file), newline="") as f:
                 for row in csv.DictReader(f):
                     if "cvo_align_kernel" in row.get("Name", ""):

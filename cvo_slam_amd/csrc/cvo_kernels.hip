@@ -1500,10 +1500,23 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
             for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<(NT && ENT_NT(YM))>(at_off(eb1, (unsigned)lane + (unsigned)u * rp));
         }
         for (int n0 = 0; n0 < lw; n0 += PF) {
-            if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
             v4u en4[PF / 2];
+#ifndef CVO_ALWAYS_PREFETCH
+            // the next step's entries -- when there is a next step.  (The last step of a block used to fetch entries nobody reads and to wait for them at its end:
+            // in the light iterations, where a block is one step, every step ended with a round trip to memory.)
+            if (n0 + PF < lw) {
+                eo += estep;
+#pragma unroll
+                for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<(NT && ENT_NT(YM))>(at_off(eb, eo + (unsigned)u * rp));
+            } else {
+#pragma unroll
+                for (int u = 0; u < PF / 2; ++u) en4[u] = eq4[u];
+            }
+#else
+            if (n0 + 2 * PF <= c.capn) eo += estep;                 // the prefetch stays inside the lists (the last step re-reads its own entries)
 #pragma unroll
             for (int u = 0; u < PF / 2; ++u) en4[u] = ld_ent2<(NT && ENT_NT(YM))>(at_off(eb, eo + (unsigned)u * rp));
+#endif
             v2u eq[PF];
 #pragma unroll
             for (int u = 0; u < PF / 2; ++u) { eq[2 * u].x = eq4[u].x; eq[2 * u].y = eq4[u].y; eq[2 * u + 1].x = eq4[u].z; eq[2 * u + 1].y = eq4[u].w; }
