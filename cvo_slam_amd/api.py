@@ -279,8 +279,8 @@ def selftest_dist_se3(dR_dT, device: int = 0):
 
 
 def selftest_libm(x, device: int = 0):
-    """The device's float routines element by element: (n, 5) = OCML sinf, cosf, logf, then the correctly rounded sine and cosine of exp_sek3."""
-    a = np.ascontiguousarray(x, np.float32).reshape(-1); out = np.zeros((a.shape[0], 5), np.float32)
+    """The device's float routines element by element: (n, 6) = OCML sinf, cosf, logf, then the correctly rounded sine, cosine (exp_sek3) and logarithm (gates)."""
+    a = np.ascontiguousarray(x, np.float32).reshape(-1); out = np.zeros((a.shape[0], 6), np.float32)
     fp = C.POINTER(C.c_float)
     _check(load_library().cvo_selftest_libm(device, a.shape[0], a.ctypes.data_as(fp), out.ctypes.data_as(fp)))
     return out

@@ -1998,7 +1998,7 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
 int cvo_selftest_cubic_step(int device, int n, const float* coef_minstep, float* step_out) { return selftest(device, 0, n, coef_minstep, 5, step_out, 1); }
 int cvo_selftest_exp_sek3(int device, int n, const float* omega_v_dt, float* dR_dT_out) { return selftest(device, 1, n, omega_v_dt, 7, dR_dT_out, 12); }
 int cvo_selftest_dist_se3(int device, int n, const float* dR_dT, float* dist_out) { return selftest(device, 2, n, dR_dT, 12, dist_out, 1); }
-int cvo_selftest_libm(int device, int n, const float* x, float* out5) { return selftest(device, 3, n, x, 1, out5, 5); }
+int cvo_selftest_libm(int device, int n, const float* x, float* out6) { return selftest(device, 3, n, x, 1, out6, 6); }
 int cvo_selftest_pair_values(int device, const cvo_params* params, float ell, int n, const float* y_g, float* a_out, float* d2_d2c_out) {
     int rc = check_device(device, nullptr); if (rc) return rc;
     if (n <= 0 || !y_g || !a_out || !(ell > 0.f)) return fail(CVO_ERR_INVALID, "bad self-test arguments");

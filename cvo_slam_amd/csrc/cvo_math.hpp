@@ -54,10 +54,13 @@ CVO_HD void apply_transform(const float* M, float p0, float p1, float p2, float&
 }
 
 // gates, cvo.cpp:125-126 (se_kernel: log(sp/s2)) and :395-396 (scores: log(sp/sigma/sigma)).
-// std::log(float) is what the reference's overload resolution picks => logf.
-CVO_HD float gate_d2_align(float l, float sp_thres, float s2) { return (float)(-2.0 * l * l * (double)logf(sp_thres / s2)); }
-CVO_HD float gate_d2_score(float l, float sp_thres, float sigma) { return (float)(-2.0 * l * l * (double)logf(sp_thres / sigma / sigma)); }
-CVO_HD float gate_d2c(float c_ell, float sp_thres, float c_sigma) { return (float)(-2.0 * c_ell * c_ell * (double)logf(sp_thres / c_sigma / c_sigma)); }
+// std::log(float) is what the reference's overload resolution picks: the float logarithm of ITS libm, which differs between libms in the last bit (the
+// device's OCML logf and glibc's differ on 39 % of a sample of arguments, by up to 2 ulps: tests/test_gpu_pair_values.py).  Device, host and oracle take the
+// correctly rounded float -- the double routine rounded once -- as for sin / cos; for the reference's constants that is glibc's value too.
+CVO_HD float log_f32_cr(float x) { return (float)log((double)x); }
+CVO_HD float gate_d2_align(float l, float sp_thres, float s2) { return (float)(-2.0 * l * l * (double)log_f32_cr(sp_thres / s2)); }
+CVO_HD float gate_d2_score(float l, float sp_thres, float sigma) { return (float)(-2.0 * l * l * (double)log_f32_cr(sp_thres / sigma / sigma)); }
+CVO_HD float gate_d2c(float c_ell, float sp_thres, float c_sigma) { return (float)(-2.0 * c_ell * c_ell * (double)log_f32_cr(sp_thres / c_sigma / c_sigma)); }
 
 // poly_solver + root selection for 4E t^3 + 3D t^2 + 2C t + B (cvo.cpp:76-92,317-333).
 // The reference takes f32 eigenvalues of the companion matrix of the monic cubic

@@ -31,12 +31,12 @@ __global__ void selftest_dist_kernel(const float* __restrict__ in, float* __rest
 }
 
 // the device's float routines where the epilogue and the gates call them (OCML: sinf, cosf in exp_sek3 -- LieGroup.cpp:174-175 --, logf in the gates,
-// cvo.cpp:125-126), element by element: out[5 i ..] = {sinf(x), cosf(x), logf(x), sin_f32_cr(x), cos_f32_cr(x)} -- the last two are what exp_sek3 calls
+// cvo.cpp:125-126), element by element: out[6 i ..] = {sinf(x), cosf(x), logf(x), sin_f32_cr(x), cos_f32_cr(x), log_f32_cr(x)} -- the last three are what exp_sek3 and the gates call
 __global__ void selftest_libm_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = in[i];
-    out[i * 5 + 0] = sinf(x); out[i * 5 + 1] = cosf(x); out[i * 5 + 2] = logf(x); out[i * 5 + 3] = sin_f32_cr(x); out[i * 5 + 4] = cos_f32_cr(x);
+    out[i * 6 + 0] = sinf(x); out[i * 6 + 1] = cosf(x); out[i * 6 + 2] = logf(x); out[i * 6 + 3] = sin_f32_cr(x); out[i * 6 + 4] = cos_f32_cr(x); out[i * 6 + 5] = log_f32_cr(x);
 }
 
 hipError_t launch_selftest(int kind, const float* in, float* out, int n, hipStream_t s) {

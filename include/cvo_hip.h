@@ -238,15 +238,15 @@ int cvo_selftest_cubic_step(int device, int n, const float* coef_minstep, float*
 int cvo_selftest_exp_sek3(int device, int n, const float* omega_v_dt, float* dR_dT_out);
 int cvo_selftest_dist_se3(int device, int n, const float* dR_dT, float* dist_out);
 /*   libm:       the device's float routines element by element: OCML's sinf, cosf, logf (logf: the gates, cvo.cpp:125-126) and the correctly rounded
- *               float sine and cosine Exp_SEK3 is evaluated with (LieGroup.cpp:174-175; cvo_math.hpp: sin_f32_cr, cos_f32_cr)
- *               in: n floats   out: n x {sinf, cosf, logf, sin_f32_cr, cos_f32_cr}
+ *               float sine and cosine Exp_SEK3 is evaluated with (LieGroup.cpp:174-175; cvo_math.hpp: sin_f32_cr, cos_f32_cr) and the correctly rounded logarithm of the
+ *               gates (log_f32_cr)     in: n floats   out: n x {sinf, cosf, logf, sin_f32_cr, cos_f32_cr, log_f32_cr}
  *   pair_values: the pair arithmetic of se_kernel (cvo.cpp:166-175) by the four routes the align kernel has for it, for n pairs {fixed point at the
  *               origin with zero features; moving point y[3] with features g[5]} at length-scale `ell`:   in: n x {y0, y1, y2, g0, g1, g2, g3, g4}
  *               out: n x {a by the branchy full evaluation (dense fallback), a with the colour factor made once per list entry (lists outside the
  *               polynomial's range), a by the branch-free 12-term chain, a by the degree-7 polynomial with its rounding guard (the steady walk)} --
  *               a = 0 for a pair that is not a member of A; d2_d2c_out (may be NULL): n x {d2, d2c} as the device formed them.
  *               tests/test_gpu_pair_values.py: all four bit-equal to the oracle's (float)(s2*exp(-d2/(2.0*l*l))) sequence on >= 1e7 samples. */
-int cvo_selftest_libm(int device, int n, const float* x, float* out5);
+int cvo_selftest_libm(int device, int n, const float* x, float* out6);
 int cvo_selftest_pair_values(int device, const cvo_params* params /* NULL = defaults */, float ell, int n, const float* y_g, float* a_out, float* d2_d2c_out);
 
 /* ======================= batched alignment (independent frame pairs) ===========

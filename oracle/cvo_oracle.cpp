@@ -44,6 +44,10 @@
 #include <omp.h>
 #endif
 
+// log(float) of the reference is its libm's float logarithm (cvo.cpp:125-126, 395-396); libms differ in its last bit, so oracle, host and device take the
+// correctly rounded float: the double routine rounded once (cvo_math.hpp: log_f32_cr).  For the reference's constants glibc's logf gives the same floats.
+static inline float log_cr(float x) { return (float)std::log((double)x); }
+
 namespace {
 
 // ---------------------------------------------------------------- small algebra
@@ -299,9 +303,9 @@ void se_kernel_clouds(orc_cvo* o, const float* a_xyz, const Cloud& A, const floa
     const int N = A.n, M = B.n;
     const int feat_order = (o->variant & ORC_VAR_FEAT_HADD) ? 1 : ((o->variant & ORC_VAR_FEAT_MOVEHL) ? 2 : 0);
     // float d2_thres = -2.0*l*l*log(sp_thres/s2);            cvo.cpp:125
-    const float d2_thres = (float)(-2.0 * l * l * (double)std::log(P.sp_thres / s2));
+    const float d2_thres = (float)(-2.0 * l * l * (double)log_cr(P.sp_thres / s2));
     // float d2_c_thres = -2.0*c_ell*c_ell*log(sp_thres/c_sigma/c_sigma);   cvo.cpp:126
-    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)std::log(P.sp_thres / P.c_sigma / P.c_sigma));
+    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)log_cr(P.sp_thres / P.c_sigma / P.c_sigma));
 
     const auto tk0 = std::chrono::steady_clock::now();
     KdTree tree; const KdTree* tp = nullptr;
@@ -499,8 +503,8 @@ static int cubic_real_roots(double a, double b, double c, double* roots) {
 void orc_pair_values(const orc_params* p, float ell, int n, const float* d2v, const float* d2cv, float* a_out, float* k_out, float* ck_out) {
     const orc_params& P = *p;
     const float l = ell, s2 = P.sigma * P.sigma;                                        // se_kernel(ell, sigma*sigma), cvo.cpp:189
-    const float d2_thres = (float)(-2.0 * l * l * (double)std::log(P.sp_thres / s2));   // cvo.cpp:125
-    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)std::log(P.sp_thres / P.c_sigma / P.c_sigma));   // cvo.cpp:126
+    const float d2_thres = (float)(-2.0 * l * l * (double)log_cr(P.sp_thres / s2));   // cvo.cpp:125
+    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)log_cr(P.sp_thres / P.c_sigma / P.c_sigma));   // cvo.cpp:126
     for (int i = 0; i < n; ++i) {
         const float d2 = d2v[i], d2_color = d2cv[i];
         const float k = (float)(s2 * std::exp(-d2 / (2.0 * l * l)));                    // cvo.cpp:172
@@ -518,7 +522,7 @@ void orc_pair_values(const orc_params* p, float ell, int n, const float* d2v, co
 void orc_libm_f32(int kind, int n, const float* in, float* out) {
     for (int i = 0; i < n; ++i)
         out[i] = kind == 0 ? std::sin(in[i]) : kind == 1 ? std::cos(in[i]) : kind == 2 ? std::log(in[i])                    // the float overloads
-               : kind == 3 ? (float)std::sin((double)in[i]) : (float)std::cos((double)in[i]);                                // the correctly rounded floats (Exp_SEK3 here)
+               : kind == 3 ? (float)std::sin((double)in[i]) : kind == 4 ? (float)std::cos((double)in[i]) : log_cr(in[i]);      // the correctly rounded floats (Exp_SEK3, the gates)
 }
 
 extern "C" float orc_cubic_step(float c3, float c2, float c1, float c0, float min_step) {
@@ -858,8 +862,8 @@ extern "C" int orc_adaptive_align(const orc_adaptive_params* ap, const float* fi
 static orc_inn_p fip_impl(orc_cvo* o, const std::vector<float>& a_xyz, const Cloud& a, const Cloud& b) {
     const orc_params& P = o->p;
     const float ell = o->ell, sigma = P.sigma;
-    const float d2_thres = (float)(-2.0 * ell * ell * (double)std::log(P.sp_thres / sigma / sigma));            // cvo.cpp:395
-    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)std::log(P.sp_thres / P.c_sigma / P.c_sigma));   // cvo.cpp:396
+    const float d2_thres = (float)(-2.0 * ell * ell * (double)log_cr(P.sp_thres / sigma / sigma));            // cvo.cpp:395
+    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)log_cr(P.sp_thres / P.c_sigma / P.c_sigma));   // cvo.cpp:396
     KdTree tree; const KdTree* tp = nullptr;
     if (o->search_mode == ORC_SEARCH_KDTREE) { tree.build(b.xyz.data(), b.n); tp = &tree; }
     const int feat_order = (o->variant & ORC_VAR_FEAT_HADD) ? 1 : ((o->variant & ORC_VAR_FEAT_MOVEHL) ? 2 : 0);
@@ -941,8 +945,8 @@ static void hessian_impl(orc_cvo* o, const std::vector<float>& a_xyz, const Clou
                          double Hout[36], int* inliers_out, double* H_raw_f64) {
     const orc_params& P = o->p;
     const float ell = o->ell, sigma = P.sigma;
-    const float d2_thres = (float)(-2.0 * ell * ell * (double)std::log(P.sp_thres / sigma / sigma));
-    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)std::log(P.sp_thres / P.c_sigma / P.c_sigma));
+    const float d2_thres = (float)(-2.0 * ell * ell * (double)log_cr(P.sp_thres / sigma / sigma));
+    const float d2_c_thres = (float)(-2.0 * P.c_ell * P.c_ell * (double)log_cr(P.sp_thres / P.c_sigma / P.c_sigma));
     KdTree tree; const KdTree* tp = nullptr;
     if (o->search_mode == ORC_SEARCH_KDTREE) { tree.build(b.xyz.data(), b.n); tp = &tree; }
     const int feat_order = (o->variant & ORC_VAR_FEAT_HADD) ? 1 : ((o->variant & ORC_VAR_FEAT_MOVEHL) ? 2 : 0);

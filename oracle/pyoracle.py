@@ -311,7 +311,7 @@ def pair_values(d2, d2c, ell, params: Params | None = None):
 def libm_f32(kind: str, x):
     """glibc sinf / cosf / logf element by element (kind 'sin', 'cos', 'log'); 'sin_cr', 'cos_cr': the correctly rounded floats of the oracle's Exp_SEK3."""
     a, ap = _f(x); out = np.zeros_like(a)
-    lib().orc_libm_f32({"sin": 0, "cos": 1, "log": 2, "sin_cr": 3, "cos_cr": 4}[kind], a.size, ap, out.ctypes.data_as(C.POINTER(C.c_float)))
+    lib().orc_libm_f32({"sin": 0, "cos": 1, "log": 2, "sin_cr": 3, "cos_cr": 4, "log_cr": 5}[kind], a.size, ap, out.ctypes.data_as(C.POINTER(C.c_float)))
     return out
 
 

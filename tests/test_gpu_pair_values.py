@@ -150,18 +150,21 @@ def test_device_float_routines(hiplib, oracle):
     Exp_SEK3's sine and cosine (LieGroup.cpp:174-175; dt * theta with step <= 0.8 and |omega| from the stop threshold 5e-5 up to a few tenths, and
     larger arguments for the other branch): the reference calls its libm's float routines, whose last bit differs between libms, so oracle and device
     both take the correctly rounded float (cvo_math.hpp: sin_f32_cr, cos_f32_cr; oracle: the double routine rounded once) -- they must agree bit for
-    bit.  What that choice replaces is measured beside it: glibc's sinf / cosf and OCML's against the correctly rounded value.  logf (the gates,
-    cvo.cpp:125-126, 395-396): OCML's against glibc's, exact on the three gate arguments of the default parameters."""
+    bit.  What that choice replaces is measured beside it: glibc's sinf / cosf and OCML's against the correctly rounded value.  The logarithm of the gates
+    (cvo.cpp:125-126, 395-396) likewise: log_f32_cr on the device against the oracle's, bit for bit; OCML's and glibc's logf beside it (the three gate arguments of the
+    default parameters give the same floats in all three)."""
     from cvo_slam_amd import api as ca
     rng = np.random.default_rng(11)
     x = np.concatenate([np.exp(rng.uniform(np.log(1e-7), np.log(0.5), 2_000_000)), rng.uniform(0, 0.5, 1_000_000), rng.uniform(0.5, 6.5, 200_000),
                         -rng.uniform(0, 1.0, 100_000)]).astype(f32)
     dev = ca.selftest_libm(x)
     report = {}
-    for col, kind in ((3, "sin_cr"), (4, "cos_cr")):
-        ref = oracle.libm_f32(kind, x)
-        bad = np.nonzero(dev[:, col].view(np.uint32) != ref.view(np.uint32))[0]
-        assert bad.size == 0, f"{kind}: {bad.size} of {x.size} arguments differ; first x = {x[bad[0]]!r}: device {dev[bad[0], col]!r}, oracle {ref[bad[0]]!r}"
+    xl = np.concatenate([rng.uniform(1e-4, 1.0, 500_000), np.exp(rng.uniform(np.log(1e-6), np.log(10.0), 500_000))]).astype(f32)   # arguments of the gates' logarithm: sp / s2 and the like
+    devl6 = ca.selftest_libm(xl)
+    for col, kind, arg, out in ((3, "sin_cr", x, dev), (4, "cos_cr", x, dev), (5, "log_cr", xl, devl6)):
+        ref = oracle.libm_f32(kind, arg)
+        bad = np.nonzero(out[:, col].view(np.uint32) != ref.view(np.uint32))[0]
+        assert bad.size == 0, f"{kind}: {bad.size} of {arg.size} arguments differ; first x = {arg[bad[0]]!r}: device {out[bad[0], col]!r}, oracle {ref[bad[0]]!r}"
     small = np.abs(x) < 1e-3                                                            # where a converging alignment's dt * theta lives
     for col, kind in ((0, "sin"), (1, "cos")):
         cr = oracle.libm_f32(kind + "_cr", x); gl = oracle.libm_f32(kind, x)
@@ -174,8 +177,11 @@ def test_device_float_routines(hiplib, oracle):
     args = np.array([f32(p.sp_thres) / (f32(p.sigma) * f32(p.sigma)), f32(p.sp_thres) / f32(p.sigma) / f32(p.sigma),
                      f32(p.sp_thres) / f32(p.c_sigma) / f32(p.c_sigma)], f32)
     more = np.concatenate([args, rng.uniform(1e-4, 1.0, 500_000).astype(f32)])
-    devl = ca.selftest_libm(more)[:, 2]
-    ref = oracle.libm_f32("log", more)
-    assert np.array_equal(devl[:3].view(np.uint32), ref[:3].view(np.uint32)), (devl[:3], ref[:3])   # the gates of the default parameters: the same bits
-    assert _ulps(devl, ref).max() <= 2
-    print("logf, OCML against glibc:", int((devl != ref).sum()), "of", more.size, "arguments differ (by at most", int(_ulps(devl, ref).max()), "ulp)")
+    d6 = ca.selftest_libm(more); devl = d6[:, 2]
+    ref = oracle.libm_f32("log", more); cr = oracle.libm_f32("log_cr", more)
+    # the gates of the default parameters: glibc's logf, OCML's and the correctly rounded value (what device, host and oracle use) are the same floats
+    assert np.array_equal(devl[:3].view(np.uint32), ref[:3].view(np.uint32)) and np.array_equal(cr[:3].view(np.uint32), ref[:3].view(np.uint32)), (devl[:3], ref[:3], cr[:3])
+    assert np.array_equal(d6[:, 5].view(np.uint32), cr.view(np.uint32))
+    assert _ulps(devl, ref).max() <= 2 and _ulps(ref, cr).max() <= 1
+    print("logf: OCML against glibc", int((devl != ref).sum()), "of", more.size, "arguments differ (by at most", int(_ulps(devl, ref).max()), "ulp); glibc against the correctly rounded value",
+          int((ref != cr).sum()))
