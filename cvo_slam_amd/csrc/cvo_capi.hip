@@ -270,7 +270,7 @@ DevParams to_dev(const cvo_params& p) {
     d.overlap_stop_test = 1;
     d.predict = 0.7f; d.predict_steps = 8.f;   // lists built / filtered 0.7 of every point's allowance ahead on the path: -10 % culls, +1 % (profiles/r04_predicted_list_centres.txt)
     d.resort = 1;
-    d.adopt_kmax = 20; d.adopt_on = 0; d.adopt_inject = 0;
+    d.adopt_kmax = 20; d.adopt_on = 0; d.adopt_inject = 0; d.adopt_dwell = 0;
     d.colocate = 1;
     return d;
 }
@@ -430,6 +430,7 @@ struct Engine {
         if (const char* e = std::getenv("CVO_HIP_WIDE")) { wide_waves = std::atoi(e) != 0; wide_all = std::atoi(e) >= 2; }
         if (const char* e = std::getenv("CVO_HIP_ADOPT_KMAX")) P.adopt_kmax = std::max(0, std::atoi(e));
         if (const char* e = std::getenv("CVO_HIP_ADOPT_INJECT")) P.adopt_inject = std::atoi(e);
+        if (const char* e = std::getenv("CVO_HIP_ADOPT_DWELL_US")) P.adopt_dwell = std::max(0, std::min(100000, std::atoi(e))) * 100;
         if (const char* e = std::getenv("CVO_HIP_ADOPT")) adopt = std::atoi(e) != 0;
         if (const char* e = std::getenv("CVO_HIP_TILE")) tile_request = std::atoi(e);
         if (const char* e = std::getenv("CVO_HIP_WGS")) wg_request = std::atoi(e);
@@ -1965,7 +1966,7 @@ int cvo_adaptive_align(int device, const cvo_adaptive_params* p_in, const float*
     A.trace = want_trace ? static_cast<AdaptiveRow*>(d_trace.p) : nullptr; A.trace_cap = want_trace ? trace_cap : 0; A.trace_len = static_cast<int*>(d_len.p);
     A.ell_min = ap.ell_min; A.dl_step = ap.dl_step;
     A.P.sigma = ap.sigma; A.P.sp_thres = ap.sp_thres; A.P.c = ap.c; A.P.d = ap.d; A.P.c_ell = ap.c_ell; A.P.c_sigma = ap.c_sigma;
-    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.skin_alpha = 0.f; A.P.alpha_gamma = 0.f; A.P.first_scale = 1.f; A.P.fuse_refine = 0; A.P.nt_min = 0; A.P.overlap_stop_test = 0; A.P.predict = 0.f; A.P.predict_steps = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.colocate = 0;
+    A.P.min_step = ap.min_step; A.P.eps = ap.eps; A.P.eps_2 = ap.eps_2; A.P.max_iter = ap.max_iter; A.P.skin = 0.f; A.P.skin_alpha = 0.f; A.P.alpha_gamma = 0.f; A.P.first_scale = 1.f; A.P.fuse_refine = 0; A.P.nt_min = 0; A.P.overlap_stop_test = 0; A.P.predict = 0.f; A.P.predict_steps = 0.f; A.P.resort = 0; A.P.adopt_kmax = 0; A.P.adopt_on = 0; A.P.adopt_inject = 0; A.P.adopt_dwell = 0; A.P.colocate = 0;
     A.partials = static_cast<double*>(d_part.p);
     // a few iterations are queued at a time (five small kernels each, the rows of the sweeps spread over the device); kernels queued behind a
     // stop return at once, and the host looks at the stop flag between the chunks

@@ -38,6 +38,9 @@ struct DevParams {           // cvo.cpp:35-51
     int adopt_on;            // set per launch by the host: finished workgroups of this launch may help with its pairs that still run (one workgroup and one slot per pair)
     int adopt_inject;        // test knob (CVO_HIP_ADOPT_INJECT): 1 = a helper whose offer has been accepted leaves instead of confirming -- the owner must take the
                              // acceptance back and carry on with the members it has
+    int adopt_dwell;         // adoption: a finished workgroup offers its help only when nothing has been queued on the device for this long (ticks of 10 ns; 0 = at once):
+                             // a caller that resubmits as launches complete leaves the queue dry for a moment each time, and a helper that joins then holds its CU
+                             // for the rest of the pair while the next launch's workgroups wait for one (CVO_HIP_ADOPT_DWELL_US)
 };
 
 // per-pair state, read at kernel start and written back at the end (Q1, Q2)

@@ -2857,8 +2857,17 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             // a pair of the launch that still runs alone and offer to help; leave when there is none.
             if (tid < 64) {                                           // wave 0: a lane per slot looks, lane 0 asks
                 int found = -1; unsigned kj = 0;
-                const unsigned sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                unsigned sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sub == sta && P.adopt_dwell > 0) {                // dry right now: is it the end of the job, or the moment between a completion and the caller's next launch?
+                    const unsigned long long t_dry = __builtin_amdgcn_s_memrealtime();
+                    while (__builtin_amdgcn_s_memrealtime() - t_dry < (unsigned long long)P.adopt_dwell) {
+                        __builtin_amdgcn_s_sleep(64);
+                        sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (sub != sta) break;                        // new work has been queued: leave, its workgroups want this CU
+                    }
+                }
                 for (int attempt = 0; attempt < 4 && found < 0 && sub == sta; ++attempt) {
                     // the pair that runs alone and has the most left to do, as far as one can tell: the one with the fewest iterations behind it
                     unsigned key = 0xFFFFFFFFu;                     // iteration << 12 | slot
