@@ -66,6 +66,37 @@ namespace CVO_KNS {
 #define CVO_BLOCK_MAX 512         // threads of the largest workgroup: 512 = 2 waves per SIMD with 256 VGPRs each.  (1024 = 4 waves per SIMD with 128 each
 #endif                            //  is an experiment knob: measured, no phase gets faster -- DESIGN.md "Measured in round 2")
 constexpr int BLOCK_MAX = CVO_BLOCK_MAX;
+// Phases are functions of their own (own register allocation).  CVO_INLINE_PHASES: a bit mask of phases compiled INTO run_pair instead (experiment builds):
+// 1 line search, 2 epilogue, 4 transform (all three measured: run_pair then spills around its remaining calls), 8 below -- a call costs the callee-saved
+// saves and, at its return, a wait for their reloads from scratch
+#ifndef CVO_INLINE_PHASES
+#if CVO_BLOCK_MAX > 512
+#define CVO_INLINE_PHASES 0       // the three-wave build (168 registers): the merged function spills inside its loops
+#else
+#define CVO_INLINE_PHASES 8       // measured: +1.2 % in the long run, -2.2 % on one pair's latency (profiles/r05_one_call_per_iteration_ab.txt)
+#endif
+#endif
+#define CVO_PHASE_FN(bit) static __device__ __attribute__((CVO_PHASE_ATTR_##bit))
+#if CVO_INLINE_PHASES & 8     // 8: candidate walk + line search + epilogue compiled into ONE function, phase_iteration (one call per iteration instead of three)
+#define CVO_PHASE_ATTR_8 always_inline
+#else
+#define CVO_PHASE_ATTR_8 noinline
+#endif
+#if CVO_INLINE_PHASES & (1 | 8)
+#define CVO_PHASE_ATTR_1 always_inline
+#else
+#define CVO_PHASE_ATTR_1 noinline
+#endif
+#if CVO_INLINE_PHASES & (2 | 8)
+#define CVO_PHASE_ATTR_2 always_inline
+#else
+#define CVO_PHASE_ATTR_2 noinline
+#endif
+#if CVO_INLINE_PHASES & 4
+#define CVO_PHASE_ATTR_4 always_inline
+#else
+#define CVO_PHASE_ATTR_4 noinline
+#endif
 constexpr int MAX_WAVES = BLOCK_MAX / 64;
 constexpr unsigned ADOPT_FREE = 0u, ADOPT_REQUEST = 1u, ADOPT_ACCEPT = 2u, ADOPT_CLOSED = 3u, ADOPT_CONFIRMED = 4u;   // states of a pair's adoption word (cvo_align_kernel)
 constexpr unsigned long long ADOPT_CONFIRM_TICKS = 5000ull;   // 50 us at 100 MHz: how long an owner waits for an accepted helper to confirm before it takes the acceptance back
@@ -85,6 +116,7 @@ struct __attribute__((aligned(16))) Shared {
     float ell;
     float step;
     float M[12];
+    float Mn[12];          // the next iteration's transform while lane 0's second stop test may still fire (transform_body_t, the epilogue's call)
     float Mb[12];          // the transform the candidate lists were built (or last filtered) under
     float Rb;              // radius they were built with: its part that is the same for every row, r (1 + skin)
     float alpha_build;     // ... and the depth-proportional part of the margin they were built (or last filtered) with: row i holds every column within
@@ -116,6 +148,7 @@ struct __attribute__((aligned(16))) Shared {
     int resort;            // this refinement re-sorts the rows by their new list lengths (phase_refine)
     int resort_pending;    // ... asked for by a candidate walk that filtered the lists on its way; done before the next iteration's walk (phase_resort)
     int fused;             // list refinements made by a candidate walk on its way (diagnostics)
+    float rc, rc_ell;      // gate radius sqrt(gate_d2_align(ell)) and the ell it was worked out for (transform_body_t; rc_ell < 0: none yet)
     float reach_now;       // this iteration's reach (phase_transform), for the candidate walk that makes the next ell's lists
     int cull_next;         // next block pair of the cull to hand out
     int ws_slot;           // pair slot of the launch whose work buffers this workgroup uses (its own, or the one of the pair it helps with)
@@ -141,6 +174,7 @@ struct __attribute__((aligned(16))) Shared {
     unsigned long long nnz_total;   // nonzeros of A so far (PairState::nonzeros_total)
 #ifdef CVO_KTRACE
     unsigned long long ksub[4];  // experiment builds: line-search walk, line-search reduction, epilogue scalar part, epilogue transform (ticks, this iteration)
+    unsigned long long kabs[12];  // CVO_KTRACE_EPI == 2: absolute times inside the epilogue (lane 0: part A done, part B done, staleness maximum there, decision made; thread 64: past the first barrier, its points done)
 #endif
     float omega[3];        // this iteration's twist (f32, cvo.cpp:234-235)
     float v[3];
@@ -320,6 +354,19 @@ __device__ __forceinline__ float block_max(float v, Shared* sh, int tid, int nwa
     for (int w = 1; w < nwaves; ++w) m = fmaxf(m, sh->fred[w]);
     __syncthreads();
     return m;
+}
+
+// maximum over the wave of a value that is >= 0 in every lane (its bits then order like the numbers), wave-uniform: four DPP exchanges inside the rows
+// of 16 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: a maximum does not care who its partners are), then the four rows' values through
+// scalar registers -- no LDS round trip
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int x = (int)__float_as_uint(v);
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false));
+    const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return __uint_as_float((unsigned)max(max(a, b), max(c, d)));
 }
 
 // exclusive prefix sum of one int per thread over the workgroup; total returned to every thread
@@ -924,24 +971,36 @@ constexpr int PRE_T = 4096 / BLOCK_MAX;
 // known; if the iteration turns out to be the pair's last, cvo::transform of that iteration (Shared::M, cvo.cpp:815) stays.
 // preb (may be null): for the pre-loaded points, {where the point was listed (Mb p), alpha_build x its distance from the camera there}: that half of the
 // staleness test does not depend on the new pose, the epilogue works it out while lane 0 is at the step and the pose update.
+// v_sqrt_f32 as it is (1 ulp; sqrtf is the IEEE sequence around it, ten instructions more): for the staleness bounds, which carry a margin of 1e-4
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 template <int YM>
 __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Shared* sh, const float4 (&pre)[PRE_T], bool have_pre, int first_worker = 0, bool keep_M_on_stop = false,
                                                  bool have_preb = false, const float4* preb = nullptr) {
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int wstride = nthreads - first_worker;
-    float M[12];
-    {
+    // first_worker > 0 (the epilogue's call): the threads below it have no points -- wave 0, whose lane 0 comes from the second stop test and is the one everybody
+    // would wait for.  It touches nothing here that it does not need: the transform is made (and kept for the next phases) by the workers.
+    const bool worker = tid >= first_worker;
+    const bool have_list = sh->list_valid != 0;
+    float M[12], Mb[12];
+    if (worker) {
         float R[9], T[3];
 #pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = sh->R[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) T[i] = sh->T[i];
         make_transform(R, T, M);                                    // update_tf, cvo.cpp:770
-    }
-    const bool have_list = sh->list_valid != 0;
-    float Mb[12];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) Mb[i] = sh->Mb[i];
+        for (int i = 0; i < 12; ++i) M[i] = 0.f;
+    }
+    if (worker && have_list && !have_preb) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Mb[i] = sh->Mb[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Mb[i] = 0.f;
+    }
     // how much closer a pair can be now than when the lists were built: the largest displacement of a point since then, less the part of it the lists of
     // its neighbourhood allow for by themselves (alpha_build x its distance from the camera at build time; 0 with one margin for all rows)
     float dmax = 0.f;
@@ -957,40 +1016,72 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
             if (have_b) { b0 = bq.x; b1 = bq.y; b2 = bq.z; afar = bq.w; }
             else {
                 apply_transform(Mb, lo.x, lo.y, lo.z, b0, b1, b2);
-                afar = alpha_b * (sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f);
+                afar = alpha_b * (fast_sqrt(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f);
             }
             const float e0 = y0 - b0, e1 = y1 - b1, e2 = y2 - b2;
-            const float disp = sqrtf(__builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0))) * 1.0001f + 1.0e-5f;
+            const float disp = fast_sqrt(__builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0))) * 1.0001f + 1.0e-5f;
             dmax = fmaxf(dmax, disp - afar);
         }
     };
-    int j = tid >= first_worker ? tid - first_worker : c.nm;
+    int j = worker ? tid - first_worker : c.nm;
     if (have_pre) {
 #pragma unroll
         for (int u = 0; u < PRE_T; ++u) { if (j < c.nm) one(j, pre[u], have_preb, have_preb ? preb[u] : make_float4(0.f, 0.f, 0.f, 0.f)); j += wstride; }
     }
     for (; j < c.nm; j += wstride) one(j, ld4(c.moving + lo_off(j)), false, make_float4(0.f, 0.f, 0.f, 0.f));
-    dmax = block_max(dmax, sh, tid, nwaves);                        // also makes ybuf / ylds visible to the workgroup
+#if defined(CVO_KTRACE_EPI) && CVO_KTRACE_EPI == 2
+    if (tid == 64) { __builtin_amdgcn_sched_barrier(0); sh->kabs[5] = CVO_NOW() + (dmax == 12345.f ? 1 : 0); }
+#endif
+    // What lane 0's decision needs besides the maximum is in its registers before the barrier; the new transform is kept for the next phases by the first worker
+    // (in Shared::Mn when lane 0's second stop test may still fire: Shared::M stays the transform of the last executed iteration then).
+    float r_c = 0.f, Rb_l = 0.f, ell_b = 0.f, skin_l = 0.f, ell = 0.f;
+    int dense_l = 0;
     if (tid == 0) {
-        const float ell = sh->ell;
-        const float r_c = sqrtf(gate_d2_align(ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma));
+        ell = sh->ell; Rb_l = sh->Rb; ell_b = sh->ell_build; skin_l = sh->P.skin; dense_l = sh->dense_mode;
+        if (sh->rc_ell == ell) r_c = sh->rc;                        // the gate radius of this ell (a double-precision log): once per ell, not per iteration
+        else { r_c = sqrtf(gate_d2_align(ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma)); sh->rc = r_c; sh->rc_ell = ell; }
+    }
+    if (tid == first_worker) {
+        float* Mdst = keep_M_on_stop ? sh->Mn : sh->M;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Mdst[i] = M[i];
+    }
+    // the workgroup's maximum with ONE barrier: only lane 0 needs it, and the barrier that publishes its decision closes the phase anyway
+    if (worker) { dmax = wave_max_nonneg(dmax); if ((tid & 63) == 0) sh->fred[tid >> 6] = dmax; }
+    else if ((tid & 63) == 0) sh->fred[tid >> 6] = 0.f;
+#if defined(CVO_KTRACE_EPI) && CVO_KTRACE_EPI == 2
+    if (tid == 0) { __builtin_amdgcn_sched_barrier(0); sh->kabs[8] = CVO_NOW(); }
+    if (tid == 64) { __builtin_amdgcn_sched_barrier(0); sh->kabs[9] = CVO_NOW(); }
+#endif
+    __syncthreads();                                                // (also makes ybuf / ylds visible to the workgroup)
+#if defined(CVO_KTRACE_EPI) && CVO_KTRACE_EPI == 2
+    if (tid == 0) { __builtin_amdgcn_sched_barrier(0); sh->kabs[2] = CVO_NOW() + (dmax == 12345.f ? 1 : 0); }
+#endif
+    if (keep_M_on_stop && tid < 12) { if (!sh->stop) sh->M[tid] = sh->Mn[tid]; }   // (wave 0: it sees lane 0's sh->stop, LDS operations of one wave complete in order)
+    if (tid == 0) {
+        unsigned mx = 0u;
+#pragma unroll
+        for (int w = 0; w < MAX_WAVES; ++w) { const unsigned f = __float_as_uint(sh->fred[w]); mx = max(mx, w < nwaves ? f : 0u); }   // (>= 0: the bits order like the numbers)
+        dmax = __uint_as_float(mx);
         // Row i's list holds every column within (Rb + a |x_i|) / (1 - a) of it at the build positions (a = alpha_build).  A pair within r_c now was
         // within D < r_c + (its point's displacement) <= r_c + reach + a |y_j| <= r_c + reach + a (|x_i| + D) then: inside the list while
         // r_c + reach <= Rb.  (a = 0: the lists hold every pair within Rb, reach = the largest displacement.)
         const float reach = have_list ? dmax : 1.0e-5f;
         sh->reach_now = reach;
-        int rb = (!have_list || (sh->ell_build != ell) || (r_c + reach) * 1.00001f > sh->Rb) ? 1 : 0;
+        int rb = (!have_list || (ell_b != ell) || (r_c + reach) * 1.00001f > Rb_l) ? 1 : 0;
         // ell has dropped (cvo.cpp:810-812) and the old, wider lists still hold every pair within the NEW list radius of the
         // current positions: filter them in place instead of a dense cull (2 = refine).  Not in dense mode (no lists to filter).
         // With new radii (Rn + a' |x_i|) / (1 - a') =: Rn_i the old lists must hold D < Rn_i + reach + a (|x_i| + D), i.e. Rn_i + reach <= Rb for the
         // farthest row: that bounds the depth-proportional margin a' the filtered lists can have.
-        const float Rn = r_c * (1.0f + sh->P.skin);
-        if (rb && have_list && !sh->dense_mode && sh->ell_build != ell && (Rn + reach) * 1.00001f <= sh->Rb) {
+        const float Rn = r_c * (1.0f + skin_l);
+        if (rb && have_list && !dense_l && ell_b != ell && (Rn + reach) * 1.00001f <= Rb_l) {
             rb = 2;
             sh->reach = reach;                                      // phase_refine works the margins of the filtered lists out from it
         }
         sh->rebuild = rb;
-        if (!(keep_M_on_stop && sh->stop)) for (int i = 0; i < 12; ++i) sh->M[i] = M[i];
+#if defined(CVO_KTRACE_EPI) && CVO_KTRACE_EPI == 2
+        __builtin_amdgcn_sched_barrier(0); sh->kabs[3] = CVO_NOW() + (sh->rebuild == 12345 ? 1 : 0);
+#endif
     }
     __syncthreads();
 }
@@ -1004,7 +1095,7 @@ static __device__ __noinline__ void transform_large(const PairDesc* Dp_in, int g
     for (int u = 0; u < PRE_T; ++u) none[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (y_lds == 2) transform_body_t<2>(c, L, L.sh, none, false); else transform_body_t<0>(c, L, L.sh, none, false);
 }
-static __device__ __noinline__ void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
+CVO_PHASE_FN(4) void phase_transform(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in);
     const Lds L = lds_layout(tgeo, y_lds);
     const Ctx c = make_ctx(Dp, g, G);
@@ -1927,7 +2018,7 @@ static __device__ __noinline__ void phase_resort(const PairDesc* Dp_in, int g_in
     __syncthreads();
 }
 
-static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
+CVO_PHASE_FN(8) void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
@@ -2089,7 +2180,7 @@ static __device__ __noinline__ void phase_candidates(const PairDesc* Dp_in, int 
 }
 
 // ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
-static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
+CVO_PHASE_FN(1) void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
@@ -2206,7 +2297,7 @@ static __device__ __noinline__ void phase_linesearch(const PairDesc* Dp_in, int 
 }
 
 // ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
-static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in, int max_iter_in) {
+CVO_PHASE_FN(2) void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in, int max_iter_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in), max_iter = uni(max_iter_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
@@ -2234,7 +2325,7 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         for (int u = 0; u < PRE_T; ++u) {
             float b0, b1, b2;
             apply_transform(Mb, pre[u].x, pre[u].y, pre[u].z, b0, b1, b2);
-            preb[u] = make_float4(b0, b1, b2, alpha_b * (sqrtf(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f));
+            preb[u] = make_float4(b0, b1, b2, alpha_b * (fast_sqrt(__builtin_fmaf(b2, b2, __builtin_fmaf(b1, b1, b0 * b0))) * 0.9999f));
         }
     }
     // Lane 0's scalar work in two parts with a workgroup barrier between them (every wave passes it once): A = step, first stop test, pose update -- what the
@@ -2272,9 +2363,15 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         sh->stop = 0;
 #ifdef CVO_KTRACE_EPI
         __builtin_amdgcn_sched_barrier(0); sh->ksub[1] = CVO_NOW() - kq0 - sh->ksub[0];
+#if CVO_KTRACE_EPI == 2
+        sh->kabs[0] = CVO_NOW();
+#endif
 #endif
     }
     __syncthreads();                                                 // R, T are out
+#if defined(CVO_KTRACE_EPI) && CVO_KTRACE_EPI == 2
+    if (threadIdx.x == 64) sh->kabs[4] = CVO_NOW();
+#endif
     if (threadIdx.x == 0) {
 #ifdef CVO_KTRACE_EPI
         const unsigned long long kq2 = CVO_NOW();
@@ -2311,6 +2408,9 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
         }
 #ifdef CVO_KTRACE_EPI
         __builtin_amdgcn_sched_barrier(0); sh->ksub[2] = CVO_NOW() - kq2 + (dist == 12345.f ? 1 : 0);
+#if CVO_KTRACE_EPI == 2
+        sh->kabs[1] = CVO_NOW();
+#endif
 #endif
     }
 #ifdef CVO_KTRACE
@@ -2329,11 +2429,37 @@ static __device__ __noinline__ void phase_epilogue(const PairDesc* Dp_in, int g_
 #ifdef CVO_KTRACE
 #ifdef CVO_KTRACE_EPI
     if (threadIdx.x == 0) sh->ksub[3] = CVO_NOW() - ke0;
+#if CVO_KTRACE_EPI == 2     // times from the end of lane 0's part A: part B done | thread 64 past the barrier | its points done | lane 0 has the staleness maximum | decision made | end
+    if (threadIdx.x == 0) {
+        const unsigned long long a = sh->kabs[0], e = CVO_NOW();
+        sh->ksub[0] = a - ke0; sh->ksub[1] = sh->kabs[1] - a; sh->ksub[2] = sh->kabs[5] - a; sh->ksub[3] = sh->kabs[2] - a;
+        sh->kabs[6] = sh->kabs[3] - a; sh->kabs[7] = e - a; sh->kabs[4] = sh->kabs[4] - a; sh->kabs[10] = sh->kabs[8] - a; sh->kabs[11] = sh->kabs[9] - a;
+    }
+#endif
 #else
     if (threadIdx.x == 0) { sh->ksub[2] = ke1 - ke0; sh->ksub[3] = CVO_NOW() - ke1; }
 #endif
 #endif
 }
+
+#if CVO_INLINE_PHASES & 8
+// one iteration's three regular phases as ONE function: a phase call costs its callee-saved saves (the line search keeps ~50 constants in callee-saved scalar
+// registers, the candidate walk uses two dozen callee-saved vector registers) and, at its return, a wait for their reloads from scratch memory
+static __device__ __noinline__ void phase_iteration(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in, int max_iter_in) {
+    Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
+    const int tid = threadIdx.x;
+    unsigned long long t_prev = CVO_NOW();
+    phase_candidates(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in);
+    if (tid == 0) { atomicAdd(&sh->cand_total, (unsigned long long)sh->cand); atomicAdd(&sh->nnz_total, (unsigned long long)sh->nnz); }
+    { const unsigned long long t_now = CVO_NOW(); if (tid == 0) atomicAdd(&sh->ticks[1], t_now - t_prev); t_prev = t_now; }
+    if (sh->status != 0) return;
+    phase_linesearch(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in);
+    { const unsigned long long t_now = CVO_NOW(); if (tid == 0) atomicAdd(&sh->ticks[3], t_now - t_prev); t_prev = t_now; }
+    if (sh->status != 0) return;
+    phase_epilogue(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in, max_iter_in);
+    { const unsigned long long t_now = CVO_NOW(); if (tid == 0) atomicAdd(&sh->ticks[5], t_now - t_prev); }
+}
+#endif
 
 // ---- Tail: the tracker's score block (cvo::compute_innerproduct, cvo.cpp:475-503) for the pair this workgroup has just aligned, from
 // what is resident anyway.  inn_post = fip(T moving, fixed) and se3_Hessian(T moving, fixed) (cvo.cpp:491, 500) are sums over the pairs
@@ -2689,6 +2815,11 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
             else { __syncthreads(); if (tid == 0) sh->resort_pending = 0; __syncthreads(); }   // (the lists have been rebuilt or filtered again meanwhile)
         }
         CVO_PHASE(0);
+#if CVO_INLINE_PHASES & 8
+        phase_iteration(Dp, ge, Ge, tgeo, y_lds, k, max_iter);
+        t_prev = CVO_NOW();
+        if (sh->status != 0) break;
+#else
         phase_candidates(Dp, ge, Ge, tgeo, y_lds, k);
         if (tid == 0) { atomicAdd(&sh->cand_total, (unsigned long long)sh->cand); atomicAdd(&sh->nnz_total, (unsigned long long)sh->nnz); }
         CVO_PHASE(1);
@@ -2698,6 +2829,7 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
         if (sh->status != 0) break;
         phase_epilogue(Dp, ge, Ge, tgeo, y_lds, k, max_iter);
         CVO_PHASE(5);
+#endif
 #ifdef CVO_KTRACE   // experiment builds only: the trace row's B..E carry this iteration's phase times (100 MHz ticks) instead
         if (tid == 0 && ge == 0 && Dp->trace && k < Dp->trace_cap) {
             TraceRow& tr = Dp->trace[k];
@@ -2707,6 +2839,9 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
             // omega = candidate phase (prologue, row walk, wait + reduction), v = line-search walk, its reduction, epilogue scalar part; step = fused transform
             tr.omega[0] = (float)(sh->sub[0] - ksub_prev[0]); tr.omega[1] = (float)(sh->sub[1] - ksub_prev[1]); tr.omega[2] = (float)(sh->sub[2] - ksub_prev[2]);
             tr.v[0] = (float)sh->ksub[0]; tr.v[1] = (float)sh->ksub[1]; tr.v[2] = (float)sh->ksub[2]; tr.step = (float)sh->ksub[3];
+#if defined(CVO_KTRACE_EPI) && CVO_KTRACE_EPI == 2
+            tr.omega[0] = (float)sh->kabs[6]; tr.omega[1] = (float)sh->kabs[7]; tr.omega[2] = (float)sh->kabs[4]; tr.ell = (float)sh->kabs[10]; tr.dist = (float)sh->kabs[11];
+#endif
             for (int q = 0; q < 4; ++q) ksub_prev[q] = sh->sub[q];
             for (int q = 0; q < 10; ++q) kt_prev[q] = ticks[q];
         }
@@ -2833,7 +2968,7 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
     // "is anything queued on the device?" (adoption): every workgroup the library submits counts itself as started, whatever kind of launch it belongs to
     if (wgs_started != nullptr && tid == 0) atomicAdd(wgs_started, 1u);
     if (slot >= slots) return;                                      // gridDim.x is a multiple of G; defensive
-    if (tid == 0) { sh->P = P; sh->skin0 = P.skin; sh->alpha0 = P.skin_alpha; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
+    if (tid == 0) { sh->rc_ell = -1.f; sh->P = P; sh->skin0 = P.skin; sh->alpha0 = P.skin_alpha; sh->launch_tag = launch_tag; sh->rows_cap = rows_cap; sh->y_cap = y_cap; sh->tab_cols = tab_cols; }
     __syncthreads();                                                // (run_pair reads the parameters from there)
     const bool adopting = wgs_started != nullptr && P.adopt_on != 0;   // set by the host for launches of one workgroup and one slot per pair
     const int tgeo = pack_geometry(tile, rows_cap, y_cap);
