@@ -562,16 +562,25 @@ def main():
                         return k
         return inflight[0]
 
+    host_prof = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get("CVO_BENCH_HOSTPROF") else None   # development aid: host seconds in pick / finish / reset_states / align_async, steps
+
     def step(i):
+        tp0 = time.perf_counter()
         bi = pick()
+        tp1 = time.perf_counter()
         if bi in inflight:                         # the object is reused: its previous step must be complete first
             inflight.remove(bi); finish(bi)
+        tp2 = time.perf_counter()
         b = batches[bi]
         launch_status[bi] = 0
         if n:
             try:
                 b.reset_states()                   # every step starts from R=I, T=0, ell=0.15
+                tp3 = time.perf_counter()
                 b.align_async(n)
+                if host_prof is not None:
+                    tp4 = time.perf_counter()
+                    host_prof[0] += tp1 - tp0; host_prof[1] += tp2 - tp1; host_prof[2] += tp3 - tp2; host_prof[3] += tp4 - tp3; host_prof[4] += 1
             except ca.CvoError as e:               # the rank still enters the collective below: its records carry the status
                 launch_status[bi] = e.code
         # the 64-byte records are written by the align kernel itself; every rank sends n_block of them (its own, then padding)
@@ -612,6 +621,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed_rank = elapsed
+    if host_prof is not None and host_prof[4]:
+        print("[bench] host us per step since start (pick, finish, reset_states, align_async): " + ", ".join(f"{1e6 * x / host_prof[4]:.1f}" for x in host_prof[:4]) + f" over {host_prof[4]} steps", file=sys.stderr, flush=True)
     assert len(kernel_ms) == args.steps
     if n == 0:                                     # a rank without pairs (fewer pairs than ranks): it only takes part in the gathers
         kernel_ms[:] = [0.0]

@@ -149,6 +149,8 @@ struct __attribute__((aligned(16))) Shared {
     int resort_pending;    // ... asked for by a candidate walk that filtered the lists on its way; done before the next iteration's walk (phase_resort)
     int fused;             // list refinements made by a candidate walk on its way (diagnostics)
     float rc, rc_ell;      // gate radius sqrt(gate_d2_align(ell)) and the ell it was worked out for (transform_body_t; rc_ell < 0: none yet)
+    float inv_c, inv_d;    // 1 / P.c, 1 / P.d and ...
+    unsigned long long gates_store[10];   // ... struct Gates of rc_ell: the candidate phase's constants (two double-precision logs, a float log, four divisions) once per ell
     float reach_now;       // this iteration's reach (phase_transform), for the candidate walk that makes the next ell's lists
     int cull_next;         // next block pair of the cull to hand out
     int ws_slot;           // pair slot of the launch whose work buffers this workgroup uses (its own, or the one of the pair it helps with)
@@ -438,6 +440,7 @@ struct Gates {
     float q_lim, q_il, q_ic;  // conservative f32 pre-test of a > sp before the double exps
     bool poly_ok;             // d2_thres/(2 l^2) <= 0.25: exponents of pairs inside the radius need no range reduction
 };
+static_assert(sizeof(Gates) <= sizeof(((Shared*)nullptr)->gates_store), "Shared::gates_store holds a Gates");
 
 // exp(x) in double for the only arguments the survivor path produces: the pre-test
 // bounds both exponents by q_lim (~0.22 with the reference's constants), so no range
@@ -1039,7 +1042,10 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
     if (tid == 0) {
         ell = sh->ell; Rb_l = sh->Rb; ell_b = sh->ell_build; skin_l = sh->P.skin; dense_l = sh->dense_mode;
         if (sh->rc_ell == ell) r_c = sh->rc;                        // the gate radius of this ell (a double-precision log): once per ell, not per iteration
-        else { r_c = sqrtf(gate_d2_align(ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma)); sh->rc = r_c; sh->rc_ell = ell; }
+        else {
+            r_c = sqrtf(gate_d2_align(ell, sh->P.sp_thres, sh->P.sigma * sh->P.sigma)); sh->rc = r_c; sh->rc_ell = ell;
+            *reinterpret_cast<Gates*>(sh->gates_store) = make_gates(ell, sh->P); sh->inv_c = 1 / sh->P.c; sh->inv_d = 1 / sh->P.d;   // (read behind this function's barriers)
+        }
     }
     if (tid == first_worker) {
         float* Mdst = keep_M_on_stop ? sh->Mn : sh->M;
@@ -2025,9 +2031,9 @@ CVO_PHASE_FN(8) void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in,
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = tid >> 6;
     const int nrows = c.nrows;
     const unsigned long long ts0 = CVO_NOW();
-    const Gates gates = make_gates(sh->ell, sh->P);
+    const Gates gates = *reinterpret_cast<const Gates*>(sh->gates_store);   // make_gates(sh->ell, sh->P), kept by the transform that precedes every walk at a new ell
     const bool dense_mode = sh->dense_mode != 0, fresh_list = sh->rebuild == 1;
-    const float inv_c = 1 / sh->P.c, inv_d = 1 / sh->P.d;
+    const float inv_c = sh->inv_c, inv_d = sh->inv_d;               // 1 / P.c, 1 / P.d
     const float ell_now = sh->ell;
     bool fused = false, shifted = false; float Rn_f = 0.f, alpha_f = 0.f, ell_f = 0.f, Mb_f[12], shift_f[12];
 #pragma unroll
