@@ -404,27 +404,35 @@ __device__ __forceinline__ bool group_exchange(Shared* sh, gu64* xch, int G, int
     }
     double tot = 0;
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    // four workgroups' granules per poll (a wave's 64 lanes = 4 x XCH_WORDS): one L2 round trip per four members, not one each
+    // four workgroups' granules per load (a wave's 64 lanes = 4 x XCH_WORDS), and the loads of up to sixteen members in flight together: ONE L2 round trip per
+    // poll for the whole group, not one per four members (round 5: the exchange of eight members took two round trips at least, twice per iteration)
     static_assert(2 * K <= XCH_WORDS && 4 * XCH_WORDS == 64, "granule layout");
     const int sub = lane >> 4, wrd = lane & 15;
-    for (int g0 = 0; g0 < G; g0 += 4) {
-        const bool mine = (g0 + sub < G) && (wrd < 2 * K);
-        unsigned long long x = 0;
+    for (int gq = 0; gq < G; gq += 16) {
+        unsigned long long x[4] = {0, 0, 0, 0};
+        bool mine[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[r] = (gq + 4 * r + sub < G) && (wrd < 2 * K);
         for (;;) {
             bool ok = true;
-            if (mine) {
-                x = __hip_atomic_load(&buf[(g0 + sub) * XCH_WORDS + wrd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (unsigned)(x >> 32) == epoch;
-            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (mine[r] && (unsigned)(x[r] >> 32) != epoch) x[r] = __hip_atomic_load(&buf[(gq + 4 * r + sub) * XCH_WORDS + wrd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ok = ok && (!mine[r] || (unsigned)(x[r] >> 32) == epoch);
             if (__all(ok)) break;
             if (__builtin_amdgcn_s_memrealtime() - t_start > 300000000ull) return false;   // 3 s at 100 MHz
             __builtin_amdgcn_s_sleep(1);
         }
-        const unsigned pay = (unsigned)x;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                               // members in workgroup order: the sum has one fixed order everywhere
-            const unsigned lo = __shfl(pay, (16 * i + 2 * lane) & 63, 64), hi = __shfl(pay, (16 * i + 2 * lane + 1) & 63, 64);
-            if (lane < K && g0 + i < G) tot += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        for (int r = 0; r < 4; ++r) {
+            if (gq + 4 * r >= G) break;                             // (wave-uniform)
+            const unsigned pay = (unsigned)x[r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                           // members in workgroup order: the sum has one fixed order everywhere
+                const unsigned lo = __shfl(pay, (16 * i + 2 * lane) & 63, 64), hi = __shfl(pay, (16 * i + 2 * lane + 1) & 63, 64);
+                if (lane < K && gq + 4 * r + i < G) tot += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            }
         }
     }
     if (lane < K) sh->vals[lane] = tot;
