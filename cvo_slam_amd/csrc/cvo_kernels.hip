@@ -977,6 +977,9 @@ __device__ __forceinline__ float4 load_y_rt(const Ctx& c, const Lds& L, int y_mo
 // built (exact displacement of the very positions the tests use); rebuild decision.  The first PRE_T points of a thread may
 // arrive pre-loaded (the epilogue of the previous iteration fetches them while one lane does the scalar work).
 constexpr int PRE_T = 4096 / BLOCK_MAX;
+#ifndef CVO_FUSE_PLANES
+#define CVO_FUSE_PLANES 1          // the epilogue's fused transform (begun before the second stop test is done, lane 0 off its critical path) also in the plane layout of large clouds
+#endif
 // first_worker = 64: wave 0 takes no points (the epilogue's lane 0 is still busy with the stop test of the iteration when the others start): the points are dealt
 // to threads first_worker .. nthreads - 1, `pre` as the caller loaded it with the same deal.  keep_M_on_stop: the transform was started before the stop test was
 // known; if the iteration turns out to be the pair's last, cvo::transform of that iteration (Shared::M, cvo.cpp:815) stays.
@@ -1005,7 +1008,7 @@ __device__ __forceinline__ void transform_body_t(const Ctx& c, const Lds& L, Sha
 #pragma unroll
         for (int i = 0; i < 12; ++i) M[i] = 0.f;
     }
-    if (worker && have_list && !have_preb) {
+    if (worker && have_list && (!have_preb || c.nm > PRE_T * wstride)) {   // (the points behind the pre-loaded ones have no pre-computed list position)
 #pragma unroll
         for (int i = 0; i < 12; ++i) Mb[i] = sh->Mb[i];
     } else {
@@ -2319,7 +2322,7 @@ CVO_PHASE_FN(2) void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, i
     // In the resident float4 layout waves 1 .. n-1 take all the points: they transform them while lane 0 of wave 0 is still at the second stop test (dist_se3,
     // a third of its scalar work), which the transform does not need -- only R and T.
     const bool next_T = k + 1 < max_iter;
-    const int first_worker = (y_lds == 1 && blockDim.x > 64 && sh->P.overlap_stop_test) ? 64 : 0;
+    const int first_worker = ((y_lds == 1 || (y_lds == 2 && CVO_FUSE_PLANES)) && blockDim.x > 64 && sh->P.overlap_stop_test) ? 64 : 0;
     float4 pre[PRE_T];
     {
         int j = (int)threadIdx.x >= first_worker ? (int)threadIdx.x - first_worker : c.nm;
@@ -2433,7 +2436,8 @@ CVO_PHASE_FN(2) void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, i
     if (first_worker && next_T) {
         // T of iteration k+1 (cvo.cpp:770-771), begun before this iteration's second stop test is known: should it fire, the transformed cloud is simply not
         // used (the state written back is R, T; Shared::M keeps the transform of the last executed iteration).  Its barriers publish lane 0's part B.
-        transform_body_t<1>(c, L, sh, pre, true, first_worker, true, sh->list_valid != 0, preb);
+        if (y_lds == 1) transform_body_t<1>(c, L, sh, pre, true, first_worker, true, sh->list_valid != 0, preb);
+        else transform_body_t<2>(c, L, sh, pre, true, first_worker, true, sh->list_valid != 0, preb);   // the 12-byte planes of large clouds (round 5: fused as well)
     } else {
         __syncthreads();                                             // sh->stop and the rest of lane 0's results, for everyone
         if (!sh->stop && next_T) {                                   // T of iteration k+1 (cvo.cpp:770-771)

@@ -313,6 +313,36 @@ def test_eth3d_shape_pair_tile_sweep(hiplib, oracle):
         g.close()
 
 
+@pytest.mark.parametrize("points", [3400, 3700, 4000, 5200])
+def test_clouds_between_the_layouts_keep_their_lists(hiplib, oracle, points):
+    """Clouds a little larger than the 3 k-point shape, one workgroup per pair: more points per thread than the epilogue pre-loads for the next
+    transform, and the sizes at which the resident layout changes.  Besides the oracle's pose, iteration count and nnz: the candidate lists are
+    rebuilt a few times per pair, not at every iteration (a staleness bound fed with a wrong list position for the points behind the pre-loaded ones
+    leaves every result right and takes three times as long)."""
+    from cvo_slam_amd import synth
+    p = synth.make_pair(3, cam=synth.ETH3D)
+    def thin(c):
+        idx = np.unique(np.linspace(0, c.n - 1, points).astype(np.int64))
+        return np.ascontiguousarray(c.xyz[idx]), np.ascontiguousarray(c.feat[:, idx])   # xyz (n, 3), features (5, n) as cvo::set_pcd takes them
+    fixed, moving = thin(p.fixed), thin(p.moving)
+    o = oracle.OracleCvo(search=oracle.SEARCH_KDTREE, threads=8)
+    o.set_pcd(*fixed); o.set_pcd(*moving); rc, _ = o.align(); assert rc == 0
+    ost = o.get_state()
+    for wgs in (1, 2):
+        b = hiplib.CvoBatch(1)
+        b.set_workgroups(wgs)
+        b.set_pairs([(fixed[0], fixed[1], moving[0], moving[1])])
+        b.reset_states(); b.align_async(1)
+        r = b.wait(1)[0]
+        assert r["status"] == 0, (points, wgs, r["status"])
+        re, te = rot_trans_err(r["transform"], ost["transform"])
+        assert re <= 1e-6 and te <= 1e-6, (points, wgs, re, te)
+        assert r["iter"] == ost["iter"] and r["A_nonzero"] == ost["A_nonzero"], (points, wgs)
+        masks, _ = b.last_cull_masks(1)
+        assert bin(masks[0]).count("1") <= 8, (points, wgs, bin(masks[0]))
+        b.close()
+
+
 # ----------------------------------------------------------------------------- scores
 def test_score_block_vs_oracle(hiplib, oracle):
     from cvo_slam_amd import synth
