@@ -55,11 +55,11 @@ def test_adoption_with_several_launches_in_flight(hiplib):
     for b in bs: b.close()
 
 
-@pytest.mark.parametrize("knobs", [dict(CVO_HIP_Y_MODE="2"), dict(CVO_HIP_RESORT="2"), dict(CVO_HIP_ADOPT_KMAX="1000"), dict(CVO_HIP_ADOPT_KMAX="0")])
+@pytest.mark.parametrize("knobs", [dict(CVO_HIP_Y_MODE="2"), dict(CVO_HIP_RESORT="2"), dict(CVO_HIP_ADOPT_KMAX="1000"), dict(CVO_HIP_ADOPT_KMAX="0"), dict(CVO_HIP_ADOPT_DWELL_US="50")])
 def test_adoption_under_other_layouts_and_cutoffs(hiplib, knobs):
     """Member regions and re-dealt rows under the 12-byte plane layout (the rebuild scratch lives inside the cull tile there), with
-    rows re-sorted at every list refinement, with helpers joining at any iteration and with no pair ever eligible: the bits of the
-    same batch without adoption."""
+    rows re-sorted at every list refinement, with helpers joining at any iteration, with no pair ever eligible, and with helpers that
+    wait for the device's queue to have been dry for a while before they offer themselves: the bits of the same batch without adoption."""
     import os
     from cvo_slam_amd import synth
     pairs = [synth.make_pair(200 + i) for i in range(16)]
