@@ -2971,6 +2971,102 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
 }
 
 
+// A workgroup whose pair is done looks for a pair of its launch that still runs alone and offers to help (cvo_align_kernel, adoption): wave 0 -- a lane per
+// slot looks, lane 0 asks.  Leaves the slot found (or -1) in sh->cand and the owner's answer in sh->adopt_k.  (A function of its own: the kernel's loop around
+// run_pair then keeps nothing in vector registers across its calls.)
+static __device__ __noinline__ void adopt_search(gu64* queue, const unsigned* wgs_submitted, unsigned* wgs_started, int slots_in, int slot_in, unsigned launch_tag_in) {
+    Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
+    const int tid = threadIdx.x, slots = uni(slots_in), slot = uni(slot_in);
+    const unsigned launch_tag = (unsigned)uni((int)launch_tag_in);
+    if (tid < 64) {                                           // wave 0: a lane per slot looks, lane 0 asks
+        int found = -1; unsigned kj = 0;
+        unsigned sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sub == sta && sh->P.adopt_dwell > 0) {                // dry right now: is it the end of the job, or the moment between a completion and the caller's next launch?
+            const unsigned long long t_dry = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t_dry < (unsigned long long)sh->P.adopt_dwell) {
+                __builtin_amdgcn_s_sleep(64);
+                sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sub != sta) break;                        // new work has been queued: leave, its workgroups want this CU
+            }
+        }
+        for (int attempt = 0; attempt < 4 && found < 0 && sub == sta; ++attempt) {
+            // the pair that runs alone and has the most left to do, as far as one can tell: the one with the fewest iterations behind it
+            unsigned key = 0xFFFFFFFFu;                     // iteration << 12 | slot
+            for (int s2 = tid; s2 < slots; s2 += 64) {
+                if (s2 == slot) continue;
+                const unsigned long long w = __hip_atomic_load(&queue[1 + s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w >> 32) == (launch_tag | ADOPT_FREE)) key = min(key, (min((unsigned)w, 0xFFFFFu) << 12) | (unsigned)s2);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, off, 64));
+            if (key == 0xFFFFFFFFu) break;                  // nobody runs alone any more
+            if ((key >> 12) >= (unsigned)sh->P.adopt_kmax) break; // every pair that runs alone is in its light late iterations: a second workgroup would cost it a list rebuild and gain it next to nothing
+            const int s2 = (int)(key & 0xFFFu);
+            int got = 0;                                    // lane 0: 1 accepted, 0 try again, -1 (unused)
+            if (tid == 0) {
+                unsigned long long w = __hip_atomic_load(&queue[1 + s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long want = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)blockIdx.x;
+                if ((unsigned)(w >> 32) == (launch_tag | ADOPT_FREE) &&
+                    __hip_atomic_compare_exchange_strong(&queue[1 + s2], &w, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {                              // the owner answers in its next epilogue
+                        const unsigned long long x = __hip_atomic_load(&queue[1 + s2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned st = (unsigned)(x >> 32) - launch_tag;
+                        if (st == ADOPT_ACCEPT) {              // payload: members after the join << 24 | this helper's index << 16 | iteration of the join
+                            // confirm at once (a CAS: the owner takes the acceptance back when no confirmation comes, and only one of the two can win)
+                            unsigned long long e = x;
+                            if (sh->P.adopt_inject != 1 &&
+                                __hip_atomic_compare_exchange_strong(&queue[1 + s2], &e, ((unsigned long long)(launch_tag | ADOPT_CONFIRMED) << 32) | (unsigned)x,
+                                                                     __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = 1; kj = (unsigned)x; }
+                            break;
+                        }
+                        if (st != ADOPT_REQUEST) break;     // the pair ended meanwhile
+                        if (__builtin_amdgcn_s_memrealtime() - t_start > 200000ull) {   // 2 ms: take the offer back -- unless it has just been accepted
+                            unsigned long long e = want;
+                            const unsigned long long free_w = (unsigned long long)(launch_tag | ADOPT_FREE) << 32;
+                            if (__hip_atomic_compare_exchange_strong(&queue[1 + s2], &e, free_w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+            }
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got == 1) found = s2;
+        }
+        if (tid == 0) { sh->cand = found; sh->adopt_k = kj; }
+    }
+}
+
+// The next pair of a launch with fewer slots than pairs (cvo_align_kernel, the in-kernel queue): the slot's first workgroup takes the next index and passes it on
+// to the slot's other workgroups; leaves it in sh->cand.
+static __device__ __noinline__ void queue_pull(gu64* queue, int slot_in, int g_in, int G_in, unsigned launch_tag_in, unsigned pull_in) {
+    Shared* sh = reinterpret_cast<Shared*>(cvo_smem);
+    const int tid = threadIdx.x, slot = uni(slot_in), g = uni(g_in), G = uni(G_in);
+    const unsigned launch_tag = (unsigned)uni((int)launch_tag_in), pull = (unsigned)uni((int)pull_in);
+    if (tid == 0) {
+        unsigned long long got = 0;
+        const unsigned long long seq = (unsigned long long)(launch_tag | (pull + 1u)) << 32;
+        if (g == 0) {
+            unsigned long long old = __hip_atomic_load(&queue[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nw;
+            do { nw = ((unsigned)(old >> 32) == launch_tag) ? old + 1ull : (((unsigned long long)launch_tag << 32) | 1ull); }
+            while (!__hip_atomic_compare_exchange_strong(&queue[0], &old, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            got = ((unsigned)(old >> 32) == launch_tag) ? (old & 0xFFFFFFFFull) : 0ull;
+            if (G > 1) __hip_atomic_store(&queue[1 + slot], seq | got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 8 bytes: the data is its own flag
+        } else {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const unsigned long long x = __hip_atomic_load(&queue[1 + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((x >> 32) == (seq >> 32)) { got = x & 0xFFFFFFFFull; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t_start > 300000000ull) { got = 0xFFFFFFFFull; break; }   // 3 s: give up, leave
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        sh->cand = (int)min(got, (unsigned long long)0x7FFFFFFF);   // (re-initialised below for the pair)
+    }
+}
+
 __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD) void cvo_align_kernel(const PairDesc* __restrict__ descs, int n_pairs, int G, int tile, int y_lds, int rows_cap, int y_cap,
                                                                          unsigned launch_tag, int tab_cols, unsigned long long* __restrict__ queue_in, DevParams P,
                                                                          const unsigned* wgs_submitted /* host-mapped */, unsigned* wgs_started,
@@ -3008,91 +3104,14 @@ __global__ __launch_bounds__(BLOCK_MAX, BLOCK_MAX > 512 ? 1 : CVO_WAVES_PER_SIMD
             if (!adopt_launch) break;
             // this workgroup's pair is done.  With nothing queued on the device (every workgroup submitted so far has started), look for
             // a pair of the launch that still runs alone and offer to help; leave when there is none.
-            if (tid < 64) {                                           // wave 0: a lane per slot looks, lane 0 asks
-                int found = -1; unsigned kj = 0;
-                unsigned sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                unsigned sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sub == sta && P.adopt_dwell > 0) {                // dry right now: is it the end of the job, or the moment between a completion and the caller's next launch?
-                    const unsigned long long t_dry = __builtin_amdgcn_s_memrealtime();
-                    while (__builtin_amdgcn_s_memrealtime() - t_dry < (unsigned long long)P.adopt_dwell) {
-                        __builtin_amdgcn_s_sleep(64);
-                        sub = __hip_atomic_load(wgs_submitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        sta = __hip_atomic_load(wgs_started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (sub != sta) break;                        // new work has been queued: leave, its workgroups want this CU
-                    }
-                }
-                for (int attempt = 0; attempt < 4 && found < 0 && sub == sta; ++attempt) {
-                    // the pair that runs alone and has the most left to do, as far as one can tell: the one with the fewest iterations behind it
-                    unsigned key = 0xFFFFFFFFu;                     // iteration << 12 | slot
-                    for (int s2 = tid; s2 < slots; s2 += 64) {
-                        if (s2 == slot) continue;
-                        const unsigned long long w = __hip_atomic_load(&queue[1 + s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(w >> 32) == (launch_tag | ADOPT_FREE)) key = min(key, (min((unsigned)w, 0xFFFFFu) << 12) | (unsigned)s2);
-                    }
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, off, 64));
-                    if (key == 0xFFFFFFFFu) break;                  // nobody runs alone any more
-                    if ((key >> 12) >= (unsigned)P.adopt_kmax) break; // every pair that runs alone is in its light late iterations: a second workgroup would cost it a list rebuild and gain it next to nothing
-                    const int s2 = (int)(key & 0xFFFu);
-                    int got = 0;                                    // lane 0: 1 accepted, 0 try again, -1 (unused)
-                    if (tid == 0) {
-                        unsigned long long w = __hip_atomic_load(&queue[1 + s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long want = ((unsigned long long)(launch_tag | ADOPT_REQUEST) << 32) | (unsigned)blockIdx.x;
-                        if ((unsigned)(w >> 32) == (launch_tag | ADOPT_FREE) &&
-                            __hip_atomic_compare_exchange_strong(&queue[1 + s2], &w, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                            for (;;) {                              // the owner answers in its next epilogue
-                                const unsigned long long x = __hip_atomic_load(&queue[1 + s2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                                const unsigned st = (unsigned)(x >> 32) - launch_tag;
-                                if (st == ADOPT_ACCEPT) {              // payload: members after the join << 24 | this helper's index << 16 | iteration of the join
-                                    // confirm at once (a CAS: the owner takes the acceptance back when no confirmation comes, and only one of the two can win)
-                                    unsigned long long e = x;
-                                    if (P.adopt_inject != 1 &&
-                                        __hip_atomic_compare_exchange_strong(&queue[1 + s2], &e, ((unsigned long long)(launch_tag | ADOPT_CONFIRMED) << 32) | (unsigned)x,
-                                                                             __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = 1; kj = (unsigned)x; }
-                                    break;
-                                }
-                                if (st != ADOPT_REQUEST) break;     // the pair ended meanwhile
-                                if (__builtin_amdgcn_s_memrealtime() - t_start > 200000ull) {   // 2 ms: take the offer back -- unless it has just been accepted
-                                    unsigned long long e = want;
-                                    const unsigned long long free_w = (unsigned long long)(launch_tag | ADOPT_FREE) << 32;
-                                    if (__hip_atomic_compare_exchange_strong(&queue[1 + s2], &e, free_w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                                }
-                                __builtin_amdgcn_s_sleep(8);
-                            }
-                        }
-                    }
-                    got = __builtin_amdgcn_readfirstlane(got);
-                    if (got == 1) found = s2;
-                }
-                if (tid == 0) { sh->cand = found; sh->adopt_k = kj; }
-            }
+            adopt_search(queue, wgs_submitted, wgs_started, slots, slot, launch_tag);
             __syncthreads();
             p = sh->cand;
             { const unsigned kj = sh->adopt_k; k_join = kj & 0xFFFFu; ge = (int)((kj >> 16) & 0xFFu); Ge = (int)(kj >> 24); }
             __syncthreads();
             if (p < 0) break;
         } else {
-            if (tid == 0) {
-                unsigned long long got = 0;
-                const unsigned long long seq = (unsigned long long)(launch_tag | (pull + 1u)) << 32;
-                if (g == 0) {
-                    unsigned long long old = __hip_atomic_load(&queue[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nw;
-                    do { nw = ((unsigned)(old >> 32) == launch_tag) ? old + 1ull : (((unsigned long long)launch_tag << 32) | 1ull); }
-                    while (!__hip_atomic_compare_exchange_strong(&queue[0], &old, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    got = ((unsigned)(old >> 32) == launch_tag) ? (old & 0xFFFFFFFFull) : 0ull;
-                    if (G > 1) __hip_atomic_store(&queue[1 + slot], seq | got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 8 bytes: the data is its own flag
-                } else {
-                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                    for (;;) {
-                        const unsigned long long x = __hip_atomic_load(&queue[1 + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((x >> 32) == (seq >> 32)) { got = x & 0xFFFFFFFFull; break; }
-                        if (__builtin_amdgcn_s_memrealtime() - t_start > 300000000ull) { got = 0xFFFFFFFFull; break; }   // 3 s: give up, leave
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                sh->cand = (int)min(got, (unsigned long long)0x7FFFFFFF);   // (re-initialised below for the pair)
-            }
+            queue_pull(queue, slot, g, G, launch_tag, pull);
             __syncthreads();
             p = sh->cand;
             __syncthreads();
