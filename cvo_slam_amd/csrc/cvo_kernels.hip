@@ -176,7 +176,7 @@ struct __attribute__((aligned(16))) Shared {
     unsigned long long nnz_total;   // nonzeros of A so far (PairState::nonzeros_total)
 #ifdef CVO_KTRACE
     unsigned long long ksub[4];  // experiment builds: line-search walk, line-search reduction, epilogue scalar part, epilogue transform (ticks, this iteration)
-    unsigned long long kabs[12];  // CVO_KTRACE_EPI == 2: absolute times inside the epilogue (lane 0: part A done, part B done, staleness maximum there, decision made; thread 64: past the first barrier, its points done)
+    unsigned long long kabs[16];  // CVO_KTRACE_EPI == 2: absolute times inside the epilogue (lane 0: part A done, part B done, staleness maximum there, decision made; thread 64: past the first barrier, its points done)
 #endif
     float omega[3];        // this iteration's twist (f32, cvo.cpp:234-235)
     float v[3];
@@ -839,6 +839,19 @@ __device__ __forceinline__ float wave_max(float v) {
 extern __shared__ __attribute__((aligned(16))) unsigned char cvo_smem[];
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Issue priority of this wave by what it has left to do (r = units of work behind the current one; wave-uniform).  A SIMD issues for its OLDEST ready wave first:
+// of the two or three waves that share one, the oldest runs ahead and finishes early, and the youngest walks its last blocks alone -- a single wave fills
+// little more than half of the SIMD's issue slots.  With the wave that has more left ranked higher, the waves of a SIMD reach their (short) last blocks
+// together: the walk of one pair alone ends 5-8 % earlier (profiles/r05_wave_priority_ab.txt).  With every CU busy the gain is gone (the lone wave's
+// stalls are memory stalls then): on in the three-wave build only.  s_setprio takes an immediate.
+#ifndef CVO_WAVE_PRIO
+#define CVO_WAVE_PRIO (CVO_BLOCK_MAX > 512)   // measured: one pair alone walks 5-8 % faster either way; under load +0.6 % with three waves per SIMD (config 5), -0.7 % with two
+#endif
+__device__ __forceinline__ void prio_by_remaining(int r) {
+#if CVO_WAVE_PRIO
+    if (r >= 3) __builtin_amdgcn_s_setprio(3); else if (r == 2) __builtin_amdgcn_s_setprio(2); else if (r == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 __device__ __forceinline__ float uni_f(float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
 template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
@@ -1574,6 +1587,7 @@ __device__ __forceinline__ void cand_steady(const Ctx& c, const Lds& L, Shared* 
         for (int u = 0; u < PF / 2; ++u) ehead[u] = ld_ent2<(NT && ENT_NT(YM))>(at_off(eb0, (unsigned)lane + (unsigned)u * rp));
     }
     for (int bi = 0; bi < nb; ++bi) {
+        prio_by_remaining(uni(nb) - 1 - bi);
         const int blk = wave_block(bi, wave, nwaves);
         const int slot = blk * 64 + lane;
         const int len = L.lenS[slot];
@@ -1708,6 +1722,7 @@ __device__ __forceinline__ void cand_fresh(const Ctx& c, const Lds& L, Shared* s
     const Exp7 e7 = make_exp7(gates);
 #endif
     for (int bi = 0; bi < nb; ++bi) {
+        prio_by_remaining(uni(nb) - 1 - bi);
         const int blk = wave_block(bi, wave, nwaves);
         const int slot = blk * 64 + lane;
         const int len = L.lenS[slot];
@@ -2167,6 +2182,9 @@ CVO_PHASE_FN(8) void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in,
         }
     }
     const unsigned long long ts2 = CVO_NOW();
+#ifdef CVO_KTRACE_WAVES   // experiment builds: when every wave left its walk (ticks since the walk's start), for the trace row written by run_pair
+    if (lane == 0) sh->kabs[wave] = ts2 - ts1;
+#endif
     // (no barrier before the reduction: its own barrier is the one every wave reaches after its walk)
     const double mine = dense_mode ? block_reduce<8, 8, false>(acc8, sh, tid, nwaves) : block_reduce<8, 6, false>(acc8, sh, tid, nwaves);   // list mode: nnz and candidates are per-wave counts in lane 0
     const unsigned long long ts3 = CVO_NOW();
@@ -2252,6 +2270,7 @@ CVO_PHASE_FN(1) void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in,
 #pragma unroll
             for (int u = 0; u < RD; ++u) ring[u] = ld_rec(&sp[min(lane + 64 * u, cnt_w - 1)]);
             for (int q0 = lane; q0 < cnt_w; q0 += 64 * RD) {
+                prio_by_remaining((cnt_w - uni(q0)) >> 11);        // units of eight trips (2048 records): the waves' shares are near equal, the one with more left goes first
 #pragma unroll
                 for (int u = 0; u < RD; ++u) {
                     const int q = q0 + 64 * u;
@@ -2857,6 +2876,13 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
             // omega = candidate phase (prologue, row walk, wait + reduction), v = line-search walk, its reduction, epilogue scalar part; step = fused transform
             tr.omega[0] = (float)(sh->sub[0] - ksub_prev[0]); tr.omega[1] = (float)(sh->sub[1] - ksub_prev[1]); tr.omega[2] = (float)(sh->sub[2] - ksub_prev[2]);
             tr.v[0] = (float)sh->ksub[0]; tr.v[1] = (float)sh->ksub[1]; tr.v[2] = (float)sh->ksub[2]; tr.step = (float)sh->ksub[3];
+#ifdef CVO_KTRACE_WAVES
+            {   // omega = min / mean / max over the waves of the walk's end, v[0] = wave 0's, v[1] = the latest wave's index
+                unsigned long long mn = ~0ull, mx = 0, sm = 0; int wmx = 0; const int nw = (int)blockDim.x >> 6;
+                for (int w = 0; w < nw; ++w) { const unsigned long long t = sh->kabs[w]; mn = t < mn ? t : mn; if (t > mx) { mx = t; wmx = w; } sm += t; }
+                tr.omega[0] = (float)mn; tr.omega[1] = (float)(sm / (unsigned long long)nw); tr.omega[2] = (float)mx; tr.v[0] = (float)sh->kabs[0]; tr.v[1] = (float)wmx;
+            }
+#endif
 #if defined(CVO_KTRACE_EPI) && CVO_KTRACE_EPI == 2
             tr.omega[0] = (float)sh->kabs[6]; tr.omega[1] = (float)sh->kabs[7]; tr.omega[2] = (float)sh->kabs[4]; tr.ell = (float)sh->kabs[10]; tr.dist = (float)sh->kabs[11];
 #endif
