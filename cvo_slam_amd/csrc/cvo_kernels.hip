@@ -796,7 +796,11 @@ __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float
 // broadcast); a lane carries SWEEP_R rows (consecutive 64-row blocks) so one read feeds
 // SWEEP_R tests.
 constexpr int SWEEP_R = 2;
+#ifndef CVO_CULL_SPLIT
+#define CVO_CULL_SPLIT 1           // phase_cull: single 64-row blocks as units of work when block pairs are scarce (one pair on many workgroups)
+#endif
 
+template <int NR = SWEEP_R>                                    // NR = 1: the lane's first row only (phase_cull's single-block units); w[1] is left at 0
 __device__ __forceinline__ void sweep_group(const float* lx, const float* ly, const float* lz, int c0 /* wave-uniform */,
                                             const float (&x)[SWEEP_R][3], const float (&nthr)[SWEEP_R], uint32_t (&w)[SWEEP_R]) {
     const float4* qx = reinterpret_cast<const float4*>(lx + c0);
@@ -811,7 +815,7 @@ __device__ __forceinline__ void sweep_group(const float* lx, const float* ly, co
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int r = 0; r < SWEEP_R; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 const float dx = x[r][0] - cx[u], dy = x[r][1] - cy[u], dz = x[r][2] - cz[u];
                 const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nthr[r])));
                 w[r] = __builtin_amdgcn_alignbit(w[r], __float_as_uint(t), 31);
@@ -1249,11 +1253,16 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
         // Block pairs are handed out as the waves come for them: a pair's cost follows the hits of its 128 rows (near surfaces have several
         // times the neighbours of far ones) and a fixed deal of three pairs per wave left the workgroup waiting for the unluckiest wave.  A
         // row's list is made by one lane in column order whichever wave runs it: the lists do not depend on the order.
+        // With fewer block pairs than half the waves (one pair on eight workgroups: three block pairs for eight waves) a unit of work is ONE 64-row block: the
+        // lane's second row is padding and is not swept, twice the waves take part, each with half the arithmetic and only the groups near its own 64 rows.
+        const int halves = (CVO_CULL_SPLIT && nblk2 * 2 <= (nthreads >> 6)) ? 2 : 1;
+        auto units = [&](auto single_t) {
         for (;;) {
-            int b2 = 0;
-            if (lane == 0) b2 = atomicAdd(&sh->cull_next, 1);
-            b2 = uni(b2);
-            if (b2 >= nblk2) break;
+            int unit = 0;
+            if (lane == 0) unit = atomicAdd(&sh->cull_next, 1);
+            unit = uni(unit);
+            if (unit >= nblk2 * halves) break;
+            constexpr bool single = decltype(single_t)::value;      // true: the unit is 64-row block `unit`, the lane's row 0; its row 1 is padding
             float x[SWEEP_R][3]; int li[SWEEP_R]; int cnt[SWEEP_R];
             float nthr[SWEEP_R];                                    // - (the row's list radius)^2
             float Rrow = Rb * inv_1ma;                              // the widest radius of the wave's rows
@@ -1261,9 +1270,9 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             float blo[4] = {INF, INF, INF, INF}, bhi[4] = {-INF, -INF, -INF, -INF};
 #pragma unroll
             for (int r = 0; r < SWEEP_R; ++r) {
-                li[r] = (b2 * SWEEP_R + r) * 64 + lane;
+                li[r] = single ? unit * 64 + lane : (unit * SWEEP_R + r) * 64 + lane;
                 nthr[r] = -(Rrow * Rrow * 1.00001f);
-                if (li[r] < nrows) {
+                if (li[r] < nrows && (!single || r == 0)) {
                     const float4 lo4 = ld4(c.fixed + lo_off(global_row(c, li[r])));
                     x[r][0] = lo4.x; x[r][1] = lo4.y; x[r][2] = lo4.z;
                     if (alpha > 0.f) {
@@ -1313,7 +1322,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                     const int gi = gb + __builtin_ctzll(mask);
                     mask &= mask - 1ull;
                     uint32_t w[SWEEP_R];
-                    sweep_group(colx, coly, colz, gi * 32, x, nthr, w);
+                    if (single) sweep_group<1>(colx, coly, colz, gi * 32, x, nthr, w); else sweep_group<SWEEP_R>(colx, coly, colz, gi * 32, x, nthr, w);
                     const uint32_t col0 = (uint32_t)(t0 + gi * 32);
                     // bit 31 = first column of the group: ascending columns.  Up to four hits per row leave the words per trip (the loop runs as
                     // long as the fullest row of the wave needs: a trip per hit was more than half of the cull) and go into the rows' 8-byte
@@ -1358,6 +1367,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             }
 #pragma unroll
             for (int r = 0; r < SWEEP_R; ++r) {
+                if (single && r != 0) continue;                     // (padding)
                 if ((cnt[r] & 3) && cnt[r] < c.capn) {              // the partial word (capn is a multiple of 4: a full list never leaves one)
                     v2u w; w.x = (unsigned)buf[r]; w.y = (unsigned)(buf[r] >> 32);
                     st_jt(&c.jT4[(size_t)(cnt[r] >> 2) * c.rows_pad + li[r]], w);
@@ -1365,6 +1375,8 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
                 rowlen[li[r]] = (uint16_t)cnt[r];                   // rowlen has room for the padding rows of the last block pair
             }
         }
+        };
+        if (halves == 2) units(std::true_type{}); else units(std::false_type{});   // (two instances: the common path keeps its code and registers)
     }
     if (again) predicted = false;
     } while (again);
