@@ -1191,6 +1191,9 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
             predicted = true;
         }
     }
+#ifdef CVO_KTRACE_CULL
+    if (tid == 0) sh->kabs[0] = CVO_NOW();
+#endif
     const bool planes = y_lds == 2;                                 // columns come straight from the resident y planes: one pass over the whole cloud
     const int span = planes ? max(c.nm, 1) : tile;
     const float* colx = planes ? L.ysx : L.lx; const float* coly = planes ? L.ysy : L.ly; const float* colz = planes ? L.ysz : L.lz;
@@ -1244,6 +1247,9 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
         }
         if (tid == 0) sh->cull_next = 0;
         __syncthreads();
+#ifdef CVO_KTRACE_CULL
+        if (tid == 0) sh->kabs[1] = CVO_NOW();
+#endif
         if (predicted) {
             // (all of the cloud is in this one tile when the prediction is on: tile >= nm is required below)
             off_l = block_max(off_l, sh, tid, nthreads >> 6);
@@ -1380,6 +1386,11 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     }
     if (again) predicted = false;
     } while (again);
+#ifdef CVO_KTRACE_CULL
+    if (tid == 0) sh->kabs[2] = CVO_NOW();
+    __syncthreads();
+    if (tid == 0) sh->kabs[3] = CVO_NOW();
+#endif
     if (alpha > 0.f) xmax_l = block_max(xmax_l, sh, tid, nthreads >> 6);
     if (tid == 0) {
         sh->Rb = Rb; sh->alpha_build = alpha; sh->xmax = xmax_l; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1;
@@ -2888,6 +2899,9 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
             // omega = candidate phase (prologue, row walk, wait + reduction), v = line-search walk, its reduction, epilogue scalar part; step = fused transform
             tr.omega[0] = (float)(sh->sub[0] - ksub_prev[0]); tr.omega[1] = (float)(sh->sub[1] - ksub_prev[1]); tr.omega[2] = (float)(sh->sub[2] - ksub_prev[2]);
             tr.v[0] = (float)sh->ksub[0]; tr.v[1] = (float)sh->ksub[1]; tr.v[2] = (float)sh->ksub[2]; tr.step = (float)sh->ksub[3];
+#ifdef CVO_KTRACE_CULL
+            tr.omega[0] = (float)(sh->kabs[1] - sh->kabs[0]); tr.omega[1] = (float)(sh->kabs[2] - sh->kabs[1]); tr.omega[2] = (float)(sh->kabs[3] - sh->kabs[2]); tr.v[0] = (float)(CVO_NOW() - sh->kabs[3]);
+#endif
 #ifdef CVO_KTRACE_WAVES
             {   // omega = min / mean / max over the waves of the walk's end, v[0] = wave 0's, v[1] = the latest wave's index
                 unsigned long long mn = ~0ull, mx = 0, sm = 0; int wmx = 0; const int nw = (int)blockDim.x >> 6;
