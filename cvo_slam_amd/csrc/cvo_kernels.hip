@@ -122,7 +122,7 @@ struct __attribute__((aligned(16))) Shared {
     float alpha_build;     // ... and the depth-proportional part of the margin they were built (or last filtered) with: row i holds every column within
                            // (Rb + alpha_build |x_i|) / (1 - alpha_build) of it (DevParams::skin_alpha)
     float reach;           // phase_transform -> phase_refine: how far the points are from where they were listed, beyond what the lists allow for by themselves
-    float xmax;            // largest |x_i| of this workgroup's rows (phase_cull)
+    float xmax;            // largest |x_i| of the pair's rows (phase_cull; of this workgroup's rows when it is the pair's only one)
     int predicted;         // culls of this pair whose lists were built around extrapolated positions (diagnostics)
     float skin0, alpha0;   // the launch's list margins (a pair that falls back to the dense-scene margin changes P.skin / P.skin_alpha for itself)
     int twist_ok;          // omega, v, step below are those of the pair's previous iteration (set by this workgroup's own candidate phase and epilogue)
@@ -796,6 +796,9 @@ __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float
 // broadcast); a lane carries SWEEP_R rows (consecutive 64-row blocks) so one read feeds
 // SWEEP_R tests.
 constexpr int SWEEP_R = 2;
+#ifndef CVO_PAIR_XMAX
+#define CVO_PAIR_XMAX 1            // phase_cull: the farthest row that bounds later list margins is the pair's, not the member's (members rebuild their lists together)
+#endif
 #ifndef CVO_CULL_SPLIT
 #define CVO_CULL_SPLIT 1           // phase_cull: single 64-row blocks as units of work when block pairs are scarce (one pair on many workgroups)
 #endif
@@ -1391,6 +1394,15 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
     __syncthreads();
     if (tid == 0) sh->kabs[3] = CVO_NOW();
 #endif
+    // The margins that later list refinements may take (phase_refine, the filtering walk) depend on the farthest row.  A pair's members must agree on them -- a
+    // member with near rows only would give itself a wider margin, find its lists stale at another iteration than the others and rebuild alone, with every other
+    // member waiting for it in the exchange (seen: 67 us of one pair's 1.6 ms) -- so the farthest row is the PAIR's, whichever workgroup owns it.
+    if (alpha > 0.f && c.G > 1 && CVO_PAIR_XMAX) {
+        for (int i = tid; i < c.nf; i += nthreads) {
+            const float4 lo4 = ld4(c.fixed + lo_off(i));
+            xmax_l = fmaxf(xmax_l, sqrtf(__builtin_fmaf(lo4.z, lo4.z, __builtin_fmaf(lo4.y, lo4.y, lo4.x * lo4.x))));
+        }
+    }
     if (alpha > 0.f) xmax_l = block_max(xmax_l, sh, tid, nthreads >> 6);
     if (tid == 0) {
         sh->Rb = Rb; sh->alpha_build = alpha; sh->xmax = xmax_l; sh->ell_build = sh->ell; sh->list_valid = 1; sh->rebuilds += 1;
