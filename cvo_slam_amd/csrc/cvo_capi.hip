@@ -751,8 +751,10 @@ struct Engine {
             // lowest latency of this launch alone: as many workgroups per pair as the CUs allow, but not below ~384 rows per
             // workgroup -- a row's list is walked by one lane, so beyond one 64-row block per wave nothing gets shorter while the
             // partial-sum exchanges keep costing (measured at 3072 points: 2.37 ms at 4, 2.33 at 8, 2.44 at 16, 2.78 at 32, 4.9 at 1)
-            const int rows_min = 384 * (align_block_max() / 512);
-            int want = 1; while (want * 2 * rows_min <= nf_max && want < 32) want *= 2;
+            // (round 5: at most ~384 rows per workgroup, not at least -- a cloud of 2 817 points, what the generator makes of a 640 x 480 frame, took 4 workgroups
+            // of 704 rows where 8 of 352 align it in 1.20 ms instead of 1.37: scripts/r05/probe_tracker_g.py)
+            const int rows_max = 384 * (align_block_max() / 512);
+            const int want = std::max(1, std::min(32, (nf_max + rows_max - 1) / rows_max));
             G = 1; while (G * 2 * n_pairs <= num_cus * per_cu && G < want) G *= 2;
         }
         const int g_min = (((nf_max + 127) / 128) + (MAX_ROWS_PER_WG / 128) - 1) / (MAX_ROWS_PER_WG / 128);   // a workgroup owns at most MAX_ROWS_PER_WG rows, dealt in blocks of 128
