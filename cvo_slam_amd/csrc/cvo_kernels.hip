@@ -796,6 +796,12 @@ __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float
 // broadcast); a lane carries SWEEP_R rows (consecutive 64-row blocks) so one read feeds
 // SWEEP_R tests.
 constexpr int SWEEP_R = 2;
+#ifndef CVO_LS_EVEN_MIN
+#define CVO_LS_EVEN_MIN 512        // ... when the workgroup has at least this many records per wave
+#endif
+#ifndef CVO_LS_EVEN
+#define CVO_LS_EVEN 1              // phase_linesearch: every wave an equal share of the workgroup's nonzero records (0 = the segment it compacted itself)
+#endif
 #ifndef CVO_PAIR_XMAX
 #define CVO_PAIR_XMAX 1            // phase_cull: the farthest row that bounds later list margins is the pair's, not the member's (members rebuild their lists together)
 #endif
@@ -2250,7 +2256,8 @@ CVO_PHASE_FN(8) void phase_candidates(const PairDesc* Dp_in, int g_in, int G_in,
 }
 
 // ---- L: compute_step_size sums (cvo.cpp:239-315); f64 terms, one lane per nonzero
-CVO_PHASE_FN(1) void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
+template <bool EVEN>
+__device__ __forceinline__ void linesearch_body(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) {
     const PairDesc* Dp = uni_ptr(Dp_in); const int g = uni(g_in), G = uni(G_in), tgeo = uni(tile_in), y_lds = uni(y_lds_in), k = uni(k_in);
     const Lds L = lds_layout(tgeo, y_lds); Shared* sh = L.sh;
     const Ctx c = make_ctx(Dp, g, G);
@@ -2273,10 +2280,16 @@ CVO_PHASE_FN(1) void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in,
         // near equal, and a wave's segment is one contiguous run
         const bool x_lds = sh->x_lds != 0;
         const int wave = tid >> 6;
-        const int cnt_w = sh->wcnt[wave];
         int cnt_wg = 0;
         for (int w = 0; w < nwaves; ++w) cnt_wg += sh->wcnt[w];
-        const gv2u* sp = c.surv + c.fbase + (size_t)sh->wbase[wave];
+        // The workgroup's nonzeros lie in one segment per wave of the candidate walk (whose rows are dealt so that the segments are near equal -- when every wave
+        // had blocks to walk: a member of a pair on eight workgroups owns six blocks for eight waves, the first twice as long as the last).  The sums are order-free
+        // (cvo.cpp:309-314): every wave takes an EQUAL share of the records, wherever they lie -- a stretch of one segment, or the end of one and the start of the next.
+        // (Only where the deal could not balance -- fewer than two blocks per wave -- and there is enough to share: with the waves' segments near equal, or a few
+        // hundred records in all, a second stretch per wave costs more than it evens out: -1.5 % under load, +5 % on a tracker's frame, measured.)
+        constexpr bool even = EVEN;                                   // (decided by the caller: ls_even_shares)
+        const int share_lo = (int)(((long long)cnt_wg * wave) / nwaves), share_hi = (int)(((long long)cnt_wg * (wave + 1)) / nwaves);
+        int cnt_w = 0; const gv2u* sp = c.surv + c.fbase;             // the stretch being walked (set per segment below)
         // With several nonzeros per column the last quarter of the point part ({2*z4, |z2|^2 + 2 z1.z3}: 33 of a nonzero's ~120
         // instructions) is tabulated once per iteration, 16 bytes per column in LDS over the rebuild scratch.  (Tabulating all of
         // the point part was measured: its four 16-byte gathers per nonzero make the LDS the bottleneck -- 88 against 118 cycles
@@ -2330,8 +2343,24 @@ CVO_PHASE_FN(1) void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in,
             }
         };
         using T1 = std::true_type; using T0 = std::false_type;
-        if (use_table) { if (y_lds == 1) walk(std::integral_constant<int, 1>{}, T1{}); else walk(std::integral_constant<int, 2>{}, T1{}); }
-        else if (y_lds == 1) walk(std::integral_constant<int, 1>{}, T0{}); else if (y_lds == 2) walk(std::integral_constant<int, 2>{}, T0{}); else walk(std::integral_constant<int, 0>{}, T0{});
+        auto dispatch = [&]() {
+            if (use_table) { if (y_lds == 1) walk(std::integral_constant<int, 1>{}, T1{}); else walk(std::integral_constant<int, 2>{}, T1{}); }
+            else if (y_lds == 1) walk(std::integral_constant<int, 1>{}, T0{}); else if (y_lds == 2) walk(std::integral_constant<int, 2>{}, T0{}); else walk(std::integral_constant<int, 0>{}, T0{});
+        };
+        if (!even) {                                                   // the wave's own segment (the common path: as it always was)
+            cnt_w = sh->wcnt[wave]; sp = c.surv + c.fbase + (size_t)sh->wbase[wave];
+            dispatch();
+        } else {
+            int seg_first = 0;                                         // records before segment s, in the order of the waves
+            for (int s = 0; s < nwaves; ++s) {
+                const int seg_n = uni((int)sh->wcnt[s]);
+                const int lo = max(share_lo, seg_first) - seg_first, hi = min(share_hi, seg_first + seg_n) - seg_first;
+                seg_first += seg_n;
+                if (lo >= hi) continue;
+                cnt_w = hi - lo; sp = c.surv + c.fbase + (size_t)sh->wbase[s] + lo;
+                if (use_table) walk(std::integral_constant<int, 1>{}, T1{}); else walk(std::integral_constant<int, 1>{}, T0{});   // (the resident float4 layout only: two instances more, not five)
+            }
+        }
     } else {
         const Gates gates = make_gates(sh->ell, sh->P);
         for (int li = tid; li < c.nrows; li += nthreads) {
@@ -2366,6 +2395,20 @@ CVO_PHASE_FN(1) void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in,
         __syncthreads();                                             // sh->status is read by every thread right after the phase
     }
 }
+
+// every wave an equal share of the workgroup's nonzero records instead of the segment it compacted itself?  Where the deal could not balance the segments (fewer than
+// two blocks per wave: a member of a pair on many workgroups) and there is enough to share; the resident float4 layout only.
+__device__ __forceinline__ bool ls_even_shares(int y_lds) {
+    const Shared* sh = reinterpret_cast<const Shared*>(cvo_smem);
+    const int nwaves = (int)blockDim.x >> 6;
+    if (!CVO_LS_EVEN || y_lds != 1 || sh->dense_mode || ((sh->ctx_nrows + 63) >> 6) >= 2 * nwaves) return false;
+    int cnt_wg = 0;
+    for (int w = 0; w < nwaves; ++w) cnt_wg += sh->wcnt[w];
+    return cnt_wg >= CVO_LS_EVEN_MIN * nwaves;
+}
+CVO_PHASE_FN(1) void phase_linesearch(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) { linesearch_body<false>(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in); }
+// (a function of its own whatever the build: the common path's function does not carry its code)
+static __device__ __noinline__ void phase_linesearch_even(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in) { linesearch_body<true>(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in); }
 
 // ---- E: one lane finishes the iteration (every workgroup of the pair computes the same bits)
 CVO_PHASE_FN(2) void phase_epilogue(const PairDesc* Dp_in, int g_in, int G_in, int tile_in, int y_lds_in, int k_in, int max_iter_in) {
@@ -2525,7 +2568,7 @@ static __device__ __noinline__ void phase_iteration(const PairDesc* Dp_in, int g
     if (tid == 0) { atomicAdd(&sh->cand_total, (unsigned long long)sh->cand); atomicAdd(&sh->nnz_total, (unsigned long long)sh->nnz); }
     { const unsigned long long t_now = CVO_NOW(); if (tid == 0) atomicAdd(&sh->ticks[1], t_now - t_prev); t_prev = t_now; }
     if (sh->status != 0) return;
-    phase_linesearch(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in);
+    if (ls_even_shares(uni(y_lds_in))) phase_linesearch_even(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in); else phase_linesearch(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in);
     { const unsigned long long t_now = CVO_NOW(); if (tid == 0) atomicAdd(&sh->ticks[3], t_now - t_prev); t_prev = t_now; }
     if (sh->status != 0) return;
     phase_epilogue(Dp_in, g_in, G_in, tile_in, y_lds_in, k_in, max_iter_in);
@@ -2896,7 +2939,7 @@ static __device__ __noinline__ void run_pair(const PairDesc* descs_in, int ps_in
         if (tid == 0) { atomicAdd(&sh->cand_total, (unsigned long long)sh->cand); atomicAdd(&sh->nnz_total, (unsigned long long)sh->nnz); }
         CVO_PHASE(1);
         if (sh->status != 0) break;
-        phase_linesearch(Dp, ge, Ge, tgeo, y_lds, k);
+        if (ls_even_shares(y_lds)) phase_linesearch_even(Dp, ge, Ge, tgeo, y_lds, k); else phase_linesearch(Dp, ge, Ge, tgeo, y_lds, k);
         CVO_PHASE(3);
         if (sh->status != 0) break;
         phase_epilogue(Dp, ge, Ge, tgeo, y_lds, k, max_iter);
