@@ -270,7 +270,7 @@ DevParams to_dev(const cvo_params& p) {
     d.overlap_stop_test = 1;
     d.predict = 0.7f; d.predict_steps = 8.f;   // lists built / filtered 0.7 of every point's allowance ahead on the path: -10 % culls, +1 % (profiles/r04_predicted_list_centres.txt)
     d.resort = 1;
-    d.adopt_kmax = 20; d.adopt_on = 0; d.adopt_inject = 0; d.adopt_dwell = 0;
+    d.adopt_kmax = 40; d.adopt_on = 0; d.adopt_inject = 0; d.adopt_dwell = 0;
     d.colocate = 1;
     return d;
 }
