@@ -1270,7 +1270,7 @@ static __device__ __noinline__ void phase_cull(const PairDesc* Dp_in, int g_in, 
         // row's list is made by one lane in column order whichever wave runs it: the lists do not depend on the order.
         // With fewer block pairs than half the waves (one pair on eight workgroups: three block pairs for eight waves) a unit of work is ONE 64-row block: the
         // lane's second row is padding and is not swept, twice the waves take part, each with half the arithmetic and only the groups near its own 64 rows.
-        const int halves = (CVO_CULL_SPLIT && nblk2 * 2 <= (nthreads >> 6)) ? 2 : 1;
+        const int halves = (CVO_CULL_SPLIT == 2 || (CVO_CULL_SPLIT && nblk2 * 2 <= (nthreads >> 6))) ? 2 : 1;   // (CVO_CULL_SPLIT=2, experiment builds: always)
         auto units = [&](auto single_t) {
         for (;;) {
             int unit = 0;
