@@ -796,6 +796,9 @@ __device__ __forceinline__ void ls_terms(const float* xi, const float4 yj, float
 // broadcast); a lane carries SWEEP_R rows (consecutive 64-row blocks) so one read feeds
 // SWEEP_R tests.
 constexpr int SWEEP_R = 2;
+#ifndef CVO_LS_TAB_FACTOR
+#define CVO_LS_TAB_FACTOR 4        // phase_linesearch: the per-column table is made when the workgroup has more than this many nonzeros per column
+#endif
 #ifndef CVO_LS_EVEN_MIN
 #define CVO_LS_EVEN_MIN 512        // ... when the workgroup has at least this many records per wave
 #endif
@@ -2294,7 +2297,7 @@ __device__ __forceinline__ void linesearch_body(const PairDesc* Dp_in, int g_in,
         // instructions) is tabulated once per iteration, 16 bytes per column in LDS over the rebuild scratch.  (Tabulating all of
         // the point part was measured: its four 16-byte gathers per nonzero make the LDS the bottleneck -- 88 against 118 cycles
         // per 64 nonzeros -- and two table passes need the records binned by column in the candidate phase; one gather does not.)
-        const bool use_table = sh->tab_cols >= c.nm && cnt_wg > 4 * c.nm && y_lds != 0;
+        const bool use_table = sh->tab_cols >= c.nm && cnt_wg > CVO_LS_TAB_FACTOR * c.nm && y_lds != 0;
         if (use_table) {
             for (int j = tid; j < c.nm; j += nthreads) {
                 const float4 yj = y_lds == 1 ? load_y<1>(c, L, j) : load_y<2>(c, L, j);
